@@ -1,0 +1,391 @@
+// Batch-norm kernels for NHWC bf16 activations viewed as [M, C] (HBM-bound, 16-byte vectors).
+// Reductions are two-level and atomics-free: per-block partials [blocks][2][C] (the same layout the
+// conv epilogue emits) followed by a tiny finalize that sums the partials in fp64.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_FLOATS = 4096;  // 2 stats x 256 threads x 8 lanes
+
+struct RowTiling {
+  int vcols;      // C / 8
+  int vcb;        // vector columns handled concurrently (<= 256)
+  int rpb;        // row lanes per block
+  int rows_per_block;
+  int blocks;
+};
+
+RowTiling make_tiling(int M, int C) {
+  RowTiling t;
+  t.vcols = C / 8;
+  t.vcb = t.vcols < 256 ? t.vcols : 256;
+  t.rpb = 256 / t.vcb;
+  int rows = cdiv(M, 2048);
+  rows = cdiv(rows, t.rpb) * t.rpb;
+  if (rows < t.rpb * 4) rows = t.rpb * 4;
+  t.rows_per_block = rows;
+  t.blocks = cdiv(M, rows);
+  return t;
+}
+
+// ---- generic two-stat reduction over rows ------------------------------------------------------
+// MODE 0: (sum x, sum x^2)            inputs: a = x
+// MODE 1: (sum dz, sum dz * xhat)     inputs: a = dy, b = x, c = yout (ReLU mask, optional)
+template <int MODE>
+__global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                        const bf16_t* __restrict__ c, int relu, int M, int C,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, RowTiling t,
+                                                        float* __restrict__ partial) {
+  __shared__ float red[RED_FLOATS];
+  const int tid = threadIdx.x;
+  const int vc0 = tid % t.vcb;
+  const int rr = tid / t.vcb;
+  const bool active = rr < t.rpb;
+  const int row_begin = blockIdx.x * t.rows_per_block;
+  const int row_end = min(M, row_begin + t.rows_per_block);
+  for (int vcbase = 0; vcbase < t.vcols; vcbase += t.vcb) {
+    const int vc = vcbase + vc0;
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    if (active && vc < t.vcols) {
+      float mu[8], is[8];
+      if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          mu[e] = mean[vc * 8 + e];
+          is[e] = invstd[vc * 8 + e];
+        }
+      }
+      for (int row = row_begin + rr; row < row_end; row += t.rpb) {
+        const size_t off = (size_t)row * C + vc * 8;
+        const u32x4 va = *reinterpret_cast<const u32x4*>(a + off);
+        float fa[8];
+        unpack8(va, fa);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s[e] += fa[e];
+            ss[e] += fa[e] * fa[e];
+          }
+        } else {
+          const u32x4 vb = *reinterpret_cast<const u32x4*>(b + off);
+          float fb[8];
+          unpack8(vb, fb);
+          if (relu) {
+            const u32x4 vy = *reinterpret_cast<const u32x4*>(c + off);
+            float fy[8];
+            unpack8(vy, fy);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[e] = fy[e] > 0.f ? fa[e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s[e] += fa[e];
+            ss[e] += fa[e] * ((fb[e] - mu[e]) * is[e]);
+          }
+        }
+      }
+    }
+    // cross row-lane reduction through LDS: red[stat][rr][vc0*8+e]
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(0 * t.rpb + rr) * (t.vcb * 8) + vc0 * 8 + e] = s[e];
+        red[(1 * t.rpb + rr) * (t.vcb * 8) + vc0 * 8 + e] = ss[e];
+      }
+    }
+    __syncthreads();
+    const int ncol = t.vcb * 8;
+    for (int i = tid; i < 2 * ncol; i += 256) {
+      const int which = i / ncol, col = i - which * ncol;
+      float acc = 0.f;
+      for (int r = 0; r < t.rpb; ++r) acc += red[(which * t.rpb + r) * ncol + col];
+      const int ch = vcbase * 8 + col;
+      if (ch < C) partial[((size_t)blockIdx.x * 2 + which) * C + ch] = acc;
+    }
+  }
+}
+
+// ---- finalize: partials -> per-channel statistics / coefficients --------------------------------
+// block = 16 channels x 16 partial-lanes
+__device__ __forceinline__ void sum_partials(const float* partial, int blocks, int C, int ch, int ry,
+                                             double& s0, double& s1) {
+  s0 = 0.0;
+  s1 = 0.0;
+  if (ch < C)
+    for (int b = ry; b < blocks; b += 16) {
+      s0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
+      s1 += (double)partial[((size_t)b * 2 + 1) * C + ch];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, int M, int C,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          float* moving_mean, float* moving_var, float* mean,
+                                                          float* invstd, float* scale, float* shift) {
+  __shared__ double red[2][16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cx;
+  double s0, s1;
+  sum_partials(partial, blocks, C, ch, ry, s0, s1);
+  red[0][ry][cx] = s0;
+  red[1][ry][cx] = s1;
+  __syncthreads();
+  if (ry == 0 && ch < C) {
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < 16; ++r) {
+      a += red[0][r][cx];
+      b += red[1][r][cx];
+    }
+    const double mu = a / (double)M;
+    double var = b / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[ch] * is;
+    mean[ch] = (float)mu;
+    invstd[ch] = is;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - (float)mu * sc;
+    if (moving_mean) {
+      const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+      moving_mean[ch] = moving_mean[ch] * momentum + (float)mu * (1.f - momentum);
+      moving_var[ch] = moving_var[ch] * momentum + (float)unbiased * (1.f - momentum);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int M,
+                                                              int C, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* dgamma,
+                                                              float* dbeta, float* coefA, float* coefB,
+                                                              float* coefC) {
+  __shared__ double red[2][16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cx;
+  double s0, s1;
+  sum_partials(partial, blocks, C, ch, ry, s0, s1);
+  red[0][ry][cx] = s0;
+  red[1][ry][cx] = s1;
+  __syncthreads();
+  if (ry == 0 && ch < C) {
+    double db = 0.0, dg = 0.0;
+    for (int r = 0; r < 16; ++r) {
+      db += red[0][r][cx];
+      dg += red[1][r][cx];
+    }
+    dbeta[ch] = (float)db;
+    dgamma[ch] = (float)dg;
+    const double g = gamma[ch], is = invstd[ch], mu = mean[ch];
+    const double A = g * is;
+    const double B = -g * is * is * dg / (double)M;
+    const double Cc = -g * is * db / (double)M - B * mu;
+    coefA[ch] = (float)A;
+    coefB[ch] = (float)B;
+    coefC[ch] = (float)Cc;
+  }
+}
+
+__global__ void bn_infer_coeffs_kernel(int C, const float* gamma, const float* beta, const float* mm,
+                                       const float* mv, float eps, float* scale, float* shift) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch < C) {
+    const float is = 1.0f / sqrtf(mv[ch] + eps);
+    const float sc = gamma[ch] * is;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - mm[ch] * sc;
+  }
+}
+
+// ---- apply: y = [relu](x*scale + shift [+ residual]) ---------------------------------------------
+template <int RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       size_t nvec, int C, FastDiv fd_vcols,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const bf16_t* __restrict__ res, FastDiv fd_w, FastDiv fd_h,
+                                                       int H, int W) {
+  const int vcols = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const unsigned m = fd_div((unsigned)i, fd_vcols);
+    const int vc = (int)((unsigned)i - m * (unsigned)vcols);
+    const u32x4 vx = *reinterpret_cast<const u32x4*>(x + i * 8);
+    float f[8];
+    unpack8(vx, f);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + vc * 8);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + vc * 8 + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + vc * 8);
+    const f32x4 h1 = *reinterpret_cast<const f32x4*>(shift + vc * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[e] = f[e] * s0[e] + h0[e];
+      f[e + 4] = f[e + 4] * s1[e] + h1[e];
+    }
+    if (RES != 0) {
+      size_t ri;
+      if (RES == 1) {
+        ri = i * 8;
+      } else {
+        const unsigned nh = fd_div(m, fd_w);
+        const unsigned w = m - nh * (unsigned)W;
+        const unsigned n = fd_div(nh, fd_h);
+        const unsigned h = nh - n * (unsigned)H;
+        ri = ((((size_t)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * vcols + vc) * 8;
+      }
+      const u32x4 vr = *reinterpret_cast<const u32x4*>(res + ri);
+      float r[8];
+      unpack8(vr, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += r[e];
+    }
+    if (RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+    }
+    *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+  }
+}
+
+// ---- backward apply: dx = A*dz + B*x + C ; dz = dy * [yout > 0] -----------------------------------
+template <bool RELU, bool WRITE_DZ>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                           const bf16_t* __restrict__ yout, size_t nvec, int C,
+                                                           FastDiv fd_vcols, const float* __restrict__ cA,
+                                                           const float* __restrict__ cB,
+                                                           const float* __restrict__ cC, bf16_t* __restrict__ dx,
+                                                           bf16_t* __restrict__ dz) {
+  const int vcols = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const unsigned m = fd_div((unsigned)i, fd_vcols);
+    const int vc = (int)((unsigned)i - m * (unsigned)vcols);
+    float g[8], fx[8];
+    unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
+    unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), fx);
+    if (RELU) {
+      float fy[8];
+      unpack8(*reinterpret_cast<const u32x4*>(yout + i * 8), fy);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = fy[e] > 0.f ? g[e] : 0.f;
+    }
+    if (WRITE_DZ) *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(g);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = vc * 8 + e;
+      o[e] = cA[ch] * g[e] + cB[ch] * fx[e] + cC[ch];
+    }
+    *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(o);
+  }
+}
+
+inline unsigned ew_grid(size_t nvec) {
+  size_t b = cdivz(nvec, 256);
+  return (unsigned)(b < 4096 ? (b ? b : 1) : 4096);
+}
+
+}  // namespace
+
+extern "C" int asm_bn_stats_blocks(int M, int C) {
+  if (M <= 0 || C <= 0 || C % 8) return ASM_EINVAL;
+  return make_tiling(M, C).blocks;
+}
+
+extern "C" int asm_bn_stats(const void* x, int M, int C, float* stats_partial, void* stream) {
+  ASM_REQUIRE(x && stats_partial && M > 0 && C > 0 && C % 8 == 0, "bn_stats: bad arguments (M=%d C=%d)", M, C);
+  RowTiling t = make_tiling(M, C);
+  hipLaunchKernelGGL((rowreduce_kernel<0>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, nullptr, nullptr, 0, M, C, nullptr, nullptr, t, stats_partial);
+  ASM_CHECK_LAUNCH("bn_stats");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_finalize(const float* stats_partial, int blocks, int M, int C, const float* gamma,
+                               const float* beta, float eps, float momentum, float* moving_mean,
+                               float* moving_var, float* mean, float* invstd, float* scale, float* shift,
+                               void* stream) {
+  ASM_REQUIRE(stats_partial && gamma && beta && mean && invstd && scale && shift && blocks > 0 && M > 0 && C > 0,
+              "bn_finalize: bad arguments");
+  ASM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must both be given");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, stats_partial,
+                     blocks, M, C, gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift);
+  ASM_CHECK_LAUNCH("bn_finalize");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_infer_coeffs(int C, const float* gamma, const float* beta, const float* moving_mean,
+                                   const float* moving_var, float eps, float* scale, float* shift, void* stream) {
+  ASM_REQUIRE(C > 0 && gamma && beta && moving_mean && moving_var && scale && shift, "bn_infer_coeffs: bad arguments");
+  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+                     moving_mean, moving_var, eps, scale, shift);
+  ASM_CHECK_LAUNCH("bn_infer_coeffs");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift,
+                            const void* residual, int res_mode, int relu, int H, int W, void* stream) {
+  ASM_REQUIRE(x && y && scale && shift && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
+  ASM_REQUIRE(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bn_apply: bad residual mode");
+  ASM_REQUIRE((size_t)M * (C / 8) < 0x7fffffffull, "bn_apply: tensor too large");
+  if (res_mode == 2)
+    ASM_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && M % (H * W) == 0, "bn_apply: bad upsample geometry");
+  const size_t nvec = (size_t)M * (C / 8);
+  const FastDiv fv = make_fastdiv((unsigned)(C / 8));
+  const FastDiv fw = make_fastdiv((unsigned)(W > 0 ? W : 1)), fh = make_fastdiv((unsigned)(H > 0 ? H : 1));
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(ew_grid(nvec)), block(256);
+#define LAUNCH_APPLY(RES, RELU)                                                                          \
+  hipLaunchKernelGGL((bn_apply_kernel<RES, RELU>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, nvec, C, fv, \
+                     scale, shift, (const bf16_t*)residual, fw, fh, H, W)
+  if (res_mode == 0) { if (relu) LAUNCH_APPLY(0, true); else LAUNCH_APPLY(0, false); }
+  else if (res_mode == 1) { if (relu) LAUNCH_APPLY(1, true); else LAUNCH_APPLY(1, false); }
+  else { if (relu) LAUNCH_APPLY(2, true); else LAUNCH_APPLY(2, false); }
+#undef LAUNCH_APPLY
+  ASM_CHECK_LAUNCH("bn_apply");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_bwd_reduce(const void* dy, const void* x, const void* yout, int relu, int M, int C,
+                                 const float* mean, const float* invstd, float* partial, void* stream) {
+  ASM_REQUIRE(dy && x && mean && invstd && partial && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
+  ASM_REQUIRE(!relu || yout, "bn_bwd_reduce: relu mask needs the forward output");
+  RowTiling t = make_tiling(M, C);
+  hipLaunchKernelGGL((rowreduce_kernel<1>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)x, (const bf16_t*)yout, relu, M, C, mean, invstd, t, partial);
+  ASM_CHECK_LAUNCH("bn_bwd_reduce");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_bwd_finalize(const float* partial, int blocks, int M, int C, const float* gamma,
+                                   const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                   float* coefA, float* coefB, float* coefC, void* stream) {
+  ASM_REQUIRE(partial && gamma && mean && invstd && dgamma && dbeta && coefA && coefB && coefC && blocks > 0,
+              "bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, blocks,
+                     M, C, gamma, mean, invstd, dgamma, dbeta, coefA, coefB, coefC);
+  ASM_CHECK_LAUNCH("bn_bwd_finalize");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout, int relu, int M, int C,
+                                const float* coefA, const float* coefB, const float* coefC, void* dx,
+                                void* dz_out, void* stream) {
+  ASM_REQUIRE(dy && x && dx && coefA && coefB && coefC && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad arguments");
+  ASM_REQUIRE(!relu || yout, "bn_bwd_apply: relu mask needs the forward output");
+  ASM_REQUIRE((size_t)M * (C / 8) < 0x7fffffffull, "bn_bwd_apply: tensor too large");
+  const size_t nvec = (size_t)M * (C / 8);
+  const FastDiv fv = make_fastdiv((unsigned)(C / 8));
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(ew_grid(nvec)), block(256);
+#define LAUNCH_BWD(RELU, DZ)                                                                              \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<RELU, DZ>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, \
+                     (const bf16_t*)yout, nvec, C, fv, coefA, coefB, coefC, (bf16_t*)dx, (bf16_t*)dz_out)
+  if (relu) { if (dz_out) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
+  else { if (dz_out) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
+#undef LAUNCH_BWD
+  ASM_CHECK_LAUNCH("bn_bwd_apply");
+  return ASM_OK;
+}

@@ -1,0 +1,100 @@
+// Shared device/host helpers for libasm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/asm_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- error plumbing -------------------------------------------------------------------------
+void asm_set_error(const char* fmt, ...);
+#define ASM_FAIL(code, ...)      \
+  do {                           \
+    asm_set_error(__VA_ARGS__);  \
+    return (code);               \
+  } while (0)
+#define ASM_REQUIRE(cond, ...)                  \
+  do {                                          \
+    if (!(cond)) ASM_FAIL(ASM_EINVAL, __VA_ARGS__); \
+  } while (0)
+#define ASM_CHECK_LAUNCH(name)                                                       \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) ASM_FAIL(ASM_EHIP, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- bf16 <-> f32 ----------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+// round-to-nearest-even; lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// 8 bf16 (one 16-byte vector) <-> 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+  f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+  f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+// ---- wave / block reductions -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- invariant integer division (n < 2^31) --------------------------------------------------------
+struct FastDiv {
+  unsigned mul, shr, d;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) {
+    f.mul = 0;
+    f.shr = 0;
+    return f;
+  }
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shr = s;
+  f.mul = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned fd_div(unsigned n, const FastDiv& f) {
+  return (__umulhi(n, f.mul) + n) >> f.shr;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// buffer resource for raw (stride 0) access: out-of-range offsets load 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+#define ASM_OOB 0x80000000u

@@ -1,0 +1,285 @@
+// MFMA weight-gradient kernel for gfx950 (split-K over output pixels, deterministic slab reduce).
+//
+//   dW[n][t][c] = sum_m  dY[m][n] * X[gather(m, t)][c]          m = (img, ho, wo)
+//
+// GEMM view: rows = output channels n (128 / block), columns j = (tap t, channel c) flattened
+// (128 / block), reduction = pixels (64 per step).  Both operands arrive "reduction-major"
+// ([pixel][channel], channel contiguous) which is the transpose of what an MFMA fragment needs
+// (8 consecutive reduction elements per lane), so the fragments are read from LDS with gfx950's
+// transposing ds_read_b64_tr_b16: every 16-lane group reads a 4(pixel) x 16(channel) block and
+// receives one channel column per lane.  LDS rows are XOR-swizzled in 16-byte chunks by
+// (pixel & 3) so the four pixel rows a transposing read touches sit on disjoint banks.
+//
+// Each block accumulates a 128 x 128 fp32 tile over its pixel range and writes it to a slab
+// [split][Co][cols]; asm_wgrad_reduce sums the slabs in a fixed order (no atomics ->
+// bit-reproducible).  With one split the tile goes straight to dW.
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+  const void* dy;
+  const void* x;
+  float* out;  // slab base (or dW when splits == 1)
+  unsigned dy_bytes, x_bytes;
+  int M;
+  int Hi, Wi, Ci;
+  int Co, ldy;
+  int R, S, so, pad;
+  int x_img_pitch, x_row_pitch, x_pix_pitch;
+  int cols;  // R*S*Ci
+  int tiles_n, tiles_c, splits;
+  int m_per_split;  // multiple of 64
+  FastDiv fd_howo, fd_wo;
+  int HoWo, Wo;
+};
+
+constexpr int WT = 128;   // tile edge (channels)
+constexpr int WPX = 64;   // pixels per step
+constexpr int WROWB = WT * 2;
+constexpr int WTILE = WPX * WROWB;  // 16 KiB per operand per stage
+
+__device__ __forceinline__ bf16x4 ds_read_tr(const unsigned char* p) {
+  typedef __attribute__((ext_vector_type(4))) short s4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s4*)(const_cast<unsigned char*>(p)));
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WTILE];  // 2 stages x (dy, x)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1;
+
+  // block -> (split, tile_n, tile_c): tiles of one split adjacent (they re-read the same pixels)
+  int bid = blockIdx.x;
+  const int tiles = p.tiles_n * p.tiles_c;
+  const int split = bid / tiles;
+  bid -= split * tiles;
+  const int tile_n = bid / p.tiles_c;
+  const int tile_c = bid - tile_n * p.tiles_c;
+
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+
+  const int chunk = tid & 15;  // 16-byte chunk (8 channels) within the 128-channel tile row
+  const int prow = tid >> 4;   // pixel row 0..15 (+16 per pass)
+
+  // this thread's fixed column group of the x tile: tap + channel
+  const int j0 = tile_c * WT + chunk * 8;
+  const bool col_ok = j0 < p.cols;
+  int tap_r = 0, tap_s = 0, tap_c = 0;
+  if (col_ok) {
+    const int t = j0 / p.Ci;
+    tap_c = j0 - t * p.Ci;
+    tap_r = t / p.S;
+    tap_s = t - tap_r * p.S;
+  }
+  const int n0 = tile_n * WT + chunk * 8;
+  const bool n_ok = n0 < p.Co;
+
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int steps = (m_end - m_begin + WPX - 1) / WPX;
+
+  u32x4 ry[4], rxv[4];
+  auto load_tile = [&](int step) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m_begin + step * WPX + prow + 16 * j;
+      const bool mok = m < m_end;
+      const unsigned offy = ((unsigned)m * (unsigned)p.ldy + (unsigned)n0) * 2u;
+      ry[j] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (mok && n_ok) ? offy : ASM_OOB, 0, 0);
+      const unsigned um = mok ? (unsigned)m : 0u;
+      const unsigned img = fd_div(um, p.fd_howo);
+      const unsigned rem = um - img * (unsigned)p.HoWo;
+      const unsigned ho = fd_div(rem, p.fd_wo);
+      const unsigned wo = rem - ho * (unsigned)p.Wo;
+      const int ih = (int)ho * p.so + tap_r - p.pad;
+      const int iw = (int)wo * p.so + tap_s - p.pad;
+      const bool ok = mok && col_ok && ((unsigned)ih < (unsigned)p.Hi) && ((unsigned)iw < (unsigned)p.Wi);
+      const unsigned offx = (img * (unsigned)p.x_img_pitch + (unsigned)ih * (unsigned)p.x_row_pitch +
+                             (unsigned)iw * (unsigned)p.x_pix_pitch + (unsigned)tap_c) * 2u;
+      rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? offx : ASM_OOB, 0, 0);
+    }
+  };
+  auto store_tile = [&](int stage) {
+    unsigned char* ys = smem + stage * 2 * WTILE;
+    unsigned char* xs = ys + WTILE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = prow + 16 * j;
+      const int sc = (chunk ^ ((row & 3) << 2)) << 4;
+      *reinterpret_cast<u32x4*>(ys + row * WROWB + sc) = ry[j];
+      *reinterpret_cast<u32x4*>(xs + row * WROWB + sc) = rxv[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  if (steps > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  // transposing-read lane geometry (32x32x16 fragment: channel = lane&31, reduction group = lane>>5)
+  const int t16 = lane & 15;          // lane within its 16-lane group
+  const int g = lane >> 4;            // group 0..3
+  const int colsel = (g & 1) * 16;    // which 16 of the fragment's 32 channels
+  const int pgrp = (g >> 1) * 8;      // reduction offset 0 / 8
+  const int trow = t16 >> 2;          // pixel row within the 4-row block (== (row & 3))
+  const int tcol = (t16 & 3) * 4;     // channel offset of this lane's 4-element source
+
+  for (int step = 0; step < steps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < steps) load_tile(step + 1);
+    const unsigned char* ys = smem + cur * 2 * WTILE;
+    const unsigned char* xs = ys + WTILE;
+#pragma unroll
+    for (int kk = 0; kk < WPX / 16; ++kk) {
+      bf16x8 fy[2], fx[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int cy = wn * 64 + a * 32 + colsel + tcol;  // channel (element) index in the dy row
+        const int cx = wc * 64 + a * 32 + colsel + tcol;
+        bf16x4 y0, y1, x0, x1;
+        {
+          const int row = kk * 16 + pgrp + trow;
+          const int sw = (trow << 2);
+          y0 = ds_read_tr(ys + row * WROWB + ((((cy >> 3) ^ sw) << 4) | ((cy & 4) << 1)));
+          x0 = ds_read_tr(xs + row * WROWB + ((((cx >> 3) ^ sw) << 4) | ((cx & 4) << 1)));
+          const int row2 = row + 4;
+          y1 = ds_read_tr(ys + row2 * WROWB + ((((cy >> 3) ^ sw) << 4) | ((cy & 4) << 1)));
+          x1 = ds_read_tr(xs + row2 * WROWB + ((((cx >> 3) ^ sw) << 4) | ((cx & 4) << 1)));
+        }
+        fy[a] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+        fx[a] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
+    }
+    if (step + 1 < steps) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[i = n_local][j = col_local]: col = lane&31, n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* out = p.out + (size_t)split * p.Co * p.cols;
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = tile_c * WT + wc * 64 + b * 32 + l31;
+      if (col < p.cols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = tile_n * WT + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (n < p.Co) out[(size_t)n * p.cols + col] = acc[a][b][r];
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, float* dw, size_t n,
+                                                           int splits) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(slab + i);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slab + (size_t)k * n + i);
+    *reinterpret_cast<f32x4*>(dw + i) = s;
+  } else {
+    for (size_t e = i; e < n; ++e) {
+      float s = slab[e];
+      for (int k = 1; k < splits; ++k) s += slab[(size_t)k * n + e];
+      dw[e] = s;
+    }
+  }
+}
+
+struct Plan {
+  int tiles_n, tiles_c, splits, m_per_split;
+};
+
+Plan make_plan(const asm_conv_desc* d) {
+  Plan pl;
+  const int M = d->N * d->Ho * d->Wo;
+  const int cols = d->R * d->S * d->C;
+  pl.tiles_n = cdiv(d->K, WT);
+  pl.tiles_c = cdiv(cols, WT);
+  const int tiles = pl.tiles_n * pl.tiles_c;
+  const int msteps = cdiv(M, WPX);
+  int splits = cdiv(512, tiles);           // ~2 resident blocks per CU
+  splits = splits < 1 ? 1 : splits;
+  const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;  // at least 4 steps per block
+  if (splits > max_splits) splits = max_splits;
+  int steps_per = cdiv(msteps, splits);
+  pl.m_per_split = steps_per * WPX;
+  pl.splits = cdiv(M, pl.m_per_split);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d) {
+  if (!d) return 0;
+  Plan pl = make_plan(d);
+  if (pl.splits <= 1) return 0;
+  return (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float);
+}
+
+extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const void* dy, float* dw,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  ASM_REQUIRE(d && x && dy && dw, "conv wgrad: null pointer");
+  ASM_REQUIRE(d->C % 8 == 0, "conv wgrad: C=%d must be a multiple of 8", d->C);
+  ASM_REQUIRE(d->stride == 1 || d->stride == 2, "conv wgrad: stride %d not supported", d->stride);
+  const int ldy = d->ldy ? d->ldy : d->K;
+  ASM_REQUIRE(ldy % 8 == 0 && ldy >= d->K, "conv wgrad: dy row stride %d must be a multiple of 8", ldy);
+  const int64_t img_p = d->x_img_pitch ? d->x_img_pitch : (int64_t)d->H * d->W * d->C;
+  const int64_t xelems = (int64_t)d->N * img_p;
+  const int64_t dyelems = (int64_t)d->N * d->Ho * d->Wo * ldy;
+  ASM_REQUIRE(xelems * 2 < (int64_t)ASM_OOB && dyelems * 2 < (int64_t)ASM_OOB, "conv wgrad: tensor larger than 2 GiB");
+  Plan pl = make_plan(d);
+  const size_t need = asm_conv2d_wgrad_workspace_bytes(d);
+  ASM_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "conv wgrad: workspace too small (%zu < %zu)",
+              workspace_bytes, need);
+  WgradArgs a;
+  a.dy = dy; a.x = x;
+  a.out = pl.splits > 1 ? reinterpret_cast<float*>(workspace) : dw;
+  a.dy_bytes = (unsigned)(dyelems * 2);
+  a.x_bytes = (unsigned)(xelems * 2);
+  a.M = d->N * d->Ho * d->Wo;
+  a.Hi = d->H; a.Wi = d->W; a.Ci = d->C;
+  a.Co = d->K; a.ldy = ldy;
+  a.R = d->R; a.S = d->S; a.so = d->stride; a.pad = d->pad;
+  a.x_img_pitch = (int)img_p;
+  a.x_row_pitch = d->x_row_pitch ? d->x_row_pitch : d->W * d->C;
+  a.x_pix_pitch = d->x_pix_pitch ? d->x_pix_pitch : d->C;
+  a.cols = d->R * d->S * d->C;
+  a.tiles_n = pl.tiles_n; a.tiles_c = pl.tiles_c; a.splits = pl.splits; a.m_per_split = pl.m_per_split;
+  a.HoWo = d->Ho * d->Wo; a.Wo = d->Wo;
+  a.fd_howo = make_fastdiv((unsigned)a.HoWo);
+  a.fd_wo = make_fastdiv((unsigned)a.Wo);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(pl.tiles_n * pl.tiles_c * pl.splits), dim3(256), 0, st, a);
+  ASM_CHECK_LAUNCH("wgrad_kernel");
+  if (pl.splits > 1) {
+    const size_t n = (size_t)d->K * a.cols;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 1024)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(workspace), dw, n, pl.splits);
+    ASM_CHECK_LAUNCH("wgrad_reduce_kernel");
+  }
+  return ASM_OK;
+}

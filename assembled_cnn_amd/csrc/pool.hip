@@ -1,0 +1,482 @@
+// Pooling / resampling kernels (NHWC bf16, one thread = one output pixel x 8 channels).
+// All are HBM-bound gathers with fp32 accumulation; backward passes are written in gather form
+// (each input pixel sums the outputs whose window covers it) so there are no atomics.
+#include "common.h"
+
+namespace {
+
+inline unsigned grid_for(size_t nvec) {
+  size_t b = cdivz(nvec, 256);
+  return (unsigned)(b ? b : 1);
+}
+
+__device__ __forceinline__ u32x4 ldv(const bf16_t* p, size_t elem_off) {
+  return *reinterpret_cast<const u32x4*>(p + elem_off);
+}
+
+// decode flat vector index -> (n, h, w, vc)
+struct Pix {
+  int n, h, w, vc;
+};
+__device__ __forceinline__ Pix decode(size_t i, int H, int W, int vcols) {
+  Pix p;
+  p.vc = (int)(i % vcols);
+  size_t m = i / vcols;
+  p.w = (int)(m % W);
+  m /= W;
+  p.h = (int)(m % H);
+  p.n = (int)(m / H);
+  return p;
+}
+
+// ---- max pool 3x3 / 2, SAME (pad 0 before, up to 1 after) ---------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                          uint8_t* __restrict__ amax, int N, int H, int W, int C,
+                                                          int Ho, int Wo, int pad_h, int pad_w) {
+  const int vcols = C >> 3;
+  const size_t nvec = (size_t)N * Ho * Wo * vcols;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const Pix p = decode(i, Ho, Wo, vcols);
+  float best[8];
+  int bidx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    best[e] = -INFINITY;
+    bidx[e] = 0;
+  }
+  for (int r = 0; r < 3; ++r) {
+    const int ih = p.h * 2 + r - pad_h;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    for (int s = 0; s < 3; ++s) {
+      const int iw = p.w * 2 + s - pad_w;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      float f[8];
+      unpack8(ldv(x, (((size_t)p.n * H + ih) * W + iw) * C + p.vc * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (f[e] > best[e]) {  // strict: first maximum in window scan order wins
+          best[e] = f[e];
+          bidx[e] = r * 3 + s;
+        }
+    }
+  }
+  *reinterpret_cast<u32x4*>(y + i * 8) = pack8(best);
+  if (amax) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo |= (unsigned)bidx[e] << (8 * e);
+      hi |= (unsigned)bidx[e + 4] << (8 * e);
+    }
+    u32x2 v = {lo, hi};
+    *reinterpret_cast<u32x2*>(amax + i * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                          const uint8_t* __restrict__ amax, bf16_t* __restrict__ dx,
+                                                          int N, int H, int W, int C, int Ho, int Wo, int pad_h,
+                                                          int pad_w) {
+  const int vcols = C >> 3;
+  const size_t nvec = (size_t)N * H * W * vcols;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const Pix p = decode(i, H, W, vcols);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  // windows (ho, r) with ho*2 + r - pad_h == h
+  for (int r = 0; r < 3; ++r) {
+    const int th = p.h + pad_h - r;
+    if (th < 0 || (th & 1)) continue;
+    const int ho = th >> 1;
+    if (ho >= Ho) continue;
+    for (int s = 0; s < 3; ++s) {
+      const int tw = p.w + pad_w - s;
+      if (tw < 0 || (tw & 1)) continue;
+      const int wo = tw >> 1;
+      if (wo >= Wo) continue;
+      const size_t o = (((size_t)p.n * Ho + ho) * Wo + wo) * C + p.vc * 8;
+      const u32x2 a = *reinterpret_cast<const u32x2*>(amax + o);
+      float g[8];
+      unpack8(ldv(dy, o), g);
+      const int code = r * 3 + s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if ((int)((a.x >> (8 * e)) & 0xff) == code) acc[e] += g[e];
+        if ((int)((a.y >> (8 * e)) & 0xff) == code) acc[e + 4] += g[e + 4];
+      }
+    }
+  }
+  *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(acc);
+}
+
+// ---- average pool (zero pad before = pad; divisor k*k or valid count) ------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                          int N, int H, int W, int C, int k, int stride, int pad,
+                                                          int Ho, int Wo, int count_valid) {
+  const int vcols = C >> 3;
+  const size_t nvec = (size_t)N * Ho * Wo * vcols;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const Pix p = decode(i, Ho, Wo, vcols);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  int cnt = 0;
+  for (int r = 0; r < k; ++r) {
+    const int ih = p.h * stride + r - pad;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    for (int s = 0; s < k; ++s) {
+      const int iw = p.w * stride + s - pad;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      float f[8];
+      unpack8(ldv(x, (((size_t)p.n * H + ih) * W + iw) * C + p.vc * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e];
+      ++cnt;
+    }
+  }
+  const float inv = 1.0f / (float)(count_valid ? cnt : k * k);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] *= inv;
+  *reinterpret_cast<u32x4*>(y + i * 8) = pack8(acc);
+}
+
+__device__ __forceinline__ int valid_taps(int o, int stride, int pad, int k, int L) {
+  int c = 0;
+  for (int r = 0; r < k; ++r) c += ((unsigned)(o * stride + r - pad) < (unsigned)L);
+  return c;
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                          int N, int H, int W, int C, int k, int stride, int pad,
+                                                          int Ho, int Wo, int count_valid) {
+  const int vcols = C >> 3;
+  const size_t nvec = (size_t)N * H * W * vcols;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const Pix p = decode(i, H, W, vcols);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int r = 0; r < k; ++r) {
+    const int th = p.h + pad - r;
+    if (th < 0 || th % stride) continue;
+    const int ho = th / stride;
+    if (ho >= Ho) continue;
+    for (int s = 0; s < k; ++s) {
+      const int tw = p.w + pad - s;
+      if (tw < 0 || tw % stride) continue;
+      const int wo = tw / stride;
+      if (wo >= Wo) continue;
+      float g[8];
+      unpack8(ldv(dy, (((size_t)p.n * Ho + ho) * Wo + wo) * C + p.vc * 8), g);
+      const float inv =
+          1.0f / (float)(count_valid ? valid_taps(ho, stride, pad, k, H) * valid_taps(wo, stride, pad, k, W) : k * k);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += g[e] * inv;
+    }
+  }
+  *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(acc);
+}
+
+// ---- UpSampling2D((2,2)) backward: 2x2 block sum ---------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                           int N, int Hs, int Ws, int C) {
+  const int vcols = C >> 3;
+  const size_t nvec = (size_t)N * Hs * Ws * vcols;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const Pix p = decode(i, Hs, Ws, vcols);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const int H = Hs * 2, W = Ws * 2;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float g[8];
+      unpack8(ldv(dy, (((size_t)p.n * H + p.h * 2 + r) * W + p.w * 2 + s) * C + p.vc * 8), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += g[e];
+    }
+  *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(acc);
+}
+
+// ---- blur pool (REFLECT pad (k-1)/2, binomial k x k / sum, stride) --------------------------------
+struct BlurCoef {
+  float a[8];  // normalised 1-D binomial; 2-D weight = a[r]*a[s] (exact: all factors are dyadic)
+};
+inline BlurCoef blur_coef(int k) {
+  static const int tri[8][7] = {{0}, {1}, {1, 1}, {1, 2, 1}, {1, 3, 3, 1}, {1, 4, 6, 4, 1}, {1, 5, 10, 10, 5, 1},
+                                {1, 6, 15, 20, 15, 6, 1}};
+  BlurCoef c;
+  int sum = 0;
+  for (int i = 0; i < k; ++i) sum += tri[k][i];
+  for (int i = 0; i < 8; ++i) c.a[i] = i < k ? (float)tri[k][i] / (float)sum : 0.f;
+  return c;
+}
+__device__ __forceinline__ int reflect(int i, int L) {
+  if (i < 0) i = -i;
+  if (i >= L) i = 2 * (L - 1) - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void blur_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N,
+                                                       int H, int W, int C, int k, int stride, int Ho, int Wo,
+                                                       BlurCoef cf) {
+  const int vcols = C >> 3;
+  const size_t nvec = (size_t)N * Ho * Wo * vcols;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const Pix p = decode(i, Ho, Wo, vcols);
+  const int pad = (k - 1) / 2;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int r = 0; r < k; ++r) {
+    const int ih = reflect(p.h * stride + r - pad, H);
+    for (int s = 0; s < k; ++s) {
+      const int iw = reflect(p.w * stride + s - pad, W);
+      float f[8];
+      unpack8(ldv(x, (((size_t)p.n * H + ih) * W + iw) * C + p.vc * 8), f);
+      const float wgt = cf.a[r] * cf.a[s];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e] * wgt;
+    }
+  }
+  *reinterpret_cast<u32x4*>(y + i * 8) = pack8(acc);
+}
+
+// gather-form adjoint: input index h receives from every padded position hp with src(hp) == h
+__device__ __forceinline__ int padded_sources(int h, int L, int pad, int* hp) {
+  int n = 0;
+  hp[n++] = h + pad;
+  if (h >= 1 && h <= pad) hp[n++] = pad - h;
+  if (h <= L - 2 && h >= L - 1 - pad) hp[n++] = pad + 2 * (L - 1) - h;
+  return n;
+}
+
+__global__ __launch_bounds__(256) void blur_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N,
+                                                       int H, int W, int C, int k, int stride, int Ho, int Wo,
+                                                       BlurCoef cf) {
+  const int vcols = C >> 3;
+  const size_t nvec = (size_t)N * H * W * vcols;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const Pix p = decode(i, H, W, vcols);
+  const int pad = (k - 1) / 2;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  int hps[3], wps[3];
+  const int nh = padded_sources(p.h, H, pad, hps);
+  const int nw = padded_sources(p.w, W, pad, wps);
+  for (int a = 0; a < nh; ++a)
+    for (int r = 0; r < k; ++r) {
+      const int th = hps[a] - r;
+      if (th < 0 || th % stride) continue;
+      const int ho = th / stride;
+      if (ho >= Ho) continue;
+      for (int b = 0; b < nw; ++b)
+        for (int s = 0; s < k; ++s) {
+          const int tw = wps[b] - s;
+          if (tw < 0 || tw % stride) continue;
+          const int wo = tw / stride;
+          if (wo >= Wo) continue;
+          float g[8];
+          unpack8(ldv(dy, (((size_t)p.n * Ho + ho) * Wo + wo) * C + p.vc * 8), g);
+          const float wgt = cf.a[r] * cf.a[s];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += g[e] * wgt;
+        }
+    }
+  *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(acc);
+}
+
+// ---- global average pool: [N, HW, C] -> [N, C]; one block per (n, group of <=32 vector columns) -----
+// 256 threads = (256 / vcb) row-lanes x vcb vector columns, vcb = min(C/8, 32)
+template <bool TWO_BRANCH>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int HW,
+                                                      int Cin, int Cout, int vcb) {
+  __shared__ float red[256][9];
+  const int vcols = Cout >> 3;
+  const int vcl = threadIdx.x % vcb;
+  const int rl = threadIdx.x / vcb;
+  const int nrl = 256 / vcb;
+  const int vc = blockIdx.x * vcb + vcl;
+  const int n = blockIdx.y;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (vc < vcols && rl < nrl) {
+    for (int r = rl; r < HW; r += nrl) {
+      const size_t off = ((size_t)n * HW + r) * Cin + vc * 8;
+      float f[8];
+      unpack8(ldv(x, off), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e];
+      if (TWO_BRANCH) {
+        unpack8(ldv(x, off + Cout), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += f[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && vc < vcols) {
+    float o[8];
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      for (int r = 0; r < nrl; ++r) t += red[r * vcb + vcl][e];
+      o[e] = t * inv;
+    }
+    *reinterpret_cast<u32x4*>(y + (size_t)n * Cout + vc * 8) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N,
+                                                      int HW, int C) {
+  const int vcols = C >> 3;
+  const size_t nvec = (size_t)N * HW * vcols;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const int vc = (int)(i % vcols);
+  const int n = (int)(i / ((size_t)HW * vcols));
+  float g[8];
+  unpack8(ldv(dy, (size_t)n * C + vc * 8), g);
+  const float inv = 1.0f / (float)HW;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] *= inv;
+  *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(g);
+}
+
+}  // namespace
+
+#define POOL_ARGS_OK(name) ASM_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, name ": bad shape")
+
+static inline void same_pad(int in, int k, int s, int* out, int* before) {
+  *out = (in + s - 1) / s;
+  int total = (*out - 1) * s + k - in;
+  if (total < 0) total = 0;
+  *before = total / 2;
+}
+
+extern "C" int asm_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C,
+                                    void* stream) {
+  POOL_ARGS_OK("maxpool_fwd");
+  ASM_REQUIRE(x && y, "maxpool_fwd: null pointer");
+  int Ho, Wo, ph, pw;
+  same_pad(H, 3, 2, &Ho, &ph);
+  same_pad(W, 3, 2, &Wo, &pw);
+  const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, argmax, N, H, W, C, Ho, Wo, ph, pw);
+  ASM_CHECK_LAUNCH("maxpool_fwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int N, int H, int W, int C,
+                                    void* stream) {
+  POOL_ARGS_OK("maxpool_bwd");
+  ASM_REQUIRE(dy && argmax && dx, "maxpool_bwd: null pointer");
+  int Ho, Wo, ph, pw;
+  same_pad(H, 3, 2, &Ho, &ph);
+  same_pad(W, 3, 2, &Wo, &pw);
+  const size_t nvec = (size_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     argmax, (bf16_t*)dx, N, H, W, C, Ho, Wo, ph, pw);
+  ASM_CHECK_LAUNCH("maxpool_bwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_avgpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad,
+                               int Ho, int Wo, int count_valid, void* stream) {
+  POOL_ARGS_OK("avgpool_fwd");
+  ASM_REQUIRE(x && y && k >= 1 && k <= 7 && stride >= 1 && pad >= 0 && Ho > 0 && Wo > 0, "avgpool_fwd: bad arguments");
+  const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, N, H, W, C, k, stride, pad, Ho, Wo, count_valid);
+  ASM_CHECK_LAUNCH("avgpool_fwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
+                               int Ho, int Wo, int count_valid, void* stream) {
+  POOL_ARGS_OK("avgpool_bwd");
+  ASM_REQUIRE(dy && dx && k >= 1 && k <= 7 && stride >= 1 && pad >= 0 && Ho > 0 && Wo > 0, "avgpool_bwd: bad arguments");
+  const size_t nvec = (size_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (bf16_t*)dx, N, H, W, C, k, stride, pad, Ho, Wo, count_valid);
+  ASM_CHECK_LAUNCH("avgpool_bwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_upsample2x_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int C, void* stream) {
+  ASM_REQUIRE(dy && dx && N > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0, "upsample2x_bwd: bad arguments");
+  const size_t nvec = (size_t)N * Hs * Ws * (C / 8);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (bf16_t*)dx, N, Hs, Ws, C);
+  ASM_CHECK_LAUNCH("upsample2x_bwd");
+  return ASM_OK;
+}
+
+static int blur_out(int in, int k, int stride) { return (in + 2 * ((k - 1) / 2) - k) / stride + 1; }
+
+extern "C" int asm_blurpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, void* stream) {
+  POOL_ARGS_OK("blurpool_fwd");
+  ASM_REQUIRE(x && y && k >= 2 && k <= 7 && stride >= 1, "blurpool_fwd: filter size %d not supported", k);
+  ASM_REQUIRE((k - 1) / 2 < H && (k - 1) / 2 < W, "blurpool_fwd: REFLECT pad needs pad < size");
+  const int Ho = blur_out(H, k, stride), Wo = blur_out(W, k, stride);
+  const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(blur_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, N, H, W, C, k, stride, Ho, Wo, blur_coef(k));
+  ASM_CHECK_LAUNCH("blurpool_fwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_blurpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k, int stride,
+                                void* stream) {
+  POOL_ARGS_OK("blurpool_bwd");
+  ASM_REQUIRE(dy && dx && k >= 2 && k <= 7 && stride >= 1, "blurpool_bwd: filter size %d not supported", k);
+  const int Ho = blur_out(H, k, stride), Wo = blur_out(W, k, stride);
+  const size_t nvec = (size_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(blur_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (bf16_t*)dx, N, H, W, C, k, stride, Ho, Wo, blur_coef(k));
+  ASM_CHECK_LAUNCH("blurpool_bwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_gap_fwd(const void* x, void* y, int N, int HW, int C, void* stream) {
+  ASM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_fwd: bad arguments");
+  const int vcb = C / 8 < 32 ? C / 8 : 32;
+  hipLaunchKernelGGL((gap_fwd_kernel<false>), dim3(cdiv(C / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, HW, C, C, vcb);
+  ASM_CHECK_LAUNCH("gap_fwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_sk_gap(const void* f, void* s, int N, int HW, int F, void* stream) {
+  ASM_REQUIRE(f && s && N > 0 && HW > 0 && F > 0 && F % 8 == 0, "sk_gap: bad arguments");
+  const int vcb = F / 8 < 32 ? F / 8 : 32;
+  hipLaunchKernelGGL((gap_fwd_kernel<true>), dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)f, (bf16_t*)s, HW, 2 * F, F, vcb);
+  ASM_CHECK_LAUNCH("sk_gap");
+  return ASM_OK;
+}
+
+extern "C" int asm_gap_bwd(const void* dy, void* dx, int N, int HW, int C, void* stream) {
+  ASM_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_bwd: bad arguments");
+  const size_t nvec = (size_t)N * HW * (C / 8);
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (bf16_t*)dx, N, HW, C);
+  ASM_CHECK_LAUNCH("gap_bwd");
+  return ASM_OK;
+}

@@ -1,0 +1,122 @@
+"""ctypes binding of libasm_hip.so (the C ABI declared in include/asm_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libasm_hip.so')
+
+ASM_OK, ASM_EINVAL, ASM_ENOTSUP, ASM_EHIP = 0, -1, -2, -3
+ABI_VERSION = 1
+
+
+class AsmError(RuntimeError):
+  pass
+
+
+class ConvDesc(C.Structure):
+  """struct asm_conv_desc"""
+  _fields_ = [('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32),
+              ('K', C.c_int32), ('R', C.c_int32), ('S', C.c_int32),
+              ('stride', C.c_int32), ('pad', C.c_int32),
+              ('Ho', C.c_int32), ('Wo', C.c_int32),
+              ('x_img_pitch', C.c_int64), ('x_row_pitch', C.c_int32), ('x_pix_pitch', C.c_int32),
+              ('ldy', C.c_int32), ('out_f32', C.c_int32)]
+
+
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_D = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol declared in include/asm_hip.h
+SIGNATURES = {
+    'asm_last_error': (C.c_char_p, []),
+    'asm_abi_version': (_I, []),
+    'asm_conv2d_fprop': (_I, [_D, _P, _P, _P, _P, _P]),
+    'asm_conv2d_stats_blocks': (_I, [_D]),
+    'asm_conv2d_dgrad': (_I, [_D, _P, _P, _P, _P]),
+    'asm_conv2d_wgrad_workspace_bytes': (_Z, [_D]),
+    'asm_conv2d_wgrad': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
+    'asm_filter_transpose': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'asm_conv2d_fprop_naive': (_I, [_D, _P, _P, _P, _P]),
+    'asm_conv2d_dgrad_naive': (_I, [_D, _P, _P, _P, _P]),
+    'asm_conv2d_wgrad_naive': (_I, [_D, _P, _P, _P, _P]),
+    'asm_debug_tr_probe': (_I, [_P, _P]),
+    'asm_stem_pack_filter': (_I, [_P, _P, _I, _I, _P]),
+    'asm_stem_unpack_grad': (_I, [_P, _P, _I, _I, _P]),
+    'asm_stem_pad_input': (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    'asm_bn_stats_blocks': (_I, [_I, _I]),
+    'asm_bn_stats': (_I, [_P, _I, _I, _P, _P]),
+    'asm_bn_finalize': (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    'asm_bn_infer_coeffs': (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    'asm_bn_apply': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'asm_bn_bwd_reduce': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'asm_bn_bwd_finalize': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asm_bn_bwd_apply': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    'asm_maxpool3x3s2_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'asm_maxpool3x3s2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'asm_avgpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'asm_avgpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'asm_upsample2x_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'asm_blurpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'asm_blurpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'asm_gap_fwd': (_I, [_P, _P, _I, _I, _I, _P]),
+    'asm_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),
+    'asm_sk_gap': (_I, [_P, _P, _I, _I, _I, _P]),
+    'asm_sk_select_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_select_bwd_att': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_select_bwd_f': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_se_scale_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'asm_se_scale_bwd_e': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_se_scale_bwd_x': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_relu_fwd': (_I, [_P, _P, _Z, _P]),
+    'asm_relu_bwd': (_I, [_P, _P, _P, _Z, _P]),
+    'asm_add_bf16': (_I, [_P, _P, _P, _Z, _P]),
+    'asm_bias_add_f32': (_I, [_P, _P, _I, _I, _I, _P]),
+    'asm_bias_grad_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
+    'asm_cast_f32_to_bf16': (_I, [_P, _P, _Z, _P]),
+    'asm_softmax_ce': (_I, [_P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _P]),
+    'asm_onehot': (_I, [_P, _P, _I, _I, _P]),
+    'asm_softmax_rows': (_I, [_P, _P, _I, _I, _F, _P]),
+    'asm_mean_f32': (_I, [_P, _I, _P, _P]),
+    'asm_mixup_meansub': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'asm_mixup_labels': (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    'asm_sgd_momentum': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+  """Load the library and bind every declared symbol; raises if anything is missing."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(path):
+    raise AsmError('%s not found -- build it with `python -m assembled_cnn_amd.build` '
+                   '(there is no CPU fallback)' % path)
+  lib = C.CDLL(path)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name, None)
+    if fn is None:
+      raise AsmError('libasm_hip.so does not export %s' % name)
+    fn.restype = res
+    fn.argtypes = args
+  if lib.asm_abi_version() != ABI_VERSION:
+    raise AsmError('libasm_hip.so ABI version %d != %d' % (lib.asm_abi_version(), ABI_VERSION))
+  _lib = lib
+  return lib
+
+
+def check(code: int, what: str = ''):
+  if code != ASM_OK:
+    msg = load().asm_last_error()
+    msg = msg.decode() if msg else ''
+    if code == ASM_EINVAL:
+      raise ValueError('%s: %s' % (what, msg))
+    if code == ASM_ENOTSUP:
+      raise NotImplementedError('%s: %s' % (what, msg))
+    raise AsmError('%s: HIP error: %s' % (what, msg))

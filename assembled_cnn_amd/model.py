@@ -1,0 +1,377 @@
+"""Assemble-ResNet topology walker over the HIP layers -- the drop-in for the reference's model class.
+
+Mirrors the operator interface of the reference for this path:
+
+  * ``Model(resnet_size, data_format=None, num_classes=None, resnet_version=1, dtype=..., no_downsample,
+    zero_gamma, use_se_block, use_sk_block, bn_momentum, embedding_size, anti_alias_filter_size,
+    anti_alias_type, pool_type, loss_type, bl_alpha, bl_beta)``        functions/model_fns.py:141-157
+  * ``model(inputs NHWC, training, reuse=False, use_resnet_d=False, keep_prob=1.0,
+    return_embedding=False) -> logits [B, num_classes]``               nets/resnet_model.py:305-310
+  * the same errors: ValueError for a bad resnet_version / resnet_size / dtype, NotImplementedError for
+    non-bottleneck sizes and unknown pool / loss types.            nets/resnet_model.py:200-215,
+                                                                    functions/model_fns.py:131-135
+
+Variables are created in the reference's creation order with TF-style names
+(``resnet_model/.../conv2d_N/kernel`` ...), but kernels are stored KRSC (see ``hwio_to_krsc``).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from . import nn, ops
+from .nn import BatchNorm, ConvKernel, Ctx, SEUnit, SKUnit, Var, conv_bn
+
+
+def get_block_sizes(resnet_size, resnet_version=1):
+  """functions/model_fns.py:98-135."""
+  if resnet_version == 2:
+    choices = {50: [3, 4, 6, 3], 101: [4, 8, 18, 3], 152: [5, 12, 30, 3]}
+  else:
+    choices = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3], 200: [3, 24, 36, 3]}
+  try:
+    return choices[resnet_size]
+  except KeyError:
+    raise ValueError('Could not find layers for selected Resnet size.\n'
+                     'Size received: {}; sizes allowed: {}.'.format(resnet_size, choices.keys()))
+
+
+ALLOWED_DTYPES = ('bf16',)          # compute dtype of the HIP path
+KNOWN_DTYPES = ('bf16', 'fp16', 'fp32')
+
+
+class Model(object):
+  def __init__(self, resnet_size, data_format=None, num_classes=None, resnet_version=1, dtype='bf16',
+               no_downsample=False, zero_gamma=False, use_se_block=False, use_sk_block=False,
+               bn_momentum=0.997, embedding_size=0, anti_alias_filter_size=0, anti_alias_type="",
+               pool_type='gap', loss_type='softmax', bl_alpha=2, bl_beta=4, seed=0, device='cuda'):
+    if resnet_version not in (1, 2):
+      raise ValueError('Resnet version should be 1 or 2. See README for citations.')
+    if int(resnet_size) < 50:
+      raise NotImplementedError('only bottleneck ResNets (resnet_size >= 50) are implemented')
+    if dtype not in KNOWN_DTYPES:
+      raise ValueError('dtype must be one of: {}'.format(KNOWN_DTYPES))
+    if dtype not in ALLOWED_DTYPES:
+      raise NotImplementedError('the MI355X path computes in bf16 (fp32 master weights); got dtype=%s' % dtype)
+    if data_format not in (None, 'channels_last'):
+      raise NotImplementedError('the MI355X path is NHWC (channels_last) only')
+    if pool_type != 'gap':
+      if pool_type in ('gem', 'flatten'):
+        raise NotImplementedError('pool_type=%s is not implemented on the HIP path yet' % pool_type)
+      raise NotImplementedError
+    if loss_type == 'softmax':
+      self.dense_bias_init = 0.0
+    elif loss_type in ('sigmoid', 'focal', 'anchor'):
+      self.dense_bias_init = -math.log(num_classes - 1)
+    else:
+      raise NotImplementedError
+    self.resnet_size = int(resnet_size)
+    self.resnet_version = resnet_version
+    self.num_classes = num_classes
+    self.num_filters = 64
+    self.kernel_size = 7
+    self.conv_stride = 2
+    self.first_pool_size = 3
+    self.first_pool_stride = 2
+    self.block_sizes = get_block_sizes(self.resnet_size, resnet_version)
+    self.block_strides = [2, 2, 1, 2] if resnet_version == 2 else [1, 2, 2, 2]
+    if no_downsample:
+      self.block_strides[-1] = 1
+    self.zero_gamma = zero_gamma
+    self.use_se_block = use_se_block
+    self.use_sk_block = use_sk_block
+    self.bn_momentum = bn_momentum
+    self.embedding_size = embedding_size
+    self.anti_alias_filter_size = anti_alias_filter_size
+    self.anti_alias_type = anti_alias_type
+    self.pool_type = pool_type
+    self.alpha = bl_alpha
+    self.beta = bl_beta
+    self.dtype = dtype
+    self.seed = seed
+    self.device = torch.device(device)
+    self.arena = nn.ParamArena()
+    self._layers = []
+    self._built_with_d: Optional[bool] = None
+    self.taps: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    self.ldc = nn._round_up(num_classes, 8) if num_classes else 0
+    self._ctx: Optional[Ctx] = None
+
+  # -----------------------------------------------------------------------------------------------
+  def build(self, input_hw=(224, 224), use_resnet_d=False, batch=2):
+    """Create all variables (shape-only walk), allocate and initialise the arenas."""
+    if self.arena.finalized:
+      return
+    ctx = Ctx(self.arena, True, True, self.bn_momentum, self.device, False, self._layers)
+    x = Var(None, (batch, input_hw[0] + 6, input_hw[1] + 6, 4), needs_grad=False)
+    self._walk(ctx, x, use_resnet_d, False)
+    self._built_with_d = use_resnet_d
+    self.arena.finalize(self.device, self.seed)
+
+  def __call__(self, inputs, training, reuse=False, use_resnet_d=False, keep_prob=1.0, return_embedding=False,
+               record_tape=None, prepadded=False):
+    """inputs: [N, H, W, 3] float32 / bfloat16 NHWC (already mean-subtracted), or with ``prepadded`` the
+    zero-haloed [N, H+6, W+6, 4] bf16 buffer produced by ops.mixup_meansub.  Returns float32 logits
+    [N, num_classes] (a view of the padded logits buffer)."""
+    if isinstance(keep_prob, float) and keep_prob != 1.0 and training:
+      raise NotImplementedError('DropBlock (keep_prob < 1) is not implemented on the HIP path yet')
+    if prepadded:
+      xp = inputs
+      hw = (inputs.shape[1] - 6, inputs.shape[2] - 6)
+    else:
+      hw = (inputs.shape[1], inputs.shape[2])
+    if not self.arena.finalized:
+      self.build(hw, use_resnet_d)
+    if use_resnet_d != self._built_with_d:
+      raise ValueError('model variables were created with use_resnet_d=%s' % self._built_with_d)
+    if not prepadded:
+      xp = ops.stem_pad_input(inputs.contiguous())
+    tape = training if record_tape is None else record_tape
+    ctx = Ctx(self.arena, training, False, self.bn_momentum, self.device, tape, self._layers)
+    out = self._walk(ctx, Var(xp, needs_grad=False), use_resnet_d, return_embedding)
+    self.taps = ctx.taps
+    self._ctx = ctx
+    return out
+
+  def backward(self, dlogits: torch.Tensor):
+    """Run the recorded tape.  dlogits: bf16 [N, 1, 1, ldc] (d loss / d logits, zero padded)."""
+    if self._ctx is None or self._ctx.tape is None:
+      raise RuntimeError('no forward pass with a tape to differentiate')
+    self._ctx.dlogits = dlogits
+    self._ctx.backward()
+    self._ctx = None
+
+  # -----------------------------------------------------------------------------------------------
+  def _bottleneck(self, ctx: Ctx, x: Var, filters, projection, strides, zero_gamma, aa_size, aa_type,
+                  last_relu=True, expansion=4) -> Var:
+    """_bottleneck_block_v1 (nets/resnet_model.py:35-97)."""
+    L = ctx.layer
+    cin = x.shape[3]
+    shortcut = x
+    if projection is not None:
+      shortcut = projection(x)
+    h = conv_bn(ctx, x, L(lambda: ConvKernel(ctx, 1, cin, filters)), L(lambda: BatchNorm(ctx, filters)), 1, relu=True)
+    s3 = 1 if 'sconv' in aa_type else strides
+    if self.use_sk_block:
+      h = L(lambda: SKUnit(ctx, filters, filters))(ctx, h, s3)
+    else:
+      h = conv_bn(ctx, h, L(lambda: ConvKernel(ctx, 3, filters, filters)), L(lambda: BatchNorm(ctx, filters)), s3,
+                  relu=True)
+    if 'sconv' in aa_type and strides != 1:
+      h = nn.blur_pool(ctx, h, aa_size, strides)
+    cout = expansion * filters
+    conv3 = L(lambda: ConvKernel(ctx, 1, filters, cout))
+    bn3 = L(lambda: BatchNorm(ctx, cout, zero_gamma=zero_gamma))
+    if self.use_se_block:
+      h = conv_bn(ctx, h, conv3, bn3, 1, relu=False)
+      h = L(lambda: SEUnit(ctx, cout))(ctx, h)
+      return self._add_relu(ctx, h, shortcut, last_relu)
+    return conv_bn(ctx, h, conv3, bn3, 1, relu=last_relu, residual=shortcut, res_mode=1)
+
+  @staticmethod
+  def _add_relu(ctx: Ctx, a: Var, b: Var, relu: bool) -> Var:
+    if ctx.dry:
+      return Var(None, a.shape)
+    s = ops.add_bf16(a.data, b.data)
+    out = Var(ops.relu_fwd(s) if relu else s)
+    if ctx.tape is not None:
+      def bwd():
+        g = ops.relu_bwd(out.grad, out.data) if relu else out.grad
+        nn.accum_grad(a, g, relu)
+        nn.accum_grad(b, g, False)
+        out.grad = None
+      ctx.record(bwd)
+    return out
+
+  def _block_layer(self, ctx: Ctx, x: Var, filters, num_blocks, strides, name, use_resnet_d=False,
+                   use_bl=False, last_relu=True, expansion=4) -> Var:
+    """block_layer (nets/resnet_model.py:99-163)."""
+    L = ctx.layer
+    filters_out = filters * expansion
+    aa_size, aa_type = self.anti_alias_filter_size, self.anti_alias_type
+
+    def shortcut_conv_bn(inp: Var, stride: int) -> Var:
+      cin = inp.shape[3]
+      return conv_bn(ctx, inp, L(lambda: ConvKernel(ctx, 1, cin, filters_out)),
+                     L(lambda: BatchNorm(ctx, filters_out)), stride, relu=False)
+
+    def projection_shortcut(inp):      # :107-121
+      if 'proj' in aa_type and strides != 1:
+        return shortcut_conv_bn(nn.blur_pool(ctx, inp, aa_size, strides), 1)
+      return shortcut_conv_bn(inp, strides)
+
+    def resnet_d_projection_shortcut(inp):  # :123-131
+      if strides > 1:
+        inp = nn.avg_pool(ctx, inp, 2, strides, 0, False)
+      else:
+        inp = nn.avg_pool(ctx, inp, 2, 1, 0, True)
+      return shortcut_conv_bn(inp, 1)
+
+    def bl_projection_shortcut(inp):   # :133-141
+      if strides > 1:
+        inp = nn.avg_pool(ctx, inp, 3, strides, 1, False)
+      return shortcut_conv_bn(inp, 1)
+
+    if use_resnet_d:
+      proj = resnet_d_projection_shortcut
+    elif use_bl:
+      proj = bl_projection_shortcut
+    else:
+      proj = projection_shortcut
+
+    # first block: projection + stride + anti-alias args; last_relu is NOT forwarded (:151-155)
+    x = self._bottleneck(ctx, x, filters, proj, strides, self.zero_gamma, aa_size, aa_type, True, expansion)
+    for i in range(1, num_blocks):     # :157-161
+      x = self._bottleneck(ctx, x, filters, None, 1, self.zero_gamma, 0, "",
+                           last_relu if i == num_blocks - 1 else True, expansion)
+    ctx.tap(name, x)
+    return x
+
+  # -----------------------------------------------------------------------------------------------
+  def _walk(self, ctx: Ctx, x: Var, use_resnet_d: bool, return_embedding: bool):
+    """Model.__call__ (nets/resnet_model.py:305-599)."""
+    L = ctx.layer
+    nf = self.num_filters
+    v2 = self.resnet_version == 2
+
+    # ---- stem ------------------------------------------------------------------------------------
+    if use_resnet_d:                                      # :328-358
+      if v2:
+        ctx.push_scope('stage0')
+      c1 = L(lambda: ConvKernel(ctx, 3, 3, nf // 2, stem=True))
+      b1 = L(lambda: BatchNorm(ctx, nf // 2))
+      c2 = L(lambda: ConvKernel(ctx, 3, nf // 2, nf // 2))
+      b2 = L(lambda: BatchNorm(ctx, nf // 2))
+      c3 = L(lambda: ConvKernel(ctx, 3, nf // 2, nf))
+      if v2:
+        ctx.pop_scope()
+        ctx.push_scope('stage0')
+      b3 = L(lambda: BatchNorm(ctx, nf))
+      if v2:
+        ctx.pop_scope()
+      x = conv_bn(ctx, x, c1, b1, self.conv_stride, relu=True)
+      x = conv_bn(ctx, x, c2, b2, 1, relu=True)
+      x = conv_bn(ctx, x, c3, b3, 1, relu=True, tap_pre='initial_conv')
+    else:                                                 # :359-381
+      if v2:
+        ctx.push_scope('stage0')
+      c1 = L(lambda: ConvKernel(ctx, self.kernel_size, 3, nf, stem=True))
+      if v2:
+        ctx.pop_scope()
+        ctx.push_scope('stage0')
+      b1 = L(lambda: BatchNorm(ctx, nf))
+      if v2:
+        ctx.pop_scope()
+      x = conv_bn(ctx, x, c1, b1, self.conv_stride, relu=True, tap_pre='initial_conv')
+
+    if self.first_pool_size:
+      if v2:                                              # blModule0 :384-419
+        ctx.push_scope('stage0/pool')
+        a = self.alpha
+        cb = L(lambda: ConvKernel(ctx, 3, nf, nf)); bb = L(lambda: BatchNorm(ctx, nf))
+        big0 = conv_bn(ctx, x, cb, bb, 2, relu=False)
+        cl1 = L(lambda: ConvKernel(ctx, 3, nf, nf // a)); bl1 = L(lambda: BatchNorm(ctx, nf // a))
+        l0 = conv_bn(ctx, x, cl1, bl1, 1, relu=True)
+        cl2 = L(lambda: ConvKernel(ctx, 3, nf // a, nf // a)); bl2 = L(lambda: BatchNorm(ctx, nf // a))
+        l0 = conv_bn(ctx, l0, cl2, bl2, 2, relu=True)
+        cl3 = L(lambda: ConvKernel(ctx, 1, nf // a, nf)); bl3 = L(lambda: BatchNorm(ctx, nf))
+        x = conv_bn(ctx, l0, cl3, bl3, 1, relu=True, residual=big0, res_mode=1)   # relu(big0 + little0) :413
+        cm = L(lambda: ConvKernel(ctx, 1, nf, nf)); bm = L(lambda: BatchNorm(ctx, nf))
+        x = conv_bn(ctx, x, cm, bm, 1, relu=True)
+        ctx.pop_scope()
+      else:                                               # :420-425
+        x = nn.max_pool_3x3_s2_same(ctx, x)
+        ctx.tap('initial_max_pool', x)
+
+    # ---- stages ----------------------------------------------------------------------------------
+    for i, num_blocks in enumerate(self.block_sizes):
+      num_filters = nf * (2 ** i)
+      if v2 and i < 3:                                    # :455-516
+        ctx.push_scope('stage{}'.format(i + 1))
+        ctx.push_scope('big{}'.format(i + 1))
+        big = self._block_layer(ctx, x, num_filters, num_blocks - 1, 2, 'big{}'.format(i + 1),
+                                use_bl=True, last_relu=False)
+        ctx.pop_scope()
+        ctx.push_scope('little{}'.format(i + 1))
+        little = self._block_layer(ctx, x, num_filters // self.alpha, max(1, num_blocks // self.beta - 1), 1,
+                                   'little{}'.format(i + 1), use_bl=True)
+        cin_l = little.shape[3]
+        ce = L(lambda: ConvKernel(ctx, 1, cin_l, num_filters * 4))
+        be = L(lambda: BatchNorm(ctx, num_filters * 4))
+        ctx.pop_scope()
+        # relu(BN(little_e) + UpSampling2D(big)) :493-501
+        x = conv_bn(ctx, little, ce, be, 1, relu=True, residual=big, res_mode=2)
+        ctx.push_scope('merge{}'.format(i + 1))
+        x = self._block_layer(ctx, x, num_filters, 1, self.block_strides[i], 'merge{}'.format(i + 1), use_bl=True)
+        ctx.pop_scope()
+        ctx.pop_scope()
+      elif v2 and i == 3:                                 # :518-534
+        ctx.push_scope('stage{}'.format(i + 1))
+        x = self._block_layer(ctx, x, num_filters, num_blocks, self.block_strides[i],
+                              'block_layer{}'.format(i + 1), use_resnet_d=use_resnet_d, use_bl=True)
+        ctx.pop_scope()
+      else:                                               # :536-549
+        x = self._block_layer(ctx, x, num_filters, num_blocks, self.block_strides[i],
+                              'block_layer{}'.format(i + 1), use_resnet_d=use_resnet_d)
+
+    # ---- head :555-599 ---------------------------------------------------------------------------
+    x = nn.global_avg_pool(ctx, x)
+    ctx.tap('final_reduce_mean', x)
+    if self.embedding_size > 0:
+      cin_e = x.shape[3]
+      ce = L(lambda: ConvKernel(ctx, 1, cin_e, self.embedding_size, layer_name='embedding_dense'))
+      be = L(lambda: BatchNorm(ctx, self.embedding_size, layer_name='embedding_dense_batch_normalization'))
+      if return_embedding:
+        x = conv_bn(ctx, x, ce, be, 1, relu=False)
+      else:
+        x = conv_bn(ctx, x, ce, be, 1, relu=True)   # relu after squeeze (:591-592)
+    if return_embedding:
+      return None if ctx.dry else x.data.view(x.shape[0], x.shape[3]).float()
+    return self._dense(ctx, x)
+
+  def _dense(self, ctx: Ctx, x: Var):
+    """tf.layers.dense (nets/resnet_model.py:595-597): kernel stored [units][in], bias added in fp32."""
+    L = ctx.layer
+    cin = x.shape[3]
+    nc = self.num_classes
+    dense = L(lambda: ConvKernel(ctx, 1, cin, nc, dense=True))
+    if ctx.dry:
+      bias_name = dense.name[:-len('kernel')] + 'bias'
+      ctx.arena.register(bias_name, (nc,), True, nn.const_init((nc,), self.dense_bias_init))
+      self._bias_name = bias_name
+      return None
+    a = ctx.arena
+    logits, dense_bwd, _ = nn.conv_plain(ctx, x, dense, out_f32=True, ldy=self.ldc)
+    N = x.shape[0]
+    ops.bias_add_f32(logits, a.w(self._bias_name), N, nc, self.ldc)
+    ctx.taps['final_dense'] = logits
+    if ctx.tape is not None:
+      def bwd():
+        dz = ctx.dlogits
+        if dz is None:
+          raise RuntimeError('backward() needs d(loss)/d(logits)')
+        ops.bias_grad_bf16(dz, N, nc, self.ldc, a.g(self._bias_name))
+        dense_bwd(dz)
+      ctx.record(bwd)
+    self.logits_padded = logits
+    return logits.view(N, self.ldc)[:, :nc]
+
+  # -----------------------------------------------------------------------------------------------
+  def trainable_variables(self) -> "OrderedDict[str, torch.Tensor]":
+    """name -> fp32 master view, in creation order (tf.trainable_variables())."""
+    return OrderedDict((n, self.arena.w(n)) for n in self.arena.specs)
+
+  def num_params(self) -> int:
+    return self.arena.num_params()
+
+
+def hwio_to_krsc(w_hwio: torch.Tensor) -> torch.Tensor:
+  """TF conv kernel [k, k, Cin, Cout] -> this package's [Cout, k, k, Cin]."""
+  return w_hwio.permute(3, 0, 1, 2).contiguous()
+
+
+def krsc_to_hwio(w_krsc: torch.Tensor) -> torch.Tensor:
+  return w_krsc.permute(1, 2, 3, 0).contiguous()

@@ -1,0 +1,575 @@
+"""Host-side runtime of the training path: flat parameter arenas, a hand-written backward tape and
+the layer objects (conv+BN groups, SK / SE units, pools) the model walker composes.
+
+There is no autograd: every layer records an explicit backward closure that launches the matching
+HIP kernels (conv dgrad / wgrad, BN backward, ...), because the fused kernels (conv + BN statistics,
+BN-apply + residual + ReLU) do not map 1:1 onto autograd nodes.
+
+Layouts: activations NHWC bf16; conv / fc / dense kernels KRSC ([Cout][R][S][Cin]) with an fp32
+master copy, a bf16 shadow (fprop operand) and a bf16 CRSK copy (dgrad operand); BN gamma/beta and
+all gradients fp32.  All trainable tensors live in ONE flat fp32 arena (plus same-shaped gradient /
+momentum / bf16 arenas) so the optimiser and the gradient all-reduce are single flat launches.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+BN_EPS = 1e-5  # nets/model_helper.py:26
+
+
+def _round_up(n: int, m: int) -> int:
+  return (n + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------------
+# parameters
+# ---------------------------------------------------------------------------------------------------
+class ParamSpec(object):
+  __slots__ = ('name', 'shape', 'numel', 'decay', 'init', 'offset', 'index')
+
+  def __init__(self, name, shape, decay, init, index):
+    self.name = name
+    self.shape = tuple(int(s) for s in shape)
+    self.numel = int(np.prod(self.shape))
+    self.decay = decay
+    self.init = init
+    self.offset = -1
+    self.index = index
+
+
+class ParamArena(object):
+  """Trainable variables in creation order (== tf.trainable_variables() order of the reference) mapped
+  onto flat device arenas.  The weight-decayed set (every variable whose name lacks
+  'batch_normalization', nets/run_loop_classification.py:166-177) is stored first so weight decay is a
+  per-segment scalar of the optimiser launch."""
+
+  def __init__(self):
+    self.specs: "OrderedDict[str, ParamSpec]" = OrderedDict()
+    self.state_specs: "OrderedDict[str, Tuple[Tuple[int, ...], float, int]]" = OrderedDict()
+    self.finalized = False
+    self.decay_elems = 0
+    self.total_elems = 0
+    self.w32 = self.g32 = self.m32 = self.w16 = self.state = None
+    self.derived: List[Callable[[], None]] = []  # refresh hooks (CRSK copies, stem packing)
+
+  def register(self, name, shape, decay, init) -> ParamSpec:
+    if self.finalized:
+      if name not in self.specs:
+        raise RuntimeError('parameter %s requested after the model was built' % name)
+      return self.specs[name]
+    if name not in self.specs:
+      self.specs[name] = ParamSpec(name, shape, decay, init, len(self.specs))
+    return self.specs[name]
+
+  def register_state(self, name, shape, fill: float):
+    if name not in self.state_specs:
+      if self.finalized:
+        raise RuntimeError('state %s requested after the model was built' % name)
+      self.state_specs[name] = (tuple(shape), fill, -1)
+
+  def finalize(self, device, seed: int):
+    rng = np.random.default_rng(seed)
+    off = 0
+    for decay_pass in (True, False):
+      for sp in self.specs.values():
+        if sp.decay == decay_pass:
+          sp.offset = off
+          off += _round_up(sp.numel, 8)
+      if decay_pass:
+        self.decay_elems = off
+    self.total_elems = off
+    host = np.zeros((off,), dtype=np.float32)
+    for sp in self.specs.values():  # creation order => reproducible RNG stream
+      host[sp.offset:sp.offset + sp.numel] = np.asarray(sp.init(rng), dtype=np.float32).reshape(-1)
+    self.w32 = torch.from_numpy(host).to(device)
+    self.g32 = torch.zeros_like(self.w32)
+    self.m32 = torch.zeros_like(self.w32)
+    self.w16 = torch.empty((off,), dtype=torch.bfloat16, device=device)
+    soff = 0
+    shost = []
+    new_specs = OrderedDict()
+    for name, (shape, fill, _) in self.state_specs.items():
+      n = int(np.prod(shape))
+      new_specs[name] = (shape, fill, soff)
+      shost.append(np.full((_round_up(n, 8),), fill, dtype=np.float32))
+      soff += _round_up(n, 8)
+    self.state_specs = new_specs
+    self.state = torch.from_numpy(np.concatenate(shost) if shost else np.zeros((0,), np.float32)).to(device)
+    self.finalized = True
+    self.refresh_shadows()
+
+  # views ------------------------------------------------------------------------------------------
+  def _view(self, arena, name):
+    sp = self.specs[name]
+    return arena[sp.offset:sp.offset + sp.numel].view(sp.shape)
+
+  def w(self, name):
+    return self._view(self.w32, name)
+
+  def g(self, name):
+    return self._view(self.g32, name)
+
+  def m(self, name):
+    return self._view(self.m32, name)
+
+  def wb(self, name):
+    return self._view(self.w16, name)
+
+  def st(self, name):
+    shape, _, off = self.state_specs[name]
+    n = int(np.prod(shape))
+    return self.state[off:off + n].view(shape)
+
+  def refresh_shadows(self):
+    """fp32 master -> bf16 shadow, then the derived layouts (after init / weight import)."""
+    ops.cast_f32_to_bf16(self.w32, self.w16)
+    self.refresh_derived()
+
+  def refresh_derived(self):
+    for fn in self.derived:
+      fn()
+
+  def num_params(self) -> int:
+    return sum(sp.numel for sp in self.specs.values())
+
+
+# initialisers (distributional parity with TF) -----------------------------------
+def variance_scaling_init(shape_krsc):
+  """tf.variance_scaling_initializer() defaults: fan_in, truncated normal, stddev sqrt(1/fan_in)/0.8796."""
+  k, r, s, c = shape_krsc
+  std = math.sqrt(1.0 / (r * s * c)) / .87962566103423978
+
+  def init(rng):
+    out = rng.standard_normal(size=shape_krsc)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+      out[bad] = rng.standard_normal(size=int(bad.sum()))
+      bad = np.abs(out) > 2.0
+    return out * std
+  return init
+
+
+def glorot_uniform_init(shape_kc):
+  k, c = shape_kc
+  limit = math.sqrt(6.0 / (k + c))
+  return lambda rng: rng.uniform(-limit, limit, size=shape_kc)
+
+
+def const_init(shape, value):
+  return lambda rng: np.full(shape, value, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# activations + tape
+# ---------------------------------------------------------------------------------------------------
+class Var(object):
+  """An activation: NHWC bf16 tensor (``data`` is None during the shape-only build walk)."""
+  __slots__ = ('data', 'shape', 'grad', 'grad_owned', 'needs_grad')
+
+  def __init__(self, data, shape=None, needs_grad=True):
+    self.data = data
+    self.shape = tuple(data.shape) if data is not None else tuple(shape)
+    self.grad = None
+    self.grad_owned = False
+    self.needs_grad = needs_grad
+
+
+def accum_grad(v: Var, g: torch.Tensor, owned: bool):
+  """v.grad += g.  ``owned`` says whether g may later be updated in place by us."""
+  if not v.needs_grad:
+    return
+  if v.grad is None:
+    v.grad = g
+    v.grad_owned = owned
+  elif v.grad_owned:
+    ops.add_bf16(v.grad, g, out=v.grad)
+  else:
+    v.grad = ops.add_bf16(v.grad, g)
+    v.grad_owned = True
+
+
+class Ctx(object):
+  """Per-call context shared by the walker and the layers."""
+
+  def __init__(self, arena: ParamArena, training: bool, dry: bool, bn_momentum: float, device,
+               record_tape: bool, layers: Optional[list] = None):
+    self.arena = arena
+    self.layers = layers if layers is not None else []
+    self._cursor = 0
+    self.dlogits = None
+    self.training = training
+    self.dry = dry
+    self.bn_momentum = bn_momentum
+    self.device = device
+    self.tape: Optional[List[Callable[[], None]]] = [] if (record_tape and not dry) else None
+    self.taps: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    self._scope: List[str] = []
+    self._counters: Dict[Tuple[str, str], int] = {}
+
+  def layer(self, factory):
+    """Layer objects are created once (in walk order, during the shape-only build pass) and re-used."""
+    if self.dry:
+      obj = factory()
+      self.layers.append(obj)
+      return obj
+    obj = self.layers[self._cursor]
+    self._cursor += 1
+    return obj
+
+  # TF-style variable naming ------------------------------------------------------------------------
+  def unique(self, base: str) -> str:
+    key = ('/'.join(self._scope), base)
+    n = self._counters.get(key, 0)
+    self._counters[key] = n + 1
+    return base if n == 0 else '%s_%d' % (base, n)
+
+  def push_scope(self, default_name: str):
+    self._scope.append(self.unique(default_name))
+
+  def pop_scope(self):
+    self._scope.pop()
+
+  def full_name(self, layer: str, var: str) -> str:
+    return '/'.join(['resnet_model'] + self._scope + [layer, var])
+
+  def record(self, fn: Callable[[], None]):
+    if self.tape is not None:
+      self.tape.append(fn)
+
+  def tap(self, name: str, v: Var):
+    if not self.dry:
+      self.taps[name] = v.data
+
+  def backward(self):
+    for fn in reversed(self.tape):
+      fn()
+    self.tape = []
+
+
+# ---------------------------------------------------------------------------------------------------
+# layers
+# ---------------------------------------------------------------------------------------------------
+class ConvKernel(object):
+  """One conv / fc / dense kernel: parameter slot + bf16 shadow + CRSK copy + launches.
+  conv2d_fixed_padding (nets/model_helper.py:67-78)."""
+
+  def __init__(self, ctx: Ctx, k: int, cin: int, cout: int, layer_name: Optional[str] = None,
+               dense: bool = False, stem: bool = False, need_dgrad: bool = True):
+    layer = ctx.unique('dense' if dense else 'conv2d') if layer_name is None else layer_name
+    self.name = ctx.full_name(layer, 'kernel')
+    self.k, self.cin, self.cout = k, cin, cout
+    self.stem = stem           # 3-channel first conv (k in {3,7}, stride 2) over the halo buffer
+    self.stem_len = _round_up(4 * k, 8)
+    self.need_dgrad = need_dgrad and not stem
+    self.arena = ctx.arena
+    shape = (cout, k, k, cin)
+    init = glorot_uniform_init((cout, cin)) if dense else variance_scaling_init(shape)
+    if dense:
+      shape_init = init
+      init = lambda rng: shape_init(rng).reshape(cout, 1, 1, cin)
+    ctx.arena.register(self.name, shape, True, init)
+    self.kpad = _round_up(cout, 8)  # dy channel stride for the backward of a non-multiple-of-8 Cout
+    self._wt = None
+    self._wpack = None
+    if not ctx.arena.finalized:
+      ctx.arena.derived.append(self._refresh)
+
+  def _refresh(self):
+    a = self.arena
+    dev = a.w32.device
+    if self.stem:
+      if self._wpack is None:
+        self._wpack = torch.empty((self.cout, self.k, 1, self.stem_len), dtype=torch.bfloat16, device=dev)
+      ops.stem_pack_filter(a.w(self.name), self._wpack, self.cout, self.k)
+    if self.need_dgrad:
+      if self._wt is None:
+        self._wt = torch.zeros((self.cin, self.k, self.k, self.kpad), dtype=torch.bfloat16, device=dev)
+      ops.filter_transpose(a.wb(self.name), self._wt, self.cout, self.k, self.k, self.cin, self.kpad)
+
+  # descriptors -------------------------------------------------------------------------------------
+  def desc(self, N, H, W, stride, out_f32=False, ldy=0):
+    if self.stem:
+      # k x k / 2 first conv over the zero-haloed [N][H+6][W+6][4] buffer: R=k, S=1, "C" = stem_len
+      # (a row of k pixels x 4 channels is contiguous; 7x7 -> 32 elements, 3x3 -> 16)
+      Hp, Wp = H + 6, W + 6
+      return ops.make_conv_desc(N, Hp, Wp, self.stem_len, self.cout, self.k, 1, 2, pad=0,
+                                Ho=ops.out_size(H, self.k, 2), Wo=ops.out_size(W, self.k, 2),
+                                img_pitch=Hp * Wp * 4, row_pitch=Wp * 4, pix_pitch=4, ldy=ldy, out_f32=out_f32)
+    return ops.make_conv_desc(N, H, W, self.cin, self.cout, self.k, self.k, stride, ldy=ldy, out_f32=out_f32)
+
+  def weight(self):
+    return self._wpack if self.stem else self.arena.wb(self.name)
+
+  def _stem_view(self, x: torch.Tensor) -> torch.Tensor:
+    """The halo buffer has 3 zero pixels on every side; a k x k conv needs (k-1)//2, so start the
+    view (3 - pad) rows / pixels in (a 16-byte aligned element offset)."""
+    off = 3 - (self.k - 1) // 2
+    if off == 0:
+      return x
+    Wp = x.shape[2]
+    return x.view(-1)[(off * Wp + off) * 4:]
+
+  def fprop(self, d, x: torch.Tensor, want_stats: bool):
+    if self.stem:
+      x = self._stem_view(x)
+    return ops.conv_fprop(d, x, self.weight(), want_stats)
+
+  def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool) -> Optional[torch.Tensor]:
+    """dW into the gradient arena; returns dx (or None)."""
+    a = self.arena
+    if self.stem:
+      dwp = torch.empty((self.cout, self.k, self.stem_len), dtype=torch.float32, device=x.device)
+      ops.conv_wgrad(d, self._stem_view(x), dy, dwp)
+      ops.stem_unpack_grad(dwp, a.g(self.name), self.cout, self.k)
+      return None
+    ops.conv_wgrad(d, x, dy, a.g(self.name))
+    if not need_dx:
+      return None
+    if self.kpad != self.cout:  # dy carries kpad channels (zero padded)
+      dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, self.kpad, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo)
+      return ops.conv_dgrad(dd, dy, self._wt)
+    return ops.conv_dgrad(d, dy, self._wt)
+
+
+class BatchNorm(object):
+  """batch_norm (nets/model_helper.py:26-37): parameters + moving statistics."""
+
+  def __init__(self, ctx: Ctx, c: int, zero_gamma: bool = False, layer_name: Optional[str] = None):
+    layer = ctx.unique('batch_normalization') if layer_name is None else layer_name
+    self.c = c
+    self.arena = ctx.arena
+    self.gamma = ctx.full_name(layer, 'gamma')
+    self.beta = ctx.full_name(layer, 'beta')
+    self.mm = ctx.full_name(layer, 'moving_mean')
+    self.mv = ctx.full_name(layer, 'moving_variance')
+    ctx.arena.register(self.gamma, (c,), False, const_init((c,), 0.0 if zero_gamma else 1.0))
+    ctx.arena.register(self.beta, (c,), False, const_init((c,), 0.0))
+    ctx.arena.register_state(self.mm, (c,), 0.0)
+    ctx.arena.register_state(self.mv, (c,), 1.0)
+
+
+def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu: bool,
+            residual: Optional[Var] = None, res_mode: int = 0, tap_pre: Optional[str] = None) -> Var:
+  """conv2d_fixed_padding -> batch_norm [-> + residual] [-> relu], forward and (taped) backward.
+
+  res_mode 1: residual has the output shape; 2: residual is [N, H/2, W/2, C] and is nearest-upsampled
+  (UpSampling2D((2,2)) + add of the BigLittle merge, nets/resnet_model.py:499-501)."""
+  if conv.stem:
+    N, Hp, Wp, _ = x.shape
+    H, W = Hp - 6, Wp - 6
+  else:
+    N, H, W, _ = x.shape
+  d = conv.desc(N, H, W, stride)
+  out_shape = (N, d.Ho, d.Wo, conv.cout)
+  if ctx.dry:
+    return Var(None, out_shape)
+  a = ctx.arena
+  M = N * d.Ho * d.Wo
+  Cn = conv.cout
+  gamma, beta = a.w(bn.gamma), a.w(bn.beta)
+  res_t = residual.data if residual is not None else None
+  if ctx.training:
+    y, part = conv.fprop(d, x.data, True)
+    mean, invstd, scale, shift = ops.bn_finalize(part, M, Cn, gamma, beta, BN_EPS, ctx.bn_momentum,
+                                                 a.st(bn.mm), a.st(bn.mv))
+  else:
+    y, _ = conv.fprop(d, x.data, False)
+    scale, shift = ops.bn_infer_coeffs(Cn, gamma, beta, a.st(bn.mm), a.st(bn.mv), BN_EPS)
+    mean = invstd = None
+  if tap_pre is not None:
+    ctx.taps[tap_pre] = y
+  if tap_pre is not None:
+    ctx.taps[tap_pre] = y
+  out_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, res_mode if residual is not None else 0, relu, d.Ho, d.Wo)
+  out = Var(out_t)
+
+  if ctx.tape is not None:
+    x_t = x.data
+
+    def bwd():
+      dout = out.grad
+      if dout is None:
+        raise RuntimeError('conv_bn backward: no gradient reached this layer')
+      want_dz = residual is not None and relu
+      dy, dz = ops.bn_bwd(dout, y, out_t, relu, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), want_dz)
+      if residual is not None:
+        dres = dz if relu else dout
+        if res_mode == 2:
+          accum_grad(residual, ops.upsample2x_bwd(dres), True)
+        else:
+          accum_grad(residual, dres, relu)
+      dx = conv.backward(d, x_t, dy, x.needs_grad)
+      if dx is not None:
+        accum_grad(x, dx, True)
+      out.grad = None
+    ctx.record(bwd)
+  return out
+
+
+def conv_plain(ctx: Ctx, x: Var, conv: ConvKernel, out_f32: bool, ldy: int = 0):
+  """A bare 1x1 conv (SK fc2, SE fc, dense).  Returns (tensor, backward(dy_tensor) -> None)."""
+  N, H, W, _ = x.shape
+  d = conv.desc(N, H, W, 1, out_f32=out_f32, ldy=ldy)
+  if ctx.dry:
+    return None, None, (N, d.Ho, d.Wo, ldy if ldy else conv.cout)
+  y, _ = conv.fprop(d, x.data, False)
+  x_t = x.data
+
+  def bwd(dy: torch.Tensor):
+    # dy: bf16 with channel stride == ldy (or cout)
+    dd = d
+    if ldy and ldy != conv.cout:
+      dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo, ldy=ldy)
+    dx = conv.backward(dd, x_t, dy, x.needs_grad)
+    if dx is not None:
+      accum_grad(x, dx, True)
+  return y, bwd, tuple(y.shape)
+
+
+class SKUnit(object):
+  """blocks.sk_conv2d (nets/blocks.py:110-154)."""
+
+  def __init__(self, ctx: Ctx, cin: int, filters: int, r: int = 2, L: int = 32):
+    self.filters = filters
+    self.conv = ConvKernel(ctx, 3, cin, filters * 2)
+    self.bn = BatchNorm(ctx, filters * 2)
+    self.d = max(int(filters / r), L)
+    ctx.push_scope('sk_block')
+    self.fc1 = ConvKernel(ctx, 1, filters, self.d, layer_name='sk_fc_1')
+    self.bn1 = BatchNorm(ctx, self.d)
+    self.fc2 = ConvKernel(ctx, 1, self.d, filters * 2, layer_name='sk_fc_2')
+    ctx.pop_scope()
+
+  def __call__(self, ctx: Ctx, x: Var, stride: int) -> Var:
+    F_ = self.filters
+    f = conv_bn(ctx, x, self.conv, self.bn, stride, relu=True)
+    N, H, W, _ = f.shape
+    if ctx.dry:
+      return Var(None, (N, H, W, F_))
+    s = Var(ops.sk_gap(f.data, F_))                                   # mean_hw(f0 + f1)  :131-134
+    z = conv_bn(ctx, s, self.fc1, self.bn1, 1, relu=True)            # :137-143
+    att, fc2_bwd, _ = conv_plain(ctx, z, self.fc2, out_f32=True)      # :144-148 (fp32 logits)
+    v_t = ops.sk_select_fwd(f.data, att, F_)                          # :149-152
+    v = Var(v_t)
+    if ctx.tape is not None:
+      # tape order: [conv_bn(f), conv_bn(z)] were recorded already; backward must run
+      #   select_bwd_att -> fc2 bwd -> conv_bn(z) bwd -> select_bwd_f -> conv_bn(f) bwd
+      # so the z / f closures are pulled off the tape and re-sequenced here.
+      bwd_z = ctx.tape.pop()
+      bwd_f = ctx.tape.pop()
+      f_t = f.data
+
+      def bwd():
+        dv = v.grad
+        datt = ops.sk_select_bwd_att(f_t, dv, att, F_)
+        fc2_bwd(datt)                      # -> z.grad
+        bwd_z()                            # -> s.grad
+        df = ops.sk_select_bwd_f(dv, att, s.grad, F_)
+        s.grad = None
+        accum_grad(f, df, True)
+        bwd_f()                            # -> x.grad
+        v.grad = None
+      ctx.record(bwd)
+    return v
+
+
+class SEUnit(object):
+  """blocks.se_block (nets/blocks.py:156-184)."""
+
+  def __init__(self, ctx: Ctx, c: int, ratio: int = 16):
+    self.c = c
+    ctx.push_scope('se_block')
+    self.fc1 = ConvKernel(ctx, 1, c, c // ratio, layer_name='seblock_dense_1')
+    self.fc2 = ConvKernel(ctx, 1, c // ratio, c, layer_name='seblock_dense_2')
+    ctx.pop_scope()
+
+  def __call__(self, ctx: Ctx, x: Var) -> Var:
+    if ctx.dry:
+      return Var(None, x.shape)
+    sq = Var(ops.gap_fwd(x.data))
+    e1_t, fc1_bwd, _ = conv_plain(ctx, sq, self.fc1, out_f32=False)
+    e1r = Var(ops.relu_fwd(e1_t))
+    e_t, fc2_bwd, _ = conv_plain(ctx, e1r, self.fc2, out_f32=True)
+    y = Var(ops.se_scale_fwd(x.data, e_t))
+    if ctx.tape is not None:
+      x_t = x.data
+
+      def bwd():
+        dy = y.grad
+        de = ops.se_scale_bwd_e(x_t, dy, e_t)
+        fc2_bwd(de)                                     # -> e1r.grad
+        fc1_bwd(ops.relu_bwd(e1r.grad, e1r.data))       # -> sq.grad
+        accum_grad(x, ops.se_scale_bwd_x(dy, e_t, sq.grad), True)
+        e1r.grad = sq.grad = y.grad = None
+      ctx.record(bwd)
+    return y
+
+
+# ---- pools ---------------------------------------------------------------------------------------------
+def max_pool_3x3_s2_same(ctx: Ctx, x: Var) -> Var:
+  """tf.layers.max_pooling2d(3, 2, 'SAME') (nets/resnet_model.py:421-424)."""
+  N, H, W, Cn = x.shape
+  if ctx.dry:
+    return Var(None, (N, (H + 1) // 2, (W + 1) // 2, Cn))
+  y_t, am = ops.maxpool3x3s2_fwd(x.data)
+  y = Var(y_t)
+  if ctx.tape is not None:
+    def bwd():
+      accum_grad(x, ops.maxpool3x3s2_bwd(y.grad, am, x.shape), True)
+      y.grad = None
+    ctx.record(bwd)
+  return y
+
+
+def avg_pool(ctx: Ctx, x: Var, k: int, stride: int, pad: int, count_valid: bool) -> Var:
+  """fixed_padding + tf.layers.average_pooling2d of the ResNet-D / BL shortcuts (nets/resnet_model.py:123-141)."""
+  N, H, W, Cn = x.shape
+  if count_valid:   # SAME, stride 1
+    Ho, Wo = H, W
+  else:             # zero pad (k-1)//2 before / rest after, then VALID
+    Ho, Wo = (H + (k - 1) - k) // stride + 1, (W + (k - 1) - k) // stride + 1
+  if ctx.dry:
+    return Var(None, (N, Ho, Wo, Cn))
+  y = Var(ops.avgpool_fwd(x.data, k, stride, pad, Ho, Wo, count_valid))
+  if ctx.tape is not None:
+    def bwd():
+      accum_grad(x, ops.avgpool_bwd(y.grad, x.shape, k, stride, pad, count_valid), True)
+      y.grad = None
+    ctx.record(bwd)
+  return y
+
+
+def blur_pool(ctx: Ctx, x: Var, k: int, stride: int) -> Var:
+  """blocks.anti_aliased_downsample (nets/blocks.py:45-107)."""
+  N, H, W, Cn = x.shape
+  if k == 1:
+    raise NotImplementedError('anti_alias_filter_size=1 hard-codes NCHW slicing in the reference (blocks.py:79-84)')
+  if ctx.dry:
+    return Var(None, (N, ops.blur_out_size(H, k, stride), ops.blur_out_size(W, k, stride), Cn))
+  y = Var(ops.blurpool_fwd(x.data, k, stride))
+  if ctx.tape is not None:
+    def bwd():
+      accum_grad(x, ops.blurpool_bwd(y.grad, x.shape, k, stride), True)
+      y.grad = None
+    ctx.record(bwd)
+  return y
+
+
+def global_avg_pool(ctx: Ctx, x: Var) -> Var:
+  N, H, W, Cn = x.shape
+  if ctx.dry:
+    return Var(None, (N, 1, 1, Cn))
+  y = Var(ops.gap_fwd(x.data))
+  if ctx.tape is not None:
+    def bwd():
+      accum_grad(x, ops.gap_bwd(y.grad, x.shape), True)
+      y.grad = None
+    ctx.record(bwd)
+  return y

@@ -1,0 +1,416 @@
+"""Tensor-level wrappers over the C ABI (include/asm_hip.h).
+
+PyTorch is used only for device memory (torch.empty), streams and tensor handles; every arithmetic
+op below is a HIP kernel in libasm_hip.so.  There is no CPU fallback: tensors must live on the GPU.
+(The test-suite substitutes a CPU double of the C ABI via ``set_library`` to exercise the host logic
+in this package without a GPU; the double lives under tests/ and is never used by the product.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _lib
+from .lib import ConvDesc, check
+
+_L = None          # the bound library (or the test double)
+_IS_DOUBLE = False
+
+
+def set_library(obj, is_double: bool = False):
+  """Install the C-ABI provider (tests only)."""
+  global _L, _IS_DOUBLE
+  _L = obj
+  _IS_DOUBLE = is_double
+
+
+def L():
+  global _L
+  if _L is None:
+    _L = _lib.load()
+  return _L
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+  if t is None:
+    return 0
+  if not _IS_DOUBLE and not t.is_cuda:
+    raise _lib.AsmError('assembled_cnn_amd ops need GPU tensors (no CPU fallback)')
+  if not t.is_contiguous():
+    raise ValueError('tensor must be contiguous')
+  return t.data_ptr()
+
+
+def _stream() -> int:
+  if _IS_DOUBLE:
+    return 0
+  return torch.cuda.current_stream().cuda_stream
+
+
+def empty(shape, dtype, like: torch.Tensor) -> torch.Tensor:
+  return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------------
+def out_size(in_size: int, k: int, stride: int) -> int:
+  """conv2d_fixed_padding output size (nets/model_helper.py:67-78): SAME for stride 1,
+  fixed_padding(k) + VALID for stride > 1 -> (in + k - 1 - k) // s + 1."""
+  if stride == 1:
+    return in_size
+  return (in_size - 1) // stride + 1
+
+
+def make_conv_desc(N, H, W, Cin, K, R, S, stride, pad=None, Ho=None, Wo=None, ldy=0, out_f32=False,
+                   img_pitch=0, row_pitch=0, pix_pitch=0) -> ConvDesc:
+  d = ConvDesc()
+  d.N, d.H, d.W, d.C = N, H, W, Cin
+  d.K, d.R, d.S = K, R, S
+  d.stride = stride
+  d.pad = (R - 1) // 2 if pad is None else pad
+  d.Ho = out_size(H, R, stride) if Ho is None else Ho
+  d.Wo = out_size(W, S, stride) if Wo is None else Wo
+  d.x_img_pitch, d.x_row_pitch, d.x_pix_pitch = img_pitch, row_pitch, pix_pitch
+  d.ldy = ldy
+  d.out_f32 = 1 if out_f32 else 0
+  return d
+
+
+def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool = False
+               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+  """y [N,Ho,Wo,ldy] (bf16 or f32) and, if want_stats, the BN partials [blocks,2,K] (f32)."""
+  ldy = d.ldy if d.ldy else d.K
+  y = empty((d.N, d.Ho, d.Wo, ldy), F32 if d.out_f32 else BF16, x)
+  stats = None
+  if want_stats:
+    stats = empty((L().asm_conv2d_stats_blocks(C.byref(d)), 2, d.K), F32, x)
+  check(L().asm_conv2d_fprop(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(stats), _stream()), 'conv2d_fprop')
+  return y, stats
+
+
+def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor) -> torch.Tensor:
+  dx = empty((d.N, d.H, d.W, d.C), BF16, dy)
+  check(L().asm_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), _stream()), 'conv2d_dgrad')
+  return dx
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, like: torch.Tensor) -> Optional[torch.Tensor]:
+  """One grow-only scratch buffer per device (kernels on one stream run in order)."""
+  if nbytes == 0:
+    return None
+  key = str(like.device)
+  buf = _ws_cache.get(key)
+  if buf is None or buf.numel() < nbytes:
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=like.device)
+    _ws_cache[key] = buf
+  return buf
+
+
+def conv_wgrad(d: ConvDesc, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor):
+  """dw (f32, [K,R,S,C] contiguous view, overwritten)."""
+  need = L().asm_conv2d_wgrad_workspace_bytes(C.byref(d))
+  ws = _workspace(need, x)
+  check(L().asm_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), need, _stream()), 'conv2d_wgrad')
+
+
+def filter_transpose(w: torch.Tensor, wt: torch.Tensor, K, R, S, Cin, ldk=0):
+  check(L().asm_filter_transpose(_ptr(w), _ptr(wt), K, R, S, Cin, ldk, _stream()), 'filter_transpose')
+
+
+def stem_pack_filter(w32: torch.Tensor, wp: torch.Tensor, K: int, ksize: int):
+  check(L().asm_stem_pack_filter(_ptr(w32), _ptr(wp), K, ksize, _stream()), 'stem_pack_filter')
+
+
+def stem_unpack_grad(dwp: torch.Tensor, dw: torch.Tensor, K: int, ksize: int):
+  check(L().asm_stem_unpack_grad(_ptr(dwp), _ptr(dw), K, ksize, _stream()), 'stem_unpack_grad')
+
+
+def stem_pad_input(x: torch.Tensor) -> torch.Tensor:
+  """[N,H,W,3] f32/bf16 -> [N,H+6,W+6,4] bf16 zero halo."""
+  N, H, W, c = x.shape
+  if c != 3:
+    raise ValueError('stem input must have 3 channels')
+  if x.dtype not in (F32, BF16):
+    raise ValueError('stem input dtype must be float32 or bfloat16')
+  xp = empty((N, H + 6, W + 6, 4), BF16, x)
+  check(L().asm_stem_pad_input(_ptr(x), 1 if x.dtype == F32 else 0, _ptr(xp), N, H, W, _stream()), 'stem_pad_input')
+  return xp
+
+
+# ---------------------------------------------------------------------------------------------------
+# batch norm
+# ---------------------------------------------------------------------------------------------------
+def bn_stats(x2d: torch.Tensor, M: int, Cn: int) -> torch.Tensor:
+  blocks = L().asm_bn_stats_blocks(M, Cn)
+  if blocks <= 0:
+    raise ValueError('bn_stats: bad shape')
+  part = empty((blocks, 2, Cn), F32, x2d)
+  check(L().asm_bn_stats(_ptr(x2d), M, Cn, _ptr(part), _stream()), 'bn_stats')
+  return part
+
+
+def bn_finalize(part, M, Cn, gamma, beta, eps, momentum, mm, mv):
+  """-> mean, invstd, scale, shift (each [C] f32); updates moving stats in place when given."""
+  co = empty((4, Cn), F32, part)
+  check(L().asm_bn_finalize(_ptr(part), part.shape[0], M, Cn, _ptr(gamma), _ptr(beta), eps, momentum,
+                            _ptr(mm), _ptr(mv), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _ptr(co[3]),
+                            _stream()), 'bn_finalize')
+  return co[0], co[1], co[2], co[3]
+
+
+def bn_infer_coeffs(Cn, gamma, beta, mm, mv, eps):
+  co = empty((2, Cn), F32, gamma)
+  check(L().asm_bn_infer_coeffs(Cn, _ptr(gamma), _ptr(beta), _ptr(mm), _ptr(mv), eps, _ptr(co[0]), _ptr(co[1]),
+                                _stream()), 'bn_infer_coeffs')
+  return co[0], co[1]
+
+
+def bn_apply(x, M, Cn, scale, shift, residual=None, res_mode=0, relu=False, H=0, W=0):
+  y = torch.empty_like(x)
+  check(L().asm_bn_apply(_ptr(x), _ptr(y), M, Cn, _ptr(scale), _ptr(shift), _ptr(residual), res_mode,
+                         1 if relu else 0, H, W, _stream()), 'bn_apply')
+  return y
+
+
+def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz):
+  """-> dx, dz (dz None unless want_dz).  dgamma/dbeta: f32 [C] views, overwritten."""
+  blocks = L().asm_bn_stats_blocks(M, Cn)
+  part = empty((blocks, 2, Cn), F32, dy)
+  check(L().asm_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(yout if relu else None), 1 if relu else 0, M, Cn,
+                              _ptr(mean), _ptr(invstd), _ptr(part), _stream()), 'bn_bwd_reduce')
+  co = empty((3, Cn), F32, dy)
+  check(L().asm_bn_bwd_finalize(_ptr(part), blocks, M, Cn, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma),
+                                _ptr(dbeta), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _stream()), 'bn_bwd_finalize')
+  dx = torch.empty_like(x)
+  dz = torch.empty_like(x) if want_dz else None
+  check(L().asm_bn_bwd_apply(_ptr(dy), _ptr(x), _ptr(yout if relu else None), 1 if relu else 0, M, Cn,
+                             _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _ptr(dx), _ptr(dz), _stream()), 'bn_bwd_apply')
+  return dx, dz
+
+
+# ---------------------------------------------------------------------------------------------------
+# pooling / resampling
+# ---------------------------------------------------------------------------------------------------
+def maxpool3x3s2_fwd(x):
+  N, H, W, Cn = x.shape
+  Ho, Wo = (H + 1) // 2, (W + 1) // 2
+  y = empty((N, Ho, Wo, Cn), BF16, x)
+  am = empty((N, Ho, Wo, Cn), torch.uint8, x)
+  check(L().asm_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(am), N, H, W, Cn, _stream()), 'maxpool_fwd')
+  return y, am
+
+
+def maxpool3x3s2_bwd(dy, am, in_shape):
+  N, H, W, Cn = in_shape
+  dx = empty(in_shape, BF16, dy)
+  check(L().asm_maxpool3x3s2_bwd(_ptr(dy), _ptr(am), _ptr(dx), N, H, W, Cn, _stream()), 'maxpool_bwd')
+  return dx
+
+
+def avgpool_fwd(x, k, stride, pad, Ho, Wo, count_valid):
+  N, H, W, Cn = x.shape
+  y = empty((N, Ho, Wo, Cn), BF16, x)
+  check(L().asm_avgpool_fwd(_ptr(x), _ptr(y), N, H, W, Cn, k, stride, pad, Ho, Wo, 1 if count_valid else 0,
+                            _stream()), 'avgpool_fwd')
+  return y
+
+
+def avgpool_bwd(dy, in_shape, k, stride, pad, count_valid):
+  N, H, W, Cn = in_shape
+  dx = empty(in_shape, BF16, dy)
+  check(L().asm_avgpool_bwd(_ptr(dy), _ptr(dx), N, H, W, Cn, k, stride, pad, dy.shape[1], dy.shape[2],
+                            1 if count_valid else 0, _stream()), 'avgpool_bwd')
+  return dx
+
+
+def upsample2x_bwd(dy):
+  N, H, W, Cn = dy.shape
+  dx = empty((N, H // 2, W // 2, Cn), BF16, dy)
+  check(L().asm_upsample2x_bwd(_ptr(dy), _ptr(dx), N, H // 2, W // 2, Cn, _stream()), 'upsample2x_bwd')
+  return dx
+
+
+def blur_out_size(n, k, stride):
+  return (n + 2 * ((k - 1) // 2) - k) // stride + 1
+
+
+def blurpool_fwd(x, k, stride):
+  N, H, W, Cn = x.shape
+  y = empty((N, blur_out_size(H, k, stride), blur_out_size(W, k, stride), Cn), BF16, x)
+  check(L().asm_blurpool_fwd(_ptr(x), _ptr(y), N, H, W, Cn, k, stride, _stream()), 'blurpool_fwd')
+  return y
+
+
+def blurpool_bwd(dy, in_shape, k, stride):
+  N, H, W, Cn = in_shape
+  dx = empty(in_shape, BF16, dy)
+  check(L().asm_blurpool_bwd(_ptr(dy), _ptr(dx), N, H, W, Cn, k, stride, _stream()), 'blurpool_bwd')
+  return dx
+
+
+def gap_fwd(x):
+  N, H, W, Cn = x.shape
+  y = empty((N, 1, 1, Cn), BF16, x)
+  check(L().asm_gap_fwd(_ptr(x), _ptr(y), N, H * W, Cn, _stream()), 'gap_fwd')
+  return y
+
+
+def gap_bwd(dy, in_shape):
+  N, H, W, Cn = in_shape
+  dx = empty(in_shape, BF16, dy)
+  check(L().asm_gap_bwd(_ptr(dy), _ptr(dx), N, H * W, Cn, _stream()), 'gap_bwd')
+  return dx
+
+
+# ---------------------------------------------------------------------------------------------------
+# SK / SE
+# ---------------------------------------------------------------------------------------------------
+def sk_gap(f, F_):
+  N, H, W, _ = f.shape
+  s = empty((N, 1, 1, F_), BF16, f)
+  check(L().asm_sk_gap(_ptr(f), _ptr(s), N, H * W, F_, _stream()), 'sk_gap')
+  return s
+
+
+def sk_select_fwd(f, att, F_):
+  N, H, W, _ = f.shape
+  v = empty((N, H, W, F_), BF16, f)
+  check(L().asm_sk_select_fwd(_ptr(f), _ptr(att), _ptr(v), N, H * W, F_, _stream()), 'sk_select_fwd')
+  return v
+
+
+def sk_select_bwd_att(f, dv, att, F_):
+  N, H, W, _ = f.shape
+  datt = empty((N, 1, 1, 2 * F_), BF16, f)
+  check(L().asm_sk_select_bwd_att(_ptr(f), _ptr(dv), _ptr(att), _ptr(datt), N, H * W, F_, _stream()),
+        'sk_select_bwd_att')
+  return datt
+
+
+def sk_select_bwd_f(dv, att, ds, F_):
+  N, H, W, _ = dv.shape
+  df = empty((N, H, W, 2 * F_), BF16, dv)
+  check(L().asm_sk_select_bwd_f(_ptr(dv), _ptr(att), _ptr(ds), _ptr(df), N, H * W, F_, _stream()), 'sk_select_bwd_f')
+  return df
+
+
+def se_scale_fwd(x, e):
+  N, H, W, Cn = x.shape
+  y = torch.empty_like(x)
+  check(L().asm_se_scale_fwd(_ptr(x), _ptr(e), _ptr(y), N, H * W, Cn, _stream()), 'se_scale_fwd')
+  return y
+
+
+def se_scale_bwd_e(x, dy, e):
+  N, H, W, Cn = x.shape
+  de = empty((N, 1, 1, Cn), BF16, x)
+  check(L().asm_se_scale_bwd_e(_ptr(x), _ptr(dy), _ptr(e), _ptr(de), N, H * W, Cn, _stream()), 'se_scale_bwd_e')
+  return de
+
+
+def se_scale_bwd_x(dy, e, dsq):
+  N, H, W, Cn = dy.shape
+  dx = torch.empty_like(dy)
+  check(L().asm_se_scale_bwd_x(_ptr(dy), _ptr(e), _ptr(dsq), _ptr(dx), N, H * W, Cn, _stream()), 'se_scale_bwd_x')
+  return dx
+
+
+# ---------------------------------------------------------------------------------------------------
+# element-wise / loss / input / optimiser
+# ---------------------------------------------------------------------------------------------------
+def relu_fwd(x):
+  y = torch.empty_like(x)
+  check(L().asm_relu_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), 'relu_fwd')
+  return y
+
+
+def relu_bwd(dy, y):
+  dx = torch.empty_like(dy)
+  check(L().asm_relu_bwd(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()), 'relu_bwd')
+  return dx
+
+
+def add_bf16(a, b, out=None):
+  if out is None:
+    out = torch.empty_like(a)
+  check(L().asm_add_bf16(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), 'add_bf16')
+  return out
+
+
+def bias_add_f32(y, bias, M, Cn, ldy):
+  check(L().asm_bias_add_f32(_ptr(y), _ptr(bias), M, Cn, ldy, _stream()), 'bias_add')
+
+
+def bias_grad_bf16(dz, M, Cn, ld, dbias):
+  check(L().asm_bias_grad_bf16(_ptr(dz), M, Cn, ld, _ptr(dbias), _stream()), 'bias_grad')
+
+
+def cast_f32_to_bf16(x, y):
+  check(L().asm_cast_f32_to_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), 'cast')
+
+
+def softmax_ce(logits, ld, targets, teacher, B, Cn, label_smoothing, kd_temp, loss_scale, ld_out, want_grad=True):
+  loss_rows = empty((B,), F32, logits)
+  dlogits = empty((B, 1, 1, ld_out), BF16, logits) if want_grad else None
+  check(L().asm_softmax_ce(_ptr(logits), ld, _ptr(targets), _ptr(teacher), B, Cn, label_smoothing, kd_temp,
+                           loss_scale, _ptr(loss_rows), _ptr(dlogits), ld_out, _stream()), 'softmax_ce')
+  return loss_rows, dlogits
+
+
+def onehot(labels_i32, B, Cn):
+  out = empty((B, Cn), F32, labels_i32)
+  check(L().asm_onehot(_ptr(labels_i32), _ptr(out), B, Cn, _stream()), 'onehot')
+  return out
+
+
+def softmax_rows(x, B, Cn, inv_temp):
+  y = torch.empty_like(x)
+  check(L().asm_softmax_rows(_ptr(x), _ptr(y), B, Cn, inv_temp, _stream()), 'softmax_rows')
+  return y
+
+
+def mean_f32(x):
+  out = empty((1,), F32, x)
+  check(L().asm_mean_f32(_ptr(x), x.numel(), _ptr(out), _stream()), 'mean')
+  return out
+
+
+def mixup_meansub(images, mixup_type, lam1, lam2):
+  Bin, H, W, c = images.shape
+  if c != 3:
+    raise ValueError('images must be [B,H,W,3]')
+  if images.dtype == torch.uint8:
+    is_u8 = 1
+  elif images.dtype == F32:
+    is_u8 = 0
+  else:
+    raise ValueError('images must be uint8 or float32 (0..255)')
+  Bout = Bin // 2 if mixup_type == 1 else Bin
+  out = empty((Bout, H + 6, W + 6, 4), BF16, images)
+  check(L().asm_mixup_meansub(_ptr(images), is_u8, Bin, H, W, mixup_type, _ptr(lam1), _ptr(lam2), _ptr(out),
+                              _stream()), 'mixup_meansub')
+  return out
+
+
+def mixup_labels(y, mixup_type, lam1, lam2):
+  Bin, Cn = y.shape
+  Bout = Bin // 2 if mixup_type == 1 else Bin
+  out = empty((Bout, Cn), F32, y)
+  check(L().asm_mixup_labels(_ptr(y), Bin, Cn, mixup_type, _ptr(lam1), _ptr(lam2), _ptr(out), _stream()),
+        'mixup_labels')
+  return out
+
+
+def sgd_momentum(w, accum, grad, w_bf16, lr, momentum, weight_decay, grad_scale):
+  check(L().asm_sgd_momentum(_ptr(w), _ptr(accum), _ptr(grad), _ptr(w_bf16), w.numel(), lr, momentum, weight_decay,
+                             grad_scale, _stream()), 'sgd_momentum')

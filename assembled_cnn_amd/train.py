@@ -1,0 +1,224 @@
+"""One training step of the Assemble-ResNet path on MI355X: the body of the reference's
+``resnet_model_fn`` (nets/run_loop_classification.py:60-234) + ``get_train_op``
+(nets/optimizer_setting.py:23-38), plus the learning-rate schedule (functions/model_fns.py:36-95).
+
+  raw images -> [mixup] + mean-subtract + cast (one fused kernel)        utils/data_util.py:97-158,
+                                                                          preprocessing/imagenet_preprocessing.py:122-155
+  -> Model forward (HIP) -> softmax-CE (+label smoothing) + KD, fused fwd/bwd   losses/cls_losses.py:23-41,
+                                                                          run_loop_classification.py:156-162
+  -> hand-written backward tape -> [gradient all-reduce over RCCL]       official/utils/misc/distribution_utils.py:24-45
+  -> momentum-SGD with the L2 term folded in (one flat launch per decay group)  run_loop_classification.py:166-178
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import torch
+
+from . import ops
+from .model import Model
+
+IMAGENET_NUM_CLASSES = 1001          # functions/data_config.py:44
+IMAGENET_NUM_TRAIN_IMAGES = 1281167  # functions/data_config.py:45-47
+
+
+@dataclass
+class HParams(object):
+  """The flag surface of nets/hparams_config.py (+ official/utils/flags) that reaches the hot path.
+  Names and defaults follow the reference."""
+  # architecture
+  resnet_size: int = 50                       # main_classification.py:35-36
+  resnet_version: int = 1                     # nets/hparams_config.py:170  (2 == BigLittleNet)
+  use_resnet_d: bool = False                  # :150
+  use_se_block: bool = False                  # :154
+  use_sk_block: bool = False                  # :158
+  anti_alias_filter_size: int = 0             # :161
+  anti_alias_type: str = ""                   # :164  substring-matched for 'sconv' / 'proj'
+  bl_alpha: int = 2                           # :177
+  bl_beta: int = 4                            # :180
+  no_downsample: bool = False                 # :120
+  pool_type: str = 'gap'                      # :116
+  embedding_size: int = 0                     # :77
+  zero_gamma: bool = False                    # :214
+  bn_momentum: float = 0.997                  # :73
+  num_classes: int = IMAGENET_NUM_CLASSES
+  # regularisation / loss
+  label_smoothing: float = 0.0                # :201
+  kd_temp: float = 0.0                        # :204
+  mixup_type: int = 0                         # :137
+  weight_decay: float = 4e-5                  # :188
+  use_dropblock: bool = False                 # :192
+  dropblock_kp: List[float] = field(default_factory=lambda: [1.0, 0.9])
+  cls_loss_type: str = 'softmax'              # :98
+  # optimisation
+  base_learning_rate: float = 0.01            # :56
+  learning_rate_decay_type: str = 'exponential'  # :64
+  lr_warmup_epochs: int = 0                   # :212
+  momentum: float = 0.9                       # :69
+  num_epochs_per_decay: float = 2.0           # :48
+  learning_rate_decay_factor: float = 0.94    # :52
+  end_learning_rate: float = 1e-4             # :60
+  piecewise_lr_boundary_epochs: List[int] = field(default_factory=lambda: [30, 60, 80, 90])
+  piecewise_lr_decay_rates: List[float] = field(default_factory=lambda: [1, 0.1, 0.01, 0.001, 1e-4])
+  train_epochs: int = 90                      # main_classification.py:38
+  batch_size: int = 32                        # global batch, official/utils/flags/_base.py:91
+  dtype: str = 'bf16'                         # reference: fp16|fp32 (_performance.py:29-42); bf16 here
+  loss_scale: Optional[float] = None          # fp16 -> 128, else 1 (_performance.py:39-42)
+  num_images_train: int = IMAGENET_NUM_TRAIN_IMAGES
+
+  def get_loss_scale(self) -> float:
+    if self.loss_scale is not None:
+      return float(self.loss_scale)
+    return 128.0 if self.dtype == 'fp16' else 1.0
+
+  def make_model(self, seed=0, device='cuda') -> Model:
+    if self.resnet_size < 50:  # functions/model_fns.py:202-206
+      assert not (self.use_dropblock or self.use_se_block or self.use_sk_block or self.use_resnet_d)
+    return Model(self.resnet_size, None, num_classes=self.num_classes, resnet_version=self.resnet_version,
+                 dtype=self.dtype, no_downsample=self.no_downsample, zero_gamma=self.zero_gamma,
+                 use_se_block=self.use_se_block, use_sk_block=self.use_sk_block, bn_momentum=self.bn_momentum,
+                 embedding_size=self.embedding_size, anti_alias_filter_size=self.anti_alias_filter_size,
+                 anti_alias_type=self.anti_alias_type, pool_type=self.pool_type, loss_type=self.cls_loss_type,
+                 bl_alpha=self.bl_alpha, bl_beta=self.bl_beta, seed=seed, device=device)
+
+
+def learning_rate_with_decay(learning_rate_decay_type, batch_size, batch_denom, num_images, num_epochs_per_decay,
+                             learning_rate_decay_factor, end_learning_rate, piecewise_lr_boundary_epochs,
+                             piecewise_lr_decay_rates, base_lr, warmup_epochs=0, train_epochs=None
+                             ) -> Callable[[int], float]:
+  """functions/model_fns.py:36-95 as a host function of the global step."""
+  initial_learning_rate = base_lr * batch_size / batch_denom
+  batches_per_epoch = num_images / batch_size
+  decay_steps = int(batches_per_epoch * num_epochs_per_decay)
+  kind = learning_rate_decay_type
+  if kind not in ('exponential', 'fixed', 'polynomial', 'piecewise', 'cosine'):
+    raise NotImplementedError(kind)
+
+  def learning_rate_fn(global_step: int) -> float:
+    warmup_steps = int(batches_per_epoch * warmup_epochs)
+    if warmup_steps > 0 and global_step < warmup_steps:
+      return initial_learning_rate * float(global_step) / float(warmup_steps)
+    step = global_step - warmup_steps
+    if kind == 'exponential':
+      return initial_learning_rate * learning_rate_decay_factor ** (step // decay_steps)
+    if kind == 'fixed':
+      return base_lr
+    if kind == 'polynomial':
+      s = min(step, decay_steps)
+      return (initial_learning_rate - end_learning_rate) * (1.0 - s / decay_steps) + end_learning_rate
+    if kind == 'piecewise':
+      boundaries = [int(batches_per_epoch * e) for e in piecewise_lr_boundary_epochs]
+      values = [initial_learning_rate * float(d) for d in piecewise_lr_decay_rates]
+      for b, v in zip(boundaries, values):
+        if global_step <= b:
+          return v
+      return values[-1]
+    total_batches = int(batches_per_epoch * train_epochs) - warmup_steps
+    s = min(step, total_batches)
+    return 0.5 * (1.0 + math.cos(math.pi * s / total_batches)) * initial_learning_rate
+  return learning_rate_fn
+
+
+def lr_fn_from_hparams(p: HParams) -> Callable[[int], float]:
+  """model_fn_cls wiring (functions/model_fns.py:208-219): batch_denom == batch_size."""
+  return learning_rate_with_decay(p.learning_rate_decay_type, p.batch_size, p.batch_size, p.num_images_train,
+                                  p.num_epochs_per_decay, p.learning_rate_decay_factor, p.end_learning_rate,
+                                  p.piecewise_lr_boundary_epochs, p.piecewise_lr_decay_rates, p.base_learning_rate,
+                                  warmup_epochs=p.lr_warmup_epochs, train_epochs=p.train_epochs)
+
+
+class Trainer(object):
+  """Holds the model + optimiser state and runs training steps.  ``grad_sync`` (see dp.py) is called
+  between backward and the optimiser with the flat fp32 gradient arena."""
+
+  def __init__(self, hparams: HParams, seed: int = 0, device='cuda', grad_sync=None, world_size: int = 1):
+    self.p = hparams
+    self.model = hparams.make_model(seed, device)
+    self.lr_fn = lr_fn_from_hparams(hparams)
+    self.global_step = 0
+    self.grad_sync = grad_sync
+    self.world_size = world_size
+    self.last = {}
+
+  # -----------------------------------------------------------------------------------------------
+  def prepare_inputs(self, images, labels, lam1=None, lam2=None):
+    """images: [Bin,H,W,3] uint8 / float32 (0..255).  labels: int32 [Bin] or, with kd_temp > 0,
+    float32 [Bin, 2C] = concat(one-hot, teacher logits) (run_loop_classification.py:90-96).
+    Returns (stem input halo buffer, dense targets, teacher probabilities or None)."""
+    p = self.p
+    C = p.num_classes
+    Bin = images.shape[0]
+    if p.kd_temp > 0:
+      if labels.dim() != 2 or labels.shape[1] != 2 * C:
+        raise ValueError('kd_temp > 0 expects labels [B, 2*num_classes]')
+      onehot = labels[:, :C].contiguous()
+      teacher = ops.softmax_rows(labels[:, C:].contiguous(), Bin, C, 1.0 / p.kd_temp)
+    else:
+      onehot = ops.onehot(labels.to(torch.int32).contiguous(), Bin, C)
+      teacher = None
+    mt = p.mixup_type
+    if mt not in (0, 1, 2):
+      raise ValueError('mixup_type must be 0, 1 or 2')
+    if mt and lam1 is None:
+      raise ValueError('mixup needs the Beta(0.2, 0.2) draws (lam1 [, lam2])')
+    x = ops.mixup_meansub(images.contiguous(), mt, lam1, lam2)
+    if mt:
+      onehot = ops.mixup_labels(onehot, mt, lam1, lam2)
+      if teacher is not None:
+        if mt == 2:
+          # the reference mixes the second-half teacher targets from the HARD labels y1 (data_util.py:154);
+          # reproduce: first half from teacher, second half = lam2*y1 + (1-lam2)*reverse(y2_t)
+          raise NotImplementedError('mixup_type=2 together with KD is not implemented on the HIP path')
+        teacher = ops.mixup_labels(teacher, mt, lam1, lam2)
+    return x, onehot, teacher
+
+  def sample_mixup_lambdas(self, n: int, alpha: float = 0.2, rng=None):
+    """Beta(alpha, alpha) draws on the host (utils/data_util.py:98,105), uploaded as float32."""
+    import numpy as np
+    rng = rng if rng is not None else np.random.default_rng()
+    lam = rng.beta(alpha, alpha, size=n).astype(np.float32)
+    return torch.from_numpy(lam).to(self.model.device)
+
+  # -----------------------------------------------------------------------------------------------
+  def train_step(self, images, labels, lam1=None, lam2=None, lr: Optional[float] = None):
+    p = self.p
+    m = self.model
+    x, onehot, teacher = self.prepare_inputs(images, labels, lam1, lam2)
+    B = x.shape[0]
+    m(x, True, use_resnet_d=p.use_resnet_d, prepadded=True)
+    if p.cls_loss_type != 'softmax':
+      raise NotImplementedError('cls_loss_type=%s is not implemented on the HIP path' % p.cls_loss_type)
+    loss_scale = p.get_loss_scale()
+    loss_rows, dlogits = ops.softmax_ce(m.logits_padded, m.ldc, onehot, teacher, B, p.num_classes,
+                                        p.label_smoothing, p.kd_temp, loss_scale, m.ldc)
+    m.backward(dlogits)
+    a = m.arena
+    if self.grad_sync is not None:
+      self.grad_sync(a.g32)
+    lr = self.lr_fn(self.global_step) if lr is None else lr
+    gs = 1.0 / (loss_scale * self.world_size)   # un-scale the loss scale; SUM-all-reduce -> mean over replicas
+    nd = a.decay_elems
+    if nd:
+      ops.sgd_momentum(a.w32[:nd], a.m32[:nd], a.g32[:nd], a.w16[:nd], lr, p.momentum, p.weight_decay, gs)
+    if a.total_elems > nd:
+      ops.sgd_momentum(a.w32[nd:], a.m32[nd:], a.g32[nd:], a.w16[nd:], lr, p.momentum, 0.0, gs)
+    a.refresh_derived()
+    self.global_step += 1
+    self.last = {'loss_rows': loss_rows, 'lr': lr}
+    return loss_rows
+
+  def cross_entropy(self) -> torch.Tensor:
+    """mean over the batch of (CE + KD) of the last step (device scalar)."""
+    return ops.mean_f32(self.last['loss_rows'])
+
+  def l2_loss(self) -> torch.Tensor:
+    """weight_decay * sum(0.5 * w^2) over the decayed set -- reporting only (host-side torch reduce)."""
+    a = self.model.arena
+    return 0.5 * self.p.weight_decay * (a.w32[:a.decay_elems].double() ** 2).sum()
+
+  # -----------------------------------------------------------------------------------------------
+  def eval_logits(self, images_meansub_nhwc: torch.Tensor) -> torch.Tensor:
+    """Inference forward (BN moving statistics), logits float32 [B, C]."""
+    return self.model(images_meansub_nhwc, False, use_resnet_d=self.p.use_resnet_d)

@@ -1,0 +1,234 @@
+/*
+ * asm_hip.h -- C ABI of libasm_hip.so: the MI355X (gfx950) kernels behind the Assemble-ResNet
+ * training path of clovaai/assembled-cnn.
+ *
+ * The reference has no FFI / plugin interface (it is straight-line Python over TensorFlow 1.14,
+ * SURVEY.md section 8b); every arithmetic op it runs lives inside TF.  Each entry point below names
+ * the reference call site whose TF op it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ASM_OK, <0 = error; asm_last_error() gives a thread-local message.
+ *       ASM_EINVAL  (bad shape / flag)   ~ the reference's ValueError / assert
+ *       ASM_ENOTSUP (unsupported combo)  ~ the reference's NotImplementedError
+ *       ASM_EHIP    (a hipError_t was raised by the launch)
+ *   - all pointers are DEVICE pointers owned by the caller, 16-byte aligned.  The library never
+ *     allocates device memory; scratch is passed in (see *_workspace_bytes).
+ *   - activations: NHWC bfloat16 (C % 8 == 0); conv filters: KRSC bfloat16 ([Cout][R][S][Cin]);
+ *     statistics, BN parameters, master weights, gradients of parameters: float32.
+ *   - every launch takes the hipStream_t to enqueue on (as void*); calls are asynchronous and
+ *     hold no global mutable state, so they are re-entrant across streams/threads.
+ */
+#ifndef ASM_HIP_H_
+#define ASM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASM_OK 0
+#define ASM_EINVAL (-1)
+#define ASM_ENOTSUP (-2)
+#define ASM_EHIP (-3)
+
+#define ASM_ABI_VERSION 1
+
+const char* asm_last_error(void);
+int asm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution -- replaces tf.layers.conv2d inside conv2d_fixed_padding (nets/model_helper.py:67-78),
+ * the 1x1 "fc" convs of sk_conv2d / se_block (nets/blocks.py:139-147,172-181), the embedding conv
+ * (nets/resnet_model.py:576-580) and tf.layers.dense (nets/resnet_model.py:595-597; a 1x1 conv on a
+ * 1x1 image).  No bias (use_bias=False everywhere on this path; dense bias is added by asm_bias_add).
+ *
+ * Geometry: input  x [N, H, W, C] with element pitches (img_pitch, row_pitch, pix_pitch) so that a
+ * pre-padded or channel-padded buffer can be addressed (the 7x7x3 stem runs as R=7,S=1,C=32 over a
+ * [N][H+6][W+6][4] halo buffer: 8 pixels x 4 channels are one contiguous 32-element row).
+ * Output y [N*Ho*Wo, K] row-major with row stride ldy.
+ *   out(n, ho, wo, k) = sum_{r,s,c} x(n, ho*stride + r - pad, wo*stride + s - pad, c) * w(k, r, s, c)
+ * which is exactly fixed_padding((k-1)//2 before) + VALID for stride>1 and SAME for stride 1.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asm_conv_desc {
+  int32_t N, H, W, C;       /* input tensor logical dims                                           */
+  int32_t K, R, S;          /* filter dims                                                         */
+  int32_t stride, pad;      /* pad = rows/cols of zeros BEFORE (top/left); after is implied by Ho  */
+  int32_t Ho, Wo;           /* output spatial dims                                                 */
+  int64_t x_img_pitch;      /* elements between images     (0 => H*W*C)                            */
+  int32_t x_row_pitch;      /* elements between rows       (0 => W*C)                              */
+  int32_t x_pix_pitch;      /* elements between pixels     (0 => C)                                */
+  int32_t ldy;              /* output row stride in elements (0 => K)                              */
+  int32_t out_f32;          /* 0: bf16 output, 1: float32 output                                   */
+} asm_conv_desc;
+
+/* y = conv(x, w).  If stats_partial != NULL (bf16 output only) the kernel also writes per-channel
+ * partial sums of the bf16-rounded outputs: stats_partial[mb][0][k] = sum, [mb][1][k] = sum of
+ * squares over the rows of M-block mb (128 rows each); asm_conv2d_stats_blocks() gives the number
+ * of M-blocks.  This is the first half of tf.layers.batch_normalization(fused=True,training=True)
+ * (nets/model_helper.py:26-37) fused into the producing conv. */
+int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const void* w, void* y,
+                     float* stats_partial, void* stream);
+int asm_conv2d_stats_blocks(const asm_conv_desc* d);
+
+/* dx = conv_transpose(dy, w).  wt is the filter in [C][R][S][K] layout (asm_filter_transpose).
+ * Gradient of tf.layers.conv2d w.r.t. its input, which TF autodiff provides to
+ * optimizer.compute_gradients (nets/optimizer_setting.py:30). */
+int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream);
+
+/* dw[k][r][s][c] (float32) = sum_{n,ho,wo} dy(n,ho,wo,k) * x(n, ho*stride+r-pad, wo*stride+s-pad, c).
+ * Split-K over output pixels; `workspace` holds the per-split slabs. */
+size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d);
+int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const void* dy, float* dw,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* KRSC bf16 -> CRSK bf16 (the dgrad operand).  ldk = K-stride of the output rows (0 => K); columns
+ * k >= K of a padded output are left untouched (keep them zero). */
+int asm_filter_transpose(const void* w_krsc, void* w_crsk, int K, int R, int S, int C, int ldk, void* stream);
+
+/* Debug / test-only direct convolutions (one thread per output element, fp32 accumulate).  They
+ * exist so GPU tests can cross-check the MFMA kernels at sizes the CPU oracle cannot reach. */
+int asm_conv2d_fprop_naive(const asm_conv_desc* d, const void* x, const void* w, void* y, void* stream);
+int asm_conv2d_dgrad_naive(const asm_conv_desc* d, const void* dy, const void* w_krsc, void* dx, void* stream);
+int asm_conv2d_wgrad_naive(const asm_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+
+/* Debug: each lane l of one wave reads ds_read_b64_tr_b16 at LDS element 4*l of lds[i] = i; out[l*4+j]. */
+int asm_debug_tr_probe(void* out256_i16, void* stream);
+
+/* Stem packing for 3-channel first convs (7x7/2 stem nets/resnet_model.py:359-367; 3x3/2 ResNet-D stem
+ * :328-333,:344-347): master [K][k][k][3] float32 -> bf16 [K][k][L] rows with L = round_up(4k, 8)
+ * (element s*4+c, zero padded), and the gradient unpack [K][k][L] float32 -> [K][k][k][3]. */
+int asm_stem_pack_filter(const float* w_krsc3, void* w_packed, int K, int ksize, void* stream);
+int asm_stem_unpack_grad(const float* dw_packed, float* dw_krsc3, int K, int ksize, void* stream);
+/* [N,H,W,3] (float32 or bf16) -> zero-haloed [N][H+6][W+6][4] bf16. */
+int asm_stem_pad_input(const void* x, int x_is_f32, void* xp, int N, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch normalisation -- tf.layers.batch_normalization(fused=True) via batch_norm
+ * (nets/model_helper.py:26-37), plus the tf.nn.relu / residual add / UpSampling2D+add that follow
+ * it in _bottleneck_block_v1 (nets/resnet_model.py:50-55,92-95) and the BL merge (:499-501).
+ * x: [M, C] bf16 (M = N*H*W).  All per-channel arrays float32.
+ * ---------------------------------------------------------------------------------------------- */
+int asm_bn_stats_blocks(int M, int C);
+/* stand-alone partial statistics (same [blocks][2][C] layout as the conv epilogue) */
+int asm_bn_stats(const void* x, int M, int C, float* stats_partial, void* stream);
+/* partials -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; moving stats update
+ * m <- m*momentum + (1-momentum)*batch  (variance Bessel-corrected for the moving average). */
+int asm_bn_finalize(const float* stats_partial, int blocks, int M, int C, const float* gamma,
+                    const float* beta, float eps, float momentum, float* moving_mean,
+                    float* moving_var, float* mean, float* invstd, float* scale, float* shift,
+                    void* stream);
+/* eval mode: scale/shift from the moving statistics */
+int asm_bn_infer_coeffs(int C, const float* gamma, const float* beta, const float* moving_mean,
+                        const float* moving_var, float eps, float* scale, float* shift, void* stream);
+/* y = [relu]( x*scale[c] + shift[c] [+ residual] ).  res_mode: 0 none, 1 same shape,
+ * 2 residual is [N, H/2, W/2, C] and is nearest-upsampled 2x (needs H, W). */
+int asm_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift,
+                 const void* residual, int res_mode, int relu, int H, int W, void* stream);
+/* backward.  dy: grad of the output y; yout: the forward output (for the ReLU mask; may be NULL
+ * when relu == 0).  Pass 1 reduces dgamma/dbeta partials, finalize makes the per-channel
+ * coefficients, pass 2 writes dx (and, if dz_out != NULL, the masked gradient dz = dy*[y>0] that
+ * also flows to the residual branch). */
+int asm_bn_bwd_reduce(const void* dy, const void* x, const void* yout, int relu, int M, int C,
+                      const float* mean, const float* invstd, float* partial, void* stream);
+int asm_bn_bwd_finalize(const float* partial, int blocks, int M, int C, const float* gamma,
+                        const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                        float* coefA, float* coefB, float* coefC, void* stream);
+int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout, int relu, int M, int C,
+                     const float* coefA, const float* coefB, const float* coefC, void* dx,
+                     void* dz_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pooling / resampling (NHWC bf16)
+ * ---------------------------------------------------------------------------------------------- */
+/* tf.layers.max_pooling2d(3, 2, 'SAME') (nets/resnet_model.py:421-424): pad 0 before / 1 after. */
+int asm_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C, void* stream);
+int asm_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int N, int H, int W, int C, void* stream);
+/* zero-pad + tf.layers.average_pooling2d VALID (nets/resnet_model.py:123-141): k in {2,3}, pad
+ * before = pad, divisor k*k (count_valid = 0) or number of in-range taps (count_valid = 1, the
+ * stride-1 SAME ResNet-D case).  scale multiplies the result (1.0 for pooling; used with k=2,s=2,
+ * divisor forced to 1 for the UpSampling2D backward). */
+int asm_avgpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad,
+                    int Ho, int Wo, int count_valid, void* stream);
+int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
+                    int Ho, int Wo, int count_valid, void* stream);
+/* gradient of UpSampling2D((2,2)): dx[n,i,j,c] = sum of the 2x2 block of dy */
+int asm_upsample2x_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int C, void* stream);
+/* blocks.anti_aliased_downsample (nets/blocks.py:45-107): REFLECT pad (k-1)/2, binomial k x k, stride 2 */
+int asm_blurpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, void* stream);
+int asm_blurpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, void* stream);
+/* tf.reduce_mean over H,W (nets/resnet_model.py:561, nets/blocks.py:170): [N,HW,C] -> [N,C] bf16 */
+int asm_gap_fwd(const void* x, void* y, int N, int HW, int C, void* stream);
+int asm_gap_bwd(const void* dy, void* dx, int N, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Selective-kernel attention (blocks.sk_conv2d, nets/blocks.py:128-152) and SE (nets/blocks.py:156-184)
+ * f: [N, HW, 2F] bf16 (branch 0 = channels [0,F), branch 1 = [F,2F)).
+ * ---------------------------------------------------------------------------------------------- */
+/* s[n][c] = mean_hw (f0 + f1)  -> bf16 [N, F] */
+int asm_sk_gap(const void* f, void* s, int N, int HW, int F, void* stream);
+/* V = a0*f0 + a1*f1 with a = softmax over the 2 branches of att (float32 [N, 2F]) -> bf16 [N,HW,F] */
+int asm_sk_select_fwd(const void* f, const float* att, void* v, int N, int HW, int F, void* stream);
+/* da_b[n][c] = sum_hw f_b*dV ; datt = softmax-pair backward of da  -> datt bf16 [N, 2F] */
+int asm_sk_select_bwd_att(const void* f, const void* dv, const float* att, void* datt, int N, int HW, int F, void* stream);
+/* df_b = a_b*dV + ds[n][c]/HW  -> bf16 [N,HW,2F]  (ds: bf16 [N,F], gradient of the pooled vector) */
+int asm_sk_select_bwd_f(const void* dv, const float* att, const void* ds, void* df, int N, int HW, int F, void* stream);
+/* SE: y = x * sigmoid(e[n][c]);  e float32 [N, C] (pre-sigmoid) */
+int asm_se_scale_fwd(const void* x, const float* e, void* y, int N, int HW, int C, void* stream);
+/* de[n][c] = sigmoid'(e) * sum_hw x*dy (bf16 out) */
+int asm_se_scale_bwd_e(const void* x, const void* dy, const float* e, void* de, int N, int HW, int C, void* stream);
+/* dx = sigmoid(e)*dy + dsq[n][c]/HW (dsq: bf16 [N,C]) */
+int asm_se_scale_bwd_x(const void* dy, const float* e, const void* dsq, void* dx, int N, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise helpers
+ * ---------------------------------------------------------------------------------------------- */
+int asm_relu_fwd(const void* x, void* y, size_t n, void* stream);
+int asm_relu_bwd(const void* dy, const void* y, void* dx, size_t n, void* stream);
+int asm_add_bf16(const void* a, const void* b, void* out, size_t n, void* stream);   /* out = a + b */
+int asm_bias_add_f32(float* y, const float* bias, int M, int C, int ldy, void* stream);
+int asm_bias_grad_bf16(const void* dz, int M, int C, int ld, float* dbias, void* stream);
+int asm_cast_f32_to_bf16(const float* x, void* y, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss -- tf.losses.softmax_cross_entropy(label_smoothing) (losses/cls_losses.py:31-33) + the KD term
+ * T^2 * CE(logits/T, teacher) (nets/run_loop_classification.py:156-162), forward and backward fused.
+ * logits float32 [B][ld]; targets float32 dense [B][C] (one-hot, mixed, ...), teacher float32 dense
+ * probabilities [B][C] or NULL.  loss_rows[b] = CE_b + KD_b (caller averages over B);
+ * dlogits bf16 [B][ld_out] = loss_scale/B * (...), zero in the padding columns.
+ * ---------------------------------------------------------------------------------------------- */
+int asm_softmax_ce(const float* logits, int ld, const float* targets, const float* teacher, int B,
+                   int C, float label_smoothing, float kd_temp, float loss_scale, float* loss_rows,
+                   void* dlogits, int ld_out, void* stream);
+int asm_onehot(const int32_t* labels, float* out, int B, int C, void* stream);
+/* teacher = softmax(teacher_logits / T) (nets/run_loop_classification.py:93-94) */
+int asm_softmax_rows(const float* x, float* y, int B, int C, float inv_temp, void* stream);
+int asm_mean_f32(const float* x, int n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Input: mean subtraction + cast (preprocessing/imagenet_preprocessing.py:122-155, utils/data_util.py:382)
+ * fused with data_util.mixup (utils/data_util.py:97-158) and the stem halo padding.
+ * images: [Bin, H, W, 3] uint8 or float32 in 0..255.  mixup_type 0: out[b] = img[b]-mean.
+ * type 1 (2B->B): out[b] = lam[b]*img[b] + (1-lam[b])*img[B+b] - mean.
+ * type 2 (B->B): first half as type 1 with lam1, second half lam2[b]*img[b] + (1-lam2[b])*img[Bin-1-b].
+ * out: [Bout][H+6][W+6][4] bf16 (zero halo / zero 4th channel).
+ * ---------------------------------------------------------------------------------------------- */
+int asm_mixup_meansub(const void* images, int is_u8, int Bin, int H, int W, int mixup_type,
+                      const float* lam1, const float* lam2, void* out, void* stream);
+/* labels: dense float32 [Bin][C] -> mixed [Bout][C] (same lambda rule) */
+int asm_mixup_labels(const float* y, int Bin, int C, int mixup_type, const float* lam1,
+                     const float* lam2, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser -- tf.train.MomentumOptimizer + the L2 term folded in (nets/optimizer_setting.py:23-38,
+ * nets/run_loop_classification.py:166-178):  g' = g*grad_scale + wd*w ; a = mom*a + g' ; w -= lr*a ;
+ * w_bf16 = bf16(w).  One launch over a flat arena.
+ * ---------------------------------------------------------------------------------------------- */
+int asm_sgd_momentum(float* w, float* accum, const float* grad, void* w_bf16, size_t n, float lr,
+                     float momentum, float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASM_HIP_H_ */

@@ -1,0 +1,498 @@
+"""A CPU *test double* of the C ABI in include/asm_hip.h (TEST INFRASTRUCTURE ONLY).
+
+It lets the GPU-less test tier drive the real host code of ``assembled_cnn_amd`` (ops.py, nn.py,
+model.py, train.py, dp.py: parameter arenas, the backward tape, the topology walker, the optimiser
+wiring) end to end and compare it with the oracle.  It is installed with
+``assembled_cnn_amd.ops.set_library(CpuDouble(), is_double=True)`` by tests only; the product never
+imports it and has no CPU path.
+
+Every function follows the semantics written in the header, computing in float32 with torch CPU ops
+and rounding to bf16 exactly where the kernels store bf16.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_CT = {'bf16': (C.c_int16, torch.bfloat16), 'f32': (C.c_float, torch.float32), 'u8': (C.c_uint8, torch.uint8),
+       'i32': (C.c_int32, torch.int32)}
+
+
+def T(ptr, shape, kind):
+  """Tensor aliasing the caller's memory."""
+  if not ptr:
+    return None
+  n = int(np.prod(shape))
+  ct, tt = _CT[kind]
+  arr = np.ctypeslib.as_array((ct * n).from_address(ptr))
+  t = torch.from_numpy(arr)
+  if kind == 'bf16':
+    t = t.view(torch.bfloat16)
+  return t.view(tuple(shape))
+
+
+def _desc(d):
+  return d._obj if hasattr(d, '_obj') else d
+
+
+def _pitches(d):
+  img = d.x_img_pitch if d.x_img_pitch else d.H * d.W * d.C
+  row = d.x_row_pitch if d.x_row_pitch else d.W * d.C
+  pix = d.x_pix_pitch if d.x_pix_pitch else d.C
+  return int(img), int(row), int(pix)
+
+
+def _gather(xptr, d, r, s):
+  """[N,Ho,Wo,C] float32 of x(n, ho*stride+r-pad, wo*stride+s-pad, :) with zeros out of range."""
+  img, row, pix = _pitches(d)
+  ih = torch.arange(d.Ho) * d.stride + r - d.pad
+  iw = torch.arange(d.Wo) * d.stride + s - d.pad
+  vh = (ih >= 0) & (ih < d.H)
+  vw = (iw >= 0) & (iw < d.W)
+  valid = vh[:, None] & vw[None, :]
+  base = (torch.arange(d.N)[:, None, None] * img + ih.clamp(0, d.H - 1)[None, :, None] * row +
+          iw.clamp(0, d.W - 1)[None, None, :] * pix)
+  idx = base[..., None] + torch.arange(d.C)
+  idx = torch.where(valid[None, :, :, None].expand_as(idx), idx, torch.zeros_like(idx))
+  n = int(idx.max()) + 1
+  flat = T(xptr, (n,), 'bf16').float()
+  g = flat[idx.reshape(-1)].view(d.N, d.Ho, d.Wo, d.C)
+  return g * valid[None, :, :, None]
+
+
+class CpuDouble(object):
+  def __init__(self):
+    self._err = b''
+
+  # ---- plumbing ------------------------------------------------------------------------------------
+  def asm_last_error(self):
+    return self._err
+
+  def asm_abi_version(self):
+    return 1
+
+  # ---- conv ----------------------------------------------------------------------------------------
+  def asm_conv2d_stats_blocks(self, d):
+    d = _desc(d)
+    return (d.N * d.Ho * d.Wo + 127) // 128
+
+  def asm_conv2d_fprop(self, d, x, w, y, stats, stream):
+    d = _desc(d)
+    ldy = d.ldy if d.ldy else d.K
+    wt = T(w, (d.K, d.R, d.S, d.C), 'bf16').float()
+    acc = torch.zeros(d.N, d.Ho, d.Wo, d.K)
+    for r in range(d.R):
+      for s in range(d.S):
+        acc += _gather(x, d, r, s) @ wt[:, r, s, :].t()
+    out = T(y, (d.N * d.Ho * d.Wo, ldy), 'f32' if d.out_f32 else 'bf16')
+    out[:, :d.K] = acc.view(-1, d.K).to(out.dtype)
+    if stats:
+      M = d.N * d.Ho * d.Wo
+      nb = (M + 127) // 128
+      st = T(stats, (nb, 2, d.K), 'f32')
+      v = out[:, :d.K].float()
+      for b in range(nb):
+        blk = v[b * 128:(b + 1) * 128]
+        st[b, 0] = blk.sum(0)
+        st[b, 1] = (blk * blk).sum(0)
+    return 0
+
+  def asm_conv2d_dgrad(self, d, dy, wt, dx, stream):
+    d = _desc(d)
+    g = T(dy, (d.N, d.Ho, d.Wo, d.K), 'bf16').float()
+    w_crsk = T(wt, (d.C, d.R, d.S, d.K), 'bf16').float()
+    w_oihw = w_crsk.permute(3, 0, 1, 2)  # [K, C, R, S]
+    x = torch.zeros(d.N, d.C, d.H, d.W, requires_grad=True)
+    pad_after_h = max((d.Ho - 1) * d.stride + d.R - d.pad - d.H, 0)
+    pad_after_w = max((d.Wo - 1) * d.stride + d.S - d.pad - d.W, 0)
+    yy = F.conv2d(F.pad(x, (d.pad, pad_after_w, d.pad, pad_after_h)), w_oihw, stride=d.stride)
+    yy = yy[:, :, :d.Ho, :d.Wo]
+    (gx,) = torch.autograd.grad(yy, x, g.permute(0, 3, 1, 2))
+    T(dx, (d.N, d.H, d.W, d.C), 'bf16').copy_(gx.permute(0, 2, 3, 1))
+    return 0
+
+  def asm_conv2d_wgrad_workspace_bytes(self, d):
+    return 64
+
+  def asm_conv2d_wgrad(self, d, x, dy, dw, ws, ws_bytes, stream):
+    d = _desc(d)
+    ldy = d.ldy if d.ldy else d.K
+    g = T(dy, (d.N * d.Ho * d.Wo, ldy), 'bf16').float()[:, :d.K]
+    out = T(dw, (d.K, d.R, d.S, d.C), 'f32')
+    for r in range(d.R):
+      for s in range(d.S):
+        out[:, r, s, :] = g.t() @ _gather(x, d, r, s).view(-1, d.C)
+    return 0
+
+  def asm_filter_transpose(self, w, wt, K, R, S, Cn, ldk, stream):
+    ldk = ldk if ldk else K
+    src = T(w, (K, R, S, Cn), 'bf16')
+    dst = T(wt, (Cn, R, S, ldk), 'bf16')
+    dst[..., :K] = src.permute(3, 1, 2, 0)
+    return 0
+
+  def asm_stem_pack_filter(self, w, wp, K, ks, stream):
+    Lr = (4 * ks + 7) // 8 * 8
+    src = T(w, (K, ks, ks, 3), 'f32')
+    dst = T(wp, (K, ks, Lr), 'bf16')
+    dst.zero_()
+    tmp = torch.zeros(K, ks, Lr // 4, 4)
+    tmp[:, :, :ks, :3] = src
+    dst.copy_(tmp.view(K, ks, Lr))
+    return 0
+
+  def asm_stem_unpack_grad(self, dwp, dw, K, ks, stream):
+    Lr = (4 * ks + 7) // 8 * 8
+    src = T(dwp, (K, ks, Lr // 4, 4), 'f32')
+    T(dw, (K, ks, ks, 3), 'f32').copy_(src[:, :, :ks, :3])
+    return 0
+
+  def asm_stem_pad_input(self, x, is_f32, xp, N, H, W, stream):
+    src = T(x, (N, H, W, 3), 'f32' if is_f32 else 'bf16').float()
+    dst = T(xp, (N, H + 6, W + 6, 4), 'bf16')
+    dst.zero_()
+    dst[:, 3:3 + H, 3:3 + W, :3] = src.to(torch.bfloat16)
+    return 0
+
+  # ---- BN ------------------------------------------------------------------------------------------
+  def asm_bn_stats_blocks(self, M, Cn):
+    return (M + 255) // 256
+
+  def asm_bn_stats(self, x, M, Cn, part, stream):
+    v = T(x, (M, Cn), 'bf16').float()
+    nb = (M + 255) // 256
+    st = T(part, (nb, 2, Cn), 'f32')
+    for b in range(nb):
+      blk = v[b * 256:(b + 1) * 256]
+      st[b, 0] = blk.sum(0)
+      st[b, 1] = (blk * blk).sum(0)
+    return 0
+
+  def asm_bn_finalize(self, part, blocks, M, Cn, gamma, beta, eps, momentum, mm, mv, mean, invstd, scale, shift,
+                      stream):
+    st = T(part, (blocks, 2, Cn), 'f32').double().sum(0)
+    mu = st[0] / M
+    var = (st[1] / M - mu * mu).clamp(min=0)
+    inv = 1.0 / torch.sqrt(var + eps)
+    g, b = T(gamma, (Cn,), 'f32'), T(beta, (Cn,), 'f32')
+    T(mean, (Cn,), 'f32').copy_(mu.float())
+    T(invstd, (Cn,), 'f32').copy_(inv.float())
+    sc = g * inv.float()
+    T(scale, (Cn,), 'f32').copy_(sc)
+    T(shift, (Cn,), 'f32').copy_(b - mu.float() * sc)
+    if mm:
+      tm, tv = T(mm, (Cn,), 'f32'), T(mv, (Cn,), 'f32')
+      unb = var * (M / max(M - 1, 1))
+      tm.copy_(tm * momentum + mu.float() * (1 - momentum))
+      tv.copy_(tv * momentum + unb.float() * (1 - momentum))
+    return 0
+
+  def asm_bn_infer_coeffs(self, Cn, gamma, beta, mm, mv, eps, scale, shift, stream):
+    g, b = T(gamma, (Cn,), 'f32'), T(beta, (Cn,), 'f32')
+    inv = 1.0 / torch.sqrt(T(mv, (Cn,), 'f32') + eps)
+    sc = g * inv
+    T(scale, (Cn,), 'f32').copy_(sc)
+    T(shift, (Cn,), 'f32').copy_(b - T(mm, (Cn,), 'f32') * sc)
+    return 0
+
+  def asm_bn_apply(self, x, y, M, Cn, scale, shift, residual, res_mode, relu, H, W, stream):
+    v = T(x, (M, Cn), 'bf16').float() * T(scale, (Cn,), 'f32') + T(shift, (Cn,), 'f32')
+    if res_mode == 1:
+      v = v + T(residual, (M, Cn), 'bf16').float()
+    elif res_mode == 2:
+      N = M // (H * W)
+      r = T(residual, (N, H // 2, W // 2, Cn), 'bf16').float()
+      r = r.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+      v = v + r.reshape(M, Cn)
+    if relu:
+      v = F.relu(v)
+    T(y, (M, Cn), 'bf16').copy_(v)
+    return 0
+
+  def _dz(self, dy, yout, relu, M, Cn):
+    g = T(dy, (M, Cn), 'bf16').float()
+    if relu:
+      g = g * (T(yout, (M, Cn), 'bf16').float() > 0)
+    return g
+
+  def asm_bn_bwd_reduce(self, dy, x, yout, relu, M, Cn, mean, invstd, part, stream):
+    g = self._dz(dy, yout, relu, M, Cn)
+    xh = (T(x, (M, Cn), 'bf16').float() - T(mean, (Cn,), 'f32')) * T(invstd, (Cn,), 'f32')
+    nb = (M + 255) // 256
+    st = T(part, (nb, 2, Cn), 'f32')
+    for b in range(nb):
+      sl = slice(b * 256, (b + 1) * 256)
+      st[b, 0] = g[sl].sum(0)
+      st[b, 1] = (g[sl] * xh[sl]).sum(0)
+    return 0
+
+  def asm_bn_bwd_finalize(self, part, blocks, M, Cn, gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, stream):
+    st = T(part, (blocks, 2, Cn), 'f32').double().sum(0)
+    db, dg = st[0], st[1]
+    g, mu, inv = (T(p, (Cn,), 'f32').double() for p in (gamma, mean, invstd))
+    T(dbeta, (Cn,), 'f32').copy_(db.float())
+    T(dgamma, (Cn,), 'f32').copy_(dg.float())
+    A = g * inv
+    B = -g * inv * inv * dg / M
+    Cc = -g * inv * db / M - B * mu
+    T(cA, (Cn,), 'f32').copy_(A.float())
+    T(cB, (Cn,), 'f32').copy_(B.float())
+    T(cC, (Cn,), 'f32').copy_(Cc.float())
+    return 0
+
+  def asm_bn_bwd_apply(self, dy, x, yout, relu, M, Cn, cA, cB, cC, dx, dz_out, stream):
+    g = self._dz(dy, yout, relu, M, Cn)
+    if dz_out:
+      T(dz_out, (M, Cn), 'bf16').copy_(g)
+    v = T(cA, (Cn,), 'f32') * g + T(cB, (Cn,), 'f32') * T(x, (M, Cn), 'bf16').float() + T(cC, (Cn,), 'f32')
+    T(dx, (M, Cn), 'bf16').copy_(v)
+    return 0
+
+  # ---- pools ---------------------------------------------------------------------------------------
+  @staticmethod
+  def _nchw(ptr, N, H, W, Cn, grad=False):
+    t = T(ptr, (N, H, W, Cn), 'bf16').float().permute(0, 3, 1, 2).contiguous()
+    return t.requires_grad_(True) if grad else t
+
+  def _maxpool(self, x):
+    H, W = x.shape[2], x.shape[3]
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    ph = max((Ho - 1) * 2 + 3 - H, 0)
+    pw = max((Wo - 1) * 2 + 3 - W, 0)
+    xp = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=float('-inf'))
+    return F.max_pool2d(xp, 3, 2)
+
+  def asm_maxpool3x3s2_fwd(self, x, y, am, N, H, W, Cn, stream):
+    xt = self._nchw(x, N, H, W, Cn)
+    out = self._maxpool(xt)
+    T(y, (N, out.shape[2], out.shape[3], Cn), 'bf16').copy_(out.permute(0, 2, 3, 1))
+    self._mp_x = xt  # the double keeps the input instead of decoding the argmax codes
+    return 0
+
+  def asm_maxpool3x3s2_bwd(self, dy, am, dx, N, H, W, Cn, stream):
+    xt = self._mp_x.clone().requires_grad_(True)
+    out = self._maxpool(xt)
+    g = T(dy, (N, out.shape[2], out.shape[3], Cn), 'bf16').float().permute(0, 3, 1, 2)
+    (gx,) = torch.autograd.grad(out, xt, g)
+    T(dx, (N, H, W, Cn), 'bf16').copy_(gx.permute(0, 2, 3, 1))
+    return 0
+
+  @staticmethod
+  def _avgpool(x, k, stride, pad, Ho, Wo, count_valid):
+    H, W = x.shape[2], x.shape[3]
+    pa_h = max((Ho - 1) * stride + k - pad - H, 0)
+    pa_w = max((Wo - 1) * stride + k - pad - W, 0)
+    xp = F.pad(x, (pad, pa_w, pad, pa_h))
+    num = F.avg_pool2d(xp, k, stride)[:, :, :Ho, :Wo] * (k * k)
+    if count_valid:
+      ones = F.pad(torch.ones(1, 1, H, W), (pad, pa_w, pad, pa_h))
+      den = F.avg_pool2d(ones, k, stride)[:, :, :Ho, :Wo] * (k * k)
+      return num / den
+    return num / (k * k)
+
+  def asm_avgpool_fwd(self, x, y, N, H, W, Cn, k, stride, pad, Ho, Wo, cv, stream):
+    out = self._avgpool(self._nchw(x, N, H, W, Cn), k, stride, pad, Ho, Wo, cv)
+    T(y, (N, Ho, Wo, Cn), 'bf16').copy_(out.permute(0, 2, 3, 1))
+    return 0
+
+  def asm_avgpool_bwd(self, dy, dx, N, H, W, Cn, k, stride, pad, Ho, Wo, cv, stream):
+    xt = torch.zeros(N, Cn, H, W, requires_grad=True)
+    out = self._avgpool(xt, k, stride, pad, Ho, Wo, cv)
+    g = T(dy, (N, Ho, Wo, Cn), 'bf16').float().permute(0, 3, 1, 2)
+    (gx,) = torch.autograd.grad(out, xt, g)
+    T(dx, (N, H, W, Cn), 'bf16').copy_(gx.permute(0, 2, 3, 1))
+    return 0
+
+  def asm_upsample2x_bwd(self, dy, dx, N, Hs, Ws, Cn, stream):
+    g = T(dy, (N, Hs, 2, Ws, 2, Cn), 'bf16').float().sum(dim=(2, 4))
+    T(dx, (N, Hs, Ws, Cn), 'bf16').copy_(g)
+    return 0
+
+  @staticmethod
+  def _blur(x, k, stride):
+    tri = {2: [1., 1.], 3: [1., 2., 1.], 4: [1., 3., 3., 1.], 5: [1., 4., 6., 4., 1.],
+           6: [1., 5., 10., 10., 5., 1.], 7: [1., 6., 15., 20., 15., 6., 1.]}[k]
+    a = torch.tensor(tri)
+    f = a[:, None] * a[None, :]
+    f = f / f.sum()
+    p = (k - 1) // 2
+    c = x.shape[1]
+    xp = F.pad(x, (p, p, p, p), mode='reflect')
+    return F.conv2d(xp, f.view(1, 1, k, k).repeat(c, 1, 1, 1), stride=stride, groups=c)
+
+  def asm_blurpool_fwd(self, x, y, N, H, W, Cn, k, stride, stream):
+    out = self._blur(self._nchw(x, N, H, W, Cn), k, stride)
+    T(y, (N, out.shape[2], out.shape[3], Cn), 'bf16').copy_(out.permute(0, 2, 3, 1))
+    return 0
+
+  def asm_blurpool_bwd(self, dy, dx, N, H, W, Cn, k, stride, stream):
+    xt = torch.zeros(N, Cn, H, W, requires_grad=True)
+    out = self._blur(xt, k, stride)
+    g = T(dy, (N, out.shape[2], out.shape[3], Cn), 'bf16').float().permute(0, 3, 1, 2)
+    (gx,) = torch.autograd.grad(out, xt, g)
+    T(dx, (N, H, W, Cn), 'bf16').copy_(gx.permute(0, 2, 3, 1))
+    return 0
+
+  def asm_gap_fwd(self, x, y, N, HW, Cn, stream):
+    T(y, (N, Cn), 'bf16').copy_(T(x, (N, HW, Cn), 'bf16').float().mean(1))
+    return 0
+
+  def asm_gap_bwd(self, dy, dx, N, HW, Cn, stream):
+    g = T(dy, (N, 1, Cn), 'bf16').float() / HW
+    T(dx, (N, HW, Cn), 'bf16').copy_(g.expand(N, HW, Cn))
+    return 0
+
+  # ---- SK / SE -------------------------------------------------------------------------------------
+  def asm_sk_gap(self, f, s, N, HW, F_, stream):
+    ff = T(f, (N, HW, 2, F_), 'bf16').float()
+    T(s, (N, F_), 'bf16').copy_(ff.sum(2).mean(1))
+    return 0
+
+  @staticmethod
+  def _a0(att, N, F_):
+    a = T(att, (N, 2, F_), 'f32')
+    return torch.sigmoid(a[:, 0] - a[:, 1])
+
+  def asm_sk_select_fwd(self, f, att, v, N, HW, F_, stream):
+    ff = T(f, (N, HW, 2, F_), 'bf16').float()
+    a0 = self._a0(att, N, F_)[:, None, :]
+    T(v, (N, HW, F_), 'bf16').copy_(a0 * ff[:, :, 0] + (1 - a0) * ff[:, :, 1])
+    return 0
+
+  def asm_sk_select_bwd_att(self, f, dv, att, datt, N, HW, F_, stream):
+    ff = T(f, (N, HW, 2, F_), 'bf16').float()
+    g = T(dv, (N, HW, F_), 'bf16').float()
+    a0 = self._a0(att, N, F_)
+    t = ((ff[:, :, 0] - ff[:, :, 1]) * g).sum(1)
+    d0 = a0 * (1 - a0) * t
+    out = T(datt, (N, 2, F_), 'bf16')
+    out[:, 0] = d0.to(torch.bfloat16)
+    out[:, 1] = (-d0).to(torch.bfloat16)
+    return 0
+
+  def asm_sk_select_bwd_f(self, dv, att, ds, df, N, HW, F_, stream):
+    g = T(dv, (N, HW, F_), 'bf16').float()
+    a0 = self._a0(att, N, F_)[:, None, :]
+    u = T(ds, (N, 1, F_), 'bf16').float() / HW
+    out = T(df, (N, HW, 2, F_), 'bf16')
+    out[:, :, 0] = (a0 * g + u).to(torch.bfloat16)
+    out[:, :, 1] = ((1 - a0) * g + u).to(torch.bfloat16)
+    return 0
+
+  def asm_se_scale_fwd(self, x, e, y, N, HW, Cn, stream):
+    s = torch.sigmoid(T(e, (N, 1, Cn), 'f32'))
+    T(y, (N, HW, Cn), 'bf16').copy_(T(x, (N, HW, Cn), 'bf16').float() * s)
+    return 0
+
+  def asm_se_scale_bwd_e(self, x, dy, e, de, N, HW, Cn, stream):
+    s = torch.sigmoid(T(e, (N, Cn), 'f32'))
+    t = (T(x, (N, HW, Cn), 'bf16').float() * T(dy, (N, HW, Cn), 'bf16').float()).sum(1)
+    T(de, (N, Cn), 'bf16').copy_(t * s * (1 - s))
+    return 0
+
+  def asm_se_scale_bwd_x(self, dy, e, dsq, dx, N, HW, Cn, stream):
+    s = torch.sigmoid(T(e, (N, 1, Cn), 'f32'))
+    v = T(dy, (N, HW, Cn), 'bf16').float() * s + T(dsq, (N, 1, Cn), 'bf16').float() / HW
+    T(dx, (N, HW, Cn), 'bf16').copy_(v)
+    return 0
+
+  # ---- element-wise --------------------------------------------------------------------------------
+  def asm_relu_fwd(self, x, y, n, stream):
+    T(y, (n,), 'bf16').copy_(F.relu(T(x, (n,), 'bf16').float()))
+    return 0
+
+  def asm_relu_bwd(self, dy, y, dx, n, stream):
+    T(dx, (n,), 'bf16').copy_(T(dy, (n,), 'bf16').float() * (T(y, (n,), 'bf16').float() > 0))
+    return 0
+
+  def asm_add_bf16(self, a, b, out, n, stream):
+    v = T(a, (n,), 'bf16').float() + T(b, (n,), 'bf16').float()
+    T(out, (n,), 'bf16').copy_(v)
+    return 0
+
+  def asm_bias_add_f32(self, y, bias, M, Cn, ldy, stream):
+    T(y, (M, ldy), 'f32')[:, :Cn] += T(bias, (Cn,), 'f32')
+    return 0
+
+  def asm_bias_grad_bf16(self, dz, M, Cn, ld, dbias, stream):
+    T(dbias, (Cn,), 'f32').copy_(T(dz, (M, ld), 'bf16').float()[:, :Cn].sum(0))
+    return 0
+
+  def asm_cast_f32_to_bf16(self, x, y, n, stream):
+    if n:
+      T(y, (n,), 'bf16').copy_(T(x, (n,), 'f32'))
+    return 0
+
+  # ---- loss ----------------------------------------------------------------------------------------
+  def asm_softmax_ce(self, logits, ld, targets, teacher, B, Cn, eps, T_, loss_scale, loss_rows, dlogits, ld_out,
+                     stream):
+    z = T(logits, (B, ld), 'f32')[:, :Cn].clone().requires_grad_(True)
+    y = T(targets, (B, Cn), 'f32') * (1 - eps) + eps / Cn
+    rows = -(y * torch.log_softmax(z, 1)).sum(1)
+    if teacher:
+      t = T(teacher, (B, Cn), 'f32')
+      rows = rows + T_ * T_ * (-(t * torch.log_softmax(z / T_, 1)).sum(1))
+    T(loss_rows, (B,), 'f32').copy_(rows.detach())
+    if dlogits:
+      (g,) = torch.autograd.grad(rows.sum() * (loss_scale / B), z)
+      out = T(dlogits, (B, ld_out), 'bf16')
+      out.zero_()
+      out[:, :Cn] = g.to(torch.bfloat16)
+    return 0
+
+  def asm_onehot(self, labels, out, B, Cn, stream):
+    T(out, (B, Cn), 'f32').copy_(F.one_hot(T(labels, (B,), 'i32').long(), Cn).float())
+    return 0
+
+  def asm_softmax_rows(self, x, y, B, Cn, inv_temp, stream):
+    T(y, (B, Cn), 'f32').copy_(torch.softmax(T(x, (B, Cn), 'f32') * inv_temp, 1))
+    return 0
+
+  def asm_mean_f32(self, x, n, out, stream):
+    T(out, (1,), 'f32').copy_(T(x, (n,), 'f32').mean().view(1))
+    return 0
+
+  # ---- input ---------------------------------------------------------------------------------------
+  @staticmethod
+  def _mix(v, Bin, mixup_type, lam1, lam2):
+    if mixup_type == 0:
+      return v
+    shape = [-1] + [1] * (v.dim() - 1)
+    half = Bin // 2
+    l1 = T(lam1, (half,), 'f32').view(shape)
+    first = l1 * v[:half] + (1 - l1) * v[half:]
+    if mixup_type == 1:
+      return first
+    l2 = T(lam2, (half,), 'f32').view(shape)
+    second = l2 * v[:half] + (1 - l2) * torch.flip(v[half:], [0])
+    return torch.cat([first, second], 0)
+
+  def asm_mixup_meansub(self, images, is_u8, Bin, H, W, mixup_type, lam1, lam2, out, stream):
+    img = T(images, (Bin, H, W, 3), 'u8' if is_u8 else 'f32').float()
+    img = img - torch.tensor([123.68, 116.78, 103.94])
+    mixed = self._mix(img, Bin, mixup_type, lam1, lam2)
+    Bout = mixed.shape[0]
+    dst = T(out, (Bout, H + 6, W + 6, 4), 'bf16')
+    dst.zero_()
+    dst[:, 3:3 + H, 3:3 + W, :3] = mixed.to(torch.bfloat16)
+    return 0
+
+  def asm_mixup_labels(self, y, Bin, Cn, mixup_type, lam1, lam2, out, stream):
+    mixed = self._mix(T(y, (Bin, Cn), 'f32'), Bin, mixup_type, lam1, lam2)
+    T(out, tuple(mixed.shape), 'f32').copy_(mixed)
+    return 0
+
+  # ---- optimiser -----------------------------------------------------------------------------------
+  def asm_sgd_momentum(self, w, accum, grad, wb, n, lr, momentum, wd, gs, stream):
+    if n == 0:
+      return 0
+    tw, ta, tg = T(w, (n,), 'f32'), T(accum, (n,), 'f32'), T(grad, (n,), 'f32')
+    gg = tg * gs + wd * tw
+    ta.copy_(momentum * ta + gg)
+    tw.copy_(tw - lr * ta)
+    if wb:
+      T(wb, (n,), 'bf16').copy_(tw)
+    return 0
