@@ -58,6 +58,13 @@ class ParamArena(object):
     self.total_elems = 0
     self.w32 = self.g32 = self.m32 = self.w16 = self.state = None
     self.derived: List[Callable[[], None]] = []  # refresh hooks (CRSK copies, stem packing)
+    self.on_grad: Optional[Callable[[int], None]] = None  # dp.GradSync.notify (gradient-ready watermark)
+
+  def notify_grad(self, name: str):
+    """The gradient slot of ``name`` has been enqueued on the compute stream (backward order is the
+    reverse of creation order, so every slot above it in its segment is final too)."""
+    if self.on_grad is not None:
+      self.on_grad(self.specs[name].offset)
 
   def register(self, name, shape, decay, init) -> ParamSpec:
     if self.finalized:
@@ -328,8 +335,10 @@ class ConvKernel(object):
       dwp = torch.empty((self.cout, self.k, self.stem_len), dtype=torch.float32, device=x.device)
       ops.conv_wgrad(d, self._stem_view(x), dy, dwp)
       ops.stem_unpack_grad(dwp, a.g(self.name), self.cout, self.k)
+      a.notify_grad(self.name)
       return None
     ops.conv_wgrad(d, x, dy, a.g(self.name))
+    a.notify_grad(self.name)
     if not need_dx:
       return None
     if self.kpad != self.cout:  # dy carries kpad channels (zero padded)
@@ -399,6 +408,7 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
         raise RuntimeError('conv_bn backward: no gradient reached this layer')
       want_dz = residual is not None and relu
       dy, dz = ops.bn_bwd(dout, y, out_t, relu, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), want_dz)
+      a.notify_grad(bn.gamma)
       if residual is not None:
         dres = dz if relu else dout
         if res_mode == 2:

@@ -83,6 +83,41 @@ def make_conv_desc(N, H, W, Cin, K, R, S, stride, pad=None, Ho=None, Wo=None, ld
   return d
 
 
+class ConvTimer(object):
+  """HIP-event timing of convolution launches on the launch stream (bench.py's roofline leg).
+  ``only`` restricts timing to one (kind, shape-key) class; otherwise every conv launch is timed."""
+
+  def __init__(self, only=None):
+    self.only = only
+    self.events = {}
+
+  @staticmethod
+  def key(kind, d):
+    return (kind, d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride)
+
+  def start(self, kind, d):
+    k = self.key(kind, d)
+    if self.only is not None and k != self.only:
+      return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    self.events.setdefault(k, []).append((e0, e1))
+    return e1
+
+  def summary(self):
+    """key -> (launches, total ms); call after a device synchronize."""
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.events.items()}
+
+
+_TIMER: Optional[ConvTimer] = None
+
+
+def set_conv_timer(t: Optional[ConvTimer]):
+  global _TIMER
+  _TIMER = t
+
+
 def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool = False
                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
   """y [N,Ho,Wo,ldy] (bf16 or f32) and, if want_stats, the BN partials [blocks,2,K] (f32)."""
@@ -91,13 +126,19 @@ def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool =
   stats = None
   if want_stats:
     stats = empty((L().asm_conv2d_stats_blocks(C.byref(d)), 2, d.K), F32, x)
+  ev = _TIMER.start('fprop', d) if _TIMER is not None else None
   check(L().asm_conv2d_fprop(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(stats), _stream()), 'conv2d_fprop')
+  if ev is not None:
+    ev.record()
   return y, stats
 
 
 def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor) -> torch.Tensor:
   dx = empty((d.N, d.H, d.W, d.C), BF16, dy)
+  ev = _TIMER.start('dgrad', d) if _TIMER is not None else None
   check(L().asm_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), _stream()), 'conv2d_dgrad')
+  if ev is not None:
+    ev.record()
   return dx
 
 
@@ -120,7 +161,10 @@ def conv_wgrad(d: ConvDesc, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor)
   """dw (f32, [K,R,S,C] contiguous view, overwritten)."""
   need = L().asm_conv2d_wgrad_workspace_bytes(C.byref(d))
   ws = _workspace(need, x)
+  ev = _TIMER.start('wgrad', d) if _TIMER is not None else None
   check(L().asm_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), need, _stream()), 'conv2d_wgrad')
+  if ev is not None:
+    ev.record()
 
 
 def filter_transpose(w: torch.Tensor, wt: torch.Tensor, K, R, S, Cin, ldk=0):

@@ -1,0 +1,217 @@
+"""GPU parity: MFMA convolution kernels (fprop / dgrad / wgrad, fused BN statistics, stem path) called
+through the C ABI vs the CPU oracle on the same seeded, bf16-rounded inputs.
+
+Tolerances (bf16 in, fp32 accumulate, bf16 out): relative L2 <= 4e-3 (~2^-8) per tensor and
+max |err| <= 2^-7 * max|ref| (one bf16 ulp of the largest value + accumulation-order slack);
+fp32 outputs (wgrad, f32 fprop): relative L2 <= 2e-3 (K-order only; inputs are identical bf16)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _rand(shape, seed, scale=1.0):
+  g = torch.Generator().manual_seed(seed)
+  return (torch.randn(shape, generator=g) * scale).to(BF)
+
+
+def _ref_conv(x_nhwc, w_krsc, stride):
+  """oracle conv2d_fixed_padding on bf16-rounded inputs, fp32 math."""
+  from oracle import assembled_oracle as O
+  k = w_krsc.shape[1]
+  w_hwio = w_krsc.float().permute(1, 2, 3, 0)
+  y = O._conv_raw(x_nhwc.float().permute(0, 3, 1, 2), w_hwio, k, stride)
+  return y.permute(0, 2, 3, 1).contiguous()
+
+
+def _check(out, ref, rel=4e-3, name=''):
+  out = out.float().cpu()
+  r = util.rel_l2(out, ref)
+  m = util.max_abs(out, ref)
+  lim = float(ref.abs().max()) * 2 ** -7 + 1e-6
+  assert r <= rel, '%s rel_l2 %.3e > %.1e' % (name, r, rel)
+  assert m <= lim, '%s max_abs %.3e > %.3e' % (name, m, lim)
+
+
+SHAPES = [
+    # N, H,  W,  C,   K,   k, stride
+    (2, 16, 16, 64, 64, 3, 1),      # BN=64, BK=64
+    (2, 16, 16, 64, 128, 3, 1),     # BN=128 (SK conv shape, small)
+    (3, 7, 7, 256, 512, 3, 1),      # M=147 (ragged M tile), 4 N-tiles
+    (2, 14, 14, 128, 128, 3, 2),    # strided 3x3
+    (2, 16, 16, 64, 256, 1, 1),     # 1x1
+    (2, 16, 16, 256, 64, 1, 1),     # 1x1 reduce
+    (2, 14, 14, 256, 512, 1, 2),    # strided 1x1 projection
+    (2, 12, 12, 32, 64, 3, 1),      # BK=32
+    (2, 12, 12, 32, 32, 3, 2),      # BN=64 with K=32 (masked N), BK=32, strided
+    (2, 9, 9, 72, 40, 3, 1),        # channel tail (72 % 32 = 8), K not multiple of 64
+    (256, 1, 1, 64, 32, 1, 1),      # SK fc1 shape
+    (4, 15, 15, 64, 64, 3, 2),      # odd spatial, strided
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_fprop_dgrad_wgrad_vs_oracle(hip_lib, shape):
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K, k, stride = shape
+  x = _rand((N, H, W, Cn), 1)
+  w = _rand((K, k, k, Cn), 2, scale=(1.0 / (k * k * Cn)) ** 0.5)
+  d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
+  xd, wd = x.cuda(), w.cuda()
+
+  # forward (+ fused statistics)
+  y, stats = ops.conv_fprop(d, xd, wd, want_stats=True)
+  ref = _ref_conv(x, w, stride)
+  assert tuple(y.shape) == tuple(ref.shape)
+  _check(y, ref, name='fprop')
+  yb = y.float()
+  s = stats.sum(0).cpu()
+  assert torch.allclose(s[0], yb.sum((0, 1, 2)).cpu(), rtol=1e-4, atol=1e-2), 'fused sum'
+  assert torch.allclose(s[1], (yb * yb).sum((0, 1, 2)).cpu(), rtol=1e-4, atol=1e-2), 'fused sum of squares'
+  # same launch without statistics gives the identical tensor
+  y2, _ = ops.conv_fprop(d, xd, wd, want_stats=False)
+  assert torch.equal(y, y2)
+
+  # backward: reference via autograd on the oracle conv
+  dy = _rand(tuple(ref.shape), 3)
+  xr = x.float().requires_grad_(True)
+  wr = w.float().requires_grad_(True)
+  from oracle import assembled_oracle as O
+  yr = O._conv_raw(xr.permute(0, 3, 1, 2), wr.permute(1, 2, 3, 0), k, stride)
+  gx, gw = torch.autograd.grad(yr, [xr, wr], dy.float().permute(0, 3, 1, 2))
+
+  wt = torch.zeros((Cn, k, k, K), dtype=BF, device='cuda')
+  ops.filter_transpose(wd, wt, K, k, k, Cn)
+  assert torch.equal(wt.cpu(), w.permute(3, 1, 2, 0).contiguous())
+  dx = ops.conv_dgrad(d, dy.cuda(), wt)
+  _check(dx, gx, name='dgrad')
+
+  dw = torch.empty((K, k, k, Cn), dtype=torch.float32, device='cuda')
+  ops.conv_wgrad(d, xd, dy.cuda(), dw)
+  r = util.rel_l2(dw.cpu(), gw)
+  assert r <= 2e-3, 'wgrad rel_l2 %.3e' % r
+
+
+def test_fprop_f32_out_with_padded_ld(hip_lib):
+  """dense-like: K=100 (not a multiple of 8), fp32 output with row stride 104, then the padded backward."""
+  from assembled_cnn_amd import ops
+  N, Cn, K, ld = 64, 256, 100, 104
+  x = _rand((N, 1, 1, Cn), 5)
+  w = _rand((K, 1, 1, Cn), 6, scale=Cn ** -0.5)
+  d = ops.make_conv_desc(N, 1, 1, Cn, K, 1, 1, 1, ldy=ld, out_f32=True)
+  y, _ = ops.conv_fprop(d, x.cuda(), w.cuda())
+  ref = x.float().view(N, Cn) @ w.float().view(K, Cn).t()
+  assert util.rel_l2(y.view(N, ld)[:, :K].cpu(), ref) <= 2e-3
+  # backward with dy padded to ld columns (zeros)
+  dy = torch.zeros((N, 1, 1, ld), dtype=BF)
+  dy[..., :K] = _rand((N, 1, 1, K), 7)
+  dd = ops.make_conv_desc(N, 1, 1, Cn, K, 1, 1, 1, ldy=ld)
+  dw = torch.empty((K, 1, 1, Cn), dtype=torch.float32, device='cuda')
+  ops.conv_wgrad(dd, x.cuda(), dy.cuda(), dw)
+  gw = dy.float().view(N, ld)[:, :K].t() @ x.float().view(N, Cn)
+  assert util.rel_l2(dw.view(K, Cn).cpu(), gw) <= 2e-3
+  wt = torch.zeros((Cn, 1, 1, ld), dtype=BF, device='cuda')
+  ops.filter_transpose(w.cuda(), wt, K, 1, 1, Cn, ld)
+  d2 = ops.make_conv_desc(N, 1, 1, Cn, ld, 1, 1, 1)
+  dx = ops.conv_dgrad(d2, dy.cuda(), wt)
+  gx = dy.float().view(N, ld)[:, :K] @ w.float().view(K, Cn)
+  _check(dx.view(N, Cn), gx, name='dense dgrad')
+
+
+@pytest.mark.parametrize('ksize,cout', [(7, 64), (3, 32)])
+def test_stem_conv_path(hip_lib, ksize, cout):
+  """3-channel first conv (7x7/2 and the ResNet-D 3x3/2) through the halo-buffer packing."""
+  from assembled_cnn_amd import nn, ops
+  N, H, W = 3, 32, 32
+  dev = torch.device('cuda')
+  arena = nn.ParamArena()
+  c = nn.Ctx(arena, True, True, 0.997, dev, False)
+  conv = nn.ConvKernel(c, ksize, 3, cout, stem=True)
+  arena.finalize(dev, 0)
+  x = _rand((N, H, W, 3), 11, scale=50.0)
+  xp = ops.stem_pad_input(x.cuda())
+  assert xp.shape == (N, H + 6, W + 6, 4)
+  assert torch.equal(xp[:, 3:3 + H, 3:3 + W, :3].cpu(), x)
+  halo = xp.clone()
+  halo[:, 3:3 + H, 3:3 + W, :3] = 0
+  assert int((halo.view(torch.int16) != 0).sum()) == 0, 'halo / 4th channel must be zero'
+  d = conv.desc(N, H, W, 2)
+  y, _ = conv.fprop(d, xp, False)
+  w = arena.wb(conv.name).cpu()
+  ref = _ref_conv(x, w, 2)
+  _check(y, ref, name='stem fprop')
+  dy = _rand(tuple(ref.shape), 12)
+  conv.backward(d, xp, dy.cuda(), False)
+  xr = x.float()
+  wr = w.float().requires_grad_(True)
+  from oracle import assembled_oracle as O
+  yr = O._conv_raw(xr.permute(0, 3, 1, 2), wr.permute(1, 2, 3, 0), ksize, 2)
+  (gw,) = torch.autograd.grad(yr, [wr], dy.float().permute(0, 3, 1, 2))
+  assert util.rel_l2(arena.g(conv.name).cpu(), gw) <= 2e-3
+
+
+def test_mfma_vs_naive_at_full_size(hip_lib):
+  """BASELINE-size layer (batch 64 slice of the 256x56x56x64 -> 128 SK conv): the MFMA kernels against
+  the one-thread-per-output debug kernels, where the CPU oracle would take minutes."""
+  from assembled_cnn_amd import ops
+  L = ops.L()
+  N, H, W, Cn, K, k = 64, 56, 56, 64, 128, 3
+  g = torch.Generator(device='cuda').manual_seed(0)
+  x = torch.randn((N, H, W, Cn), generator=g, device='cuda').to(BF)
+  w = (torch.randn((K, k, k, Cn), generator=g, device='cuda') * (k * k * Cn) ** -0.5).to(BF)
+  dy = torch.randn((N, H, W, K), generator=g, device='cuda').to(BF)
+  d = ops.make_conv_desc(N, H, W, Cn, K, k, k, 1)
+  st = torch.cuda.current_stream().cuda_stream
+  y, _ = ops.conv_fprop(d, x, w)
+  yn = torch.empty_like(y)
+  assert L.asm_conv2d_fprop_naive(C.byref(d), x.data_ptr(), w.data_ptr(), yn.data_ptr(), st) == 0
+  assert util.rel_l2(y.float(), yn.float()) <= 4e-3
+  wt = torch.empty((Cn, k, k, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w, wt, K, k, k, Cn)
+  dx = ops.conv_dgrad(d, dy, wt)
+  dxn = torch.empty_like(dx)
+  assert L.asm_conv2d_dgrad_naive(C.byref(d), dy.data_ptr(), w.data_ptr(), dxn.data_ptr(), st) == 0
+  assert util.rel_l2(dx.float(), dxn.float()) <= 4e-3
+  dw = torch.empty((K, k, k, Cn), dtype=torch.float32, device='cuda')
+  ops.conv_wgrad(d, x, dy, dw)
+  dwn = torch.empty_like(dw)
+  assert L.asm_conv2d_wgrad_naive(C.byref(d), x.data_ptr(), dy.data_ptr(), dwn.data_ptr(), st) == 0
+  assert util.rel_l2(dw, dwn) <= 2e-3
+  # linearity (size-independent property): conv(x, 2w) == 2 conv(x, w) bit-exactly in bf16
+  y2, _ = ops.conv_fprop(d, x, (w.float() * 2).to(BF))
+  assert torch.equal(y2.float(), y.float() * 2)
+  # wgrad is deterministic (slab reduce, no atomics)
+  dw2 = torch.empty_like(dw)
+  ops.conv_wgrad(d, x, dy, dw2)
+  assert torch.equal(dw, dw2)
+
+
+def test_tr_read_probe(hip_lib):
+  """ds_read_b64_tr_b16 semantics the wgrad kernel relies on: with lane l reading LDS elements
+  [4l, 4l+4) of lds[i] = i, lane l receives element j = 16*j + (l & 15) + 64*(l >> 4)."""
+  from assembled_cnn_amd import ops
+  out = torch.empty((64, 4), dtype=torch.int16, device='cuda')
+  assert ops.L().asm_debug_tr_probe(out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+  lanes = torch.arange(64)[:, None]
+  js = torch.arange(4)[None, :]
+  expect = (16 * js + (lanes & 15) + 64 * (lanes >> 4)).to(torch.int16)
+  assert torch.equal(out.cpu(), expect), out.cpu()
+
+
+def test_error_convention(hip_lib):
+  """ValueError / NotImplementedError split of the reference -> ASM_EINVAL / ASM_ENOTSUP."""
+  from assembled_cnn_amd import ops
+  x = torch.zeros((1, 4, 4, 12), dtype=BF, device='cuda')
+  w = torch.zeros((8, 3, 3, 12), dtype=BF, device='cuda')
+  with pytest.raises(ValueError):
+    ops.conv_fprop(ops.make_conv_desc(1, 4, 4, 12, 8, 3, 3, 1), x, w)   # C % 8 != 0
+  with pytest.raises(ValueError):
+    ops.conv_fprop(ops.make_conv_desc(1, 4, 4, 16, 8, 3, 3, 3), x, w)   # stride 3

@@ -1,0 +1,68 @@
+"""GPU parity of the whole hot path (HIP kernels through the C ABI) vs the CPU oracle: forward taps /
+logits, the hand-written backward tape, and short optimisation trajectories.  See tests/model_parity.py
+for why whole-network tolerances are statistical while the per-kernel ones are tight."""
+import pytest
+import torch
+
+from tests import model_parity as mp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', ['r50v1', 'a-r50', 'a-r50-d', 'r50v1-d', 'se-proj'])
+def test_forward_train_mode(hip_lib, name):
+  mp.check_forward(name, 'cuda', 16, 64, True, 6e-2)
+
+
+@pytest.mark.parametrize('name', ['r50v1', 'a-r50'])
+def test_forward_eval_mode_config1_style(hip_lib, name):
+  """BASELINE config 1 style: eval forward with non-trivial moving statistics (reduced to 16 images, 96x96)."""
+  mp.check_forward(name, 'cuda', 16, 96, False, 4e-2)
+
+
+@pytest.mark.parametrize('name', ['r50v1', 'a-r50-d', 'se-proj'])
+def test_backward_tape_vs_autograd(hip_lib, name):
+  mp.check_backward(name, 'cuda', 16, 64)
+
+
+def test_train_steps_assemble_mixup_ls(hip_lib):
+  mp.check_train_steps('a-r50-d', 'cuda', 8, 64, 3, dict(base_learning_rate=0.001, weight_decay=1e-4, label_smoothing=0.1),
+                       mixup_type=1, rel_tol=3e-2)
+
+
+def test_train_steps_kd(hip_lib):
+  mp.check_train_steps('r50v1', 'cuda', 8, 64, 2, dict(base_learning_rate=0.001, weight_decay=1e-4), kd_temp=1.0,
+                       rel_tol=3e-2)
+
+
+def test_step_is_deterministic(hip_lib):
+  """No atomics anywhere on the path: two identical steps from identical state give identical bits."""
+  from assembled_cnn_amd.train import HParams, Trainer
+  outs = []
+  for _ in range(2):
+    hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
+                 zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01, batch_size=8)
+    tr = Trainer(hp, seed=3, device='cuda')
+    img, _, labels = mp.inputs(8, 64)
+    tr.train_step(img.cuda(), labels.cuda())
+    tr.train_step(img.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    outs.append((tr.model.arena.w32.clone(), tr.last['loss_rows'].clone()))
+  assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_full_size_layer_shapes_run(hip_lib):
+  """One training step at the BASELINE image size (224x224, batch 8): shapes of every layer of
+  Assemble-ResNet-50 are exercised at full resolution; loss must be finite and near ln(1001)."""
+  import math
+  from assembled_cnn_amd.train import HParams, Trainer
+  hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
+               use_resnet_d=True, zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01,
+               batch_size=8, label_smoothing=0.1)
+  tr = Trainer(hp, seed=0, device='cuda')
+  img, _, labels = mp.inputs(8, 224)
+  tr.train_step(img.cuda(), labels.cuda())
+  ce = float(tr.cross_entropy())
+  assert abs(ce - math.log(1001)) < 1.0, ce
+  assert bool(torch.isfinite(tr.model.arena.w32).all())
+  assert tr.model.num_params() == 41867721

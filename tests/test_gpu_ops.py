@@ -1,0 +1,330 @@
+"""GPU parity: the HBM-bound kernels (BN, pools, blur, SK/SE, loss, mixup, optimiser) through the C ABI
+vs the CPU oracle on identical seeded bf16 inputs.
+
+Tolerance: outputs are bf16 -> relative L2 <= 4e-3 and max |err| <= 2^-7 max|ref|; fp32 outputs
+(statistics, parameter gradients, losses) relative <= 1e-4 unless noted."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _rand(shape, seed, scale=1.0, shift=0.0):
+  g = torch.Generator().manual_seed(seed)
+  return (torch.randn(shape, generator=g) * scale + shift).to(BF)
+
+
+def _close(out, ref, rel=4e-3, name=''):
+  out = out.float().cpu()
+  ref = ref.float()
+  r = util.rel_l2(out, ref)
+  m = util.max_abs(out, ref)
+  lim = float(ref.abs().max()) * 2 ** -7 + 1e-6
+  assert r <= rel, '%s rel_l2 %.3e' % (name, r)
+  assert m <= lim, '%s max_abs %.3e > %.3e' % (name, m, lim)
+
+
+def _nchw(t):
+  return t.float().permute(0, 3, 1, 2)
+
+
+def _nhwc(t):
+  return t.permute(0, 2, 3, 1).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [(4, 14, 14, 64), (2, 7, 7, 2048), (256, 1, 1, 32), (3, 9, 9, 72), (5, 6, 6, 1008)])
+@pytest.mark.parametrize('relu,res_mode', [(True, 0), (False, 0), (True, 1), (False, 1), (True, 2)])
+def test_bn_train_fwd_bwd(hip_lib, shape, relu, res_mode):
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  N, H, W, Cn = shape
+  if res_mode == 2 and (H % 2 or W % 2):
+    pytest.skip('upsample residual needs even H, W')
+  M = N * H * W
+  x = _rand(shape, 1, scale=2.0, shift=0.3)
+  gamma = torch.randn(Cn, generator=torch.Generator().manual_seed(2)) * 0.5 + 1
+  beta = torch.randn(Cn, generator=torch.Generator().manual_seed(3)) * 0.2
+  mm0, mv0 = torch.zeros(Cn), torch.ones(Cn)
+  res = None
+  if res_mode == 1:
+    res = _rand(shape, 4)
+  elif res_mode == 2:
+    res = _rand((N, H // 2, W // 2, Cn), 4)
+  dout = _rand(shape, 5)
+
+  # oracle
+  vs = O.VarStore(0)
+  ctx = O.Ctx(vs, True)
+  vs.begin_call()
+  xr = _nchw(x).requires_grad_(True)
+  rr = _nchw(res).requires_grad_(True) if res is not None else None
+  g_, b_, _, _, mmn, mvn = vs.bn_vars(Cn, False, layer_name='bn')
+  with torch.no_grad():
+    g_.copy_(gamma)
+    b_.copy_(beta)
+  rfull = O.upsample2x_nearest(rr) if res_mode == 2 else rr
+  yr = O.batch_norm(ctx, xr, True, momentum=0.9, relu=relu, residual=rfull, layer_name='bn')
+  outs = [xr, g_, b_] + ([rr] if rr is not None else [])
+  grads = torch.autograd.grad(yr, outs, _nchw(dout))
+
+  # HIP
+  xd = x.cuda()
+  part = ops.bn_stats(xd, M, Cn)
+  mm, mv = mm0.cuda(), mv0.cuda()
+  gd, bd = gamma.cuda(), beta.cuda()
+  mean, invstd, scale, shift = ops.bn_finalize(part, M, Cn, gd, bd, 1e-5, 0.9, mm, mv)
+  y = ops.bn_apply(xd, M, Cn, scale, shift, res.cuda() if res is not None else None, res_mode, relu, H, W)
+  _close(y, _nhwc(yr.detach()), name='bn fwd')
+  xf = x.float().view(M, Cn)
+  assert torch.allclose(mean.cpu(), xf.mean(0), rtol=1e-4, atol=1e-5)
+  assert torch.allclose(invstd.cpu(), 1 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5), rtol=2e-4)
+  assert torch.allclose(mm.cpu(), vs.pending_updates[mmn], rtol=1e-4, atol=1e-6), 'moving mean'
+  assert torch.allclose(mv.cpu(), vs.pending_updates[mvn], rtol=2e-4, atol=1e-6), 'moving variance (Bessel)'
+
+  dgamma = torch.empty(Cn, device='cuda')
+  dbeta = torch.empty(Cn, device='cuda')
+  want_dz = res is not None and relu
+  dx, dz = ops.bn_bwd(dout.cuda(), xd, y, relu, M, Cn, gd, mean, invstd, dgamma, dbeta, want_dz)
+  # the oracle mask comes from its own output; rows where the two outputs disagree in sign are
+  # measure-zero for these sizes, so the tensors are comparable at bf16 tolerance
+  _close(dx, _nhwc(grads[0]), rel=6e-3, name='bn dx')
+  assert util.rel_l2(dgamma.cpu(), grads[1]) <= 2e-3
+  assert util.rel_l2(dbeta.cpu(), grads[2]) <= 2e-3
+  if want_dz:
+    dres_ref = _nhwc(grads[3])
+    if res_mode == 2:
+      _close(ops.upsample2x_bwd(dz), dres_ref, name='upsample bwd')
+    else:
+      _close(dz, dres_ref, name='bn dz')
+
+
+def test_bn_infer(hip_lib):
+  from assembled_cnn_amd import ops
+  Cn, M = 128, 300
+  x = _rand((M, Cn), 1)
+  g = torch.rand(Cn) + 0.5
+  b = torch.randn(Cn)
+  mm = torch.randn(Cn) * 0.1
+  mv = torch.rand(Cn) + 0.5
+  scale, shift = ops.bn_infer_coeffs(Cn, g.cuda(), b.cuda(), mm.cuda(), mv.cuda(), 1e-5)
+  y = ops.bn_apply(x.cuda(), M, Cn, scale, shift, None, 0, False)
+  ref = (x.float() - mm) / torch.sqrt(mv + 1e-5) * g + b
+  _close(y, ref, name='bn infer')
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [(2, 112 // 4, 112 // 4, 64), (3, 15, 17, 8)])
+def test_maxpool_same(hip_lib, shape):
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  x = _rand(shape, 1)
+  xr = _nchw(x).requires_grad_(True)
+  yr = O.max_pool_same(xr, 3, 2)
+  y, am = ops.maxpool3x3s2_fwd(x.cuda())
+  assert torch.equal(y.float().cpu(), _nhwc(yr.detach()))
+  dy = _rand(tuple(y.shape), 2)
+  (gx,) = torch.autograd.grad(yr, xr, _nchw(dy))
+  dx = ops.maxpool3x3s2_bwd(dy.cuda(), am, shape)
+  _close(dx, _nhwc(gx), name='maxpool bwd')
+
+
+@pytest.mark.parametrize('k,stride,pad,cv', [(3, 2, 1, False), (2, 2, 0, False), (2, 1, 0, True)])
+@pytest.mark.parametrize('shape', [(2, 14, 14, 64), (2, 7, 7, 16)])
+def test_avgpool(hip_lib, shape, k, stride, pad, cv):
+  """the three shortcut poolings: BL 3x3/2 (divisor 9), ResNet-D 2x2/2, ResNet-D stride-1 SAME (valid count)."""
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  x = _rand(shape, 1)
+  xr = _nchw(x).requires_grad_(True)
+  if cv:
+    yr = O.avg_pool_same(xr, k, stride)
+  else:
+    yr = O.avg_pool_valid(O.fixed_padding(xr, k), k, stride)
+  Ho, Wo = yr.shape[2], yr.shape[3]
+  y = ops.avgpool_fwd(x.cuda(), k, stride, pad, Ho, Wo, cv)
+  _close(y, _nhwc(yr.detach()), name='avgpool fwd')
+  dy = _rand(tuple(y.shape), 2)
+  (gx,) = torch.autograd.grad(yr, xr, _nchw(dy))
+  dx = ops.avgpool_bwd(dy.cuda(), shape, k, stride, pad, cv)
+  _close(dx, _nhwc(gx), name='avgpool bwd')
+
+
+@pytest.mark.parametrize('k', [3, 5, 2])
+@pytest.mark.parametrize('shape', [(2, 14, 14, 64), (1, 7, 9, 8)])
+def test_blurpool(hip_lib, shape, k):
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  x = _rand(shape, 1)
+  xr = _nchw(x).requires_grad_(True)
+  yr = O.anti_aliased_downsample(O.Ctx(O.VarStore(0), False), xr, filt_size=k, stride=2)
+  y = ops.blurpool_fwd(x.cuda(), k, 2)
+  _close(y, _nhwc(yr.detach()), name='blur fwd')
+  dy = _rand(tuple(y.shape), 2)
+  (gx,) = torch.autograd.grad(yr, xr, _nchw(dy))
+  dx = ops.blurpool_bwd(dy.cuda(), shape, k, 2)
+  _close(dx, _nhwc(gx), name='blur bwd')
+
+
+def test_gap_and_upsample(hip_lib):
+  from assembled_cnn_amd import ops
+  x = _rand((3, 7, 7, 2048), 1)
+  y = ops.gap_fwd(x.cuda())
+  _close(y.view(3, 2048), x.float().mean((1, 2)), name='gap')
+  dy = _rand((3, 1, 1, 2048), 2)
+  dx = ops.gap_bwd(dy.cuda(), (3, 7, 7, 2048))
+  _close(dx, (dy.float() / 49).expand(3, 7, 7, 2048), name='gap bwd')
+  g = _rand((2, 8, 8, 16), 3)
+  _close(ops.upsample2x_bwd(g.cuda()), g.float().view(2, 4, 2, 4, 2, 16).sum((2, 4)), name='upsample bwd')
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,H,W,F_', [(4, 14, 14, 64), (3, 7, 7, 512), (2, 5, 5, 32)])
+def test_sk_select(hip_lib, N, H, W, F_):
+  from assembled_cnn_amd import ops
+  f = _rand((N, H, W, 2 * F_), 1).clamp(min=0)
+  att = torch.randn((N, 2 * F_), generator=torch.Generator().manual_seed(2))
+  dv = _rand((N, H, W, F_), 3)
+  fr = f.float().requires_grad_(True)
+  ar = att.clone().requires_grad_(True)
+  a = torch.softmax(torch.stack([ar[:, :F_], ar[:, F_:]], 0), 0)
+  v = fr[..., :F_] * a[0][:, None, None, :] + fr[..., F_:] * a[1][:, None, None, :]
+  s_ref = (fr[..., :F_] + fr[..., F_:]).mean((1, 2))
+  gf, ga = torch.autograd.grad(v, [fr, ar], dv.float())
+  fd, ad = f.cuda(), att.cuda()
+  _close(ops.sk_gap(fd, F_).view(N, F_), s_ref.detach(), name='sk gap')
+  _close(ops.sk_select_fwd(fd, ad, F_), v.detach(), name='sk select')
+  datt = ops.sk_select_bwd_att(fd, dv.cuda(), ad, F_)
+  _close(datt.view(N, 2 * F_), ga, rel=6e-3, name='sk datt')
+  ds = _rand((N, 1, 1, F_), 4)
+  df = ops.sk_select_bwd_f(dv.cuda(), ad, ds.cuda(), F_)
+  ref = gf + (ds.float() / (H * W)).repeat(1, 1, 1, 2).expand(N, H, W, 2 * F_)
+  _close(df, ref, name='sk df')
+
+
+def test_se_scale(hip_lib):
+  from assembled_cnn_amd import ops
+  N, H, W, Cn = 3, 7, 7, 256
+  x = _rand((N, H, W, Cn), 1)
+  e = torch.randn((N, Cn), generator=torch.Generator().manual_seed(2))
+  dy = _rand((N, H, W, Cn), 3)
+  xr = x.float().requires_grad_(True)
+  er = e.clone().requires_grad_(True)
+  y = xr * torch.sigmoid(er)[:, None, None, :]
+  gx, ge = torch.autograd.grad(y, [xr, er], dy.float())
+  _close(ops.se_scale_fwd(x.cuda(), e.cuda()), y.detach(), name='se fwd')
+  _close(ops.se_scale_bwd_e(x.cuda(), dy.cuda(), e.cuda()).view(N, Cn), ge, rel=6e-3, name='se de')
+  dsq = _rand((N, 1, 1, Cn), 4)
+  ref = gx + (dsq.float() / (H * W)).expand(N, H, W, Cn)
+  _close(ops.se_scale_bwd_x(dy.cuda(), e.cuda(), dsq.cuda()), ref, name='se dx')
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('eps,T', [(0.0, 0.0), (0.1, 0.0), (0.1, 1.0), (0.0, 4.0)])
+def test_softmax_ce(hip_lib, eps, T):
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  B, Cn, ld = 33, 1001, 1008
+  g = torch.Generator().manual_seed(1)
+  logits = torch.zeros(B, ld)
+  logits[:, :Cn] = torch.randn(B, Cn, generator=g) * 3
+  lam = torch.rand(B, 1, generator=g)
+  y = lam * F.one_hot(torch.randint(0, Cn, (B,), generator=g), Cn) + (1 - lam) * F.one_hot(
+      torch.randint(0, Cn, (B,), generator=g), Cn)
+  teacher = torch.softmax(torch.randn(B, Cn, generator=g) * 3 / max(T, 1.0), 1) if T > 0 else None
+  z = logits[:, :Cn].clone().requires_grad_(True)
+  loss = O.softmax_cross_entropy(z, y, eps)
+  if T > 0:
+    loss = loss + O.kd_loss(z, teacher, T)
+  (gz,) = torch.autograd.grad(loss * 128.0, z)
+  rows, dz = ops.softmax_ce(logits.cuda(), ld, y.float().cuda(), teacher.cuda() if T > 0 else None, B, Cn, eps, T,
+                            128.0, ld)
+  assert abs(float(rows.mean()) - float(loss)) <= 1e-5 * abs(float(loss)) + 1e-5
+  assert abs(float(ops.mean_f32(rows)) - float(loss)) <= 1e-5 * abs(float(loss)) + 1e-5
+  dz = dz.view(B, ld).float().cpu()
+  assert float(dz[:, Cn:].abs().max()) == 0.0, 'padding columns must be zero'
+  _close(dz[:, :Cn], gz, name='dlogits')
+
+
+def test_onehot_softmax_rows(hip_lib):
+  from assembled_cnn_amd import ops
+  lab = torch.tensor([0, 5, 1000, 7], dtype=torch.int32)
+  oh = ops.onehot(lab.cuda(), 4, 1001).cpu()
+  assert torch.equal(oh, F.one_hot(lab.long(), 1001).float())
+  x = torch.randn(5, 1001)
+  sm = ops.softmax_rows(x.cuda(), 5, 1001, 0.5).cpu()
+  assert torch.allclose(sm, torch.softmax(x * 0.5, 1), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('mixup_type', [0, 1, 2])
+@pytest.mark.parametrize('u8', [True, False])
+def test_mixup_meansub(hip_lib, mixup_type, u8):
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  Bin, H, W = 6, 10, 12
+  img = util.seeded_images(Bin, H, W, 1)
+  lam1 = torch.tensor([0.2, 0.9, 0.5])
+  lam2 = torch.tensor([0.7, 0.1, 0.35])
+  x = O.mean_image_subtraction(img.float())
+  y = F.one_hot(torch.tensor([1, 2, 3, 4, 5, 6]), 11).float()
+  if mixup_type == 0:
+    xr, yr = x, y
+  else:
+    xr, yr, _ = O.mixup(x, y, lam1, keep_batch_size=(mixup_type == 2), lam2=lam2)
+  src = img.cuda() if u8 else img.float().cuda()
+  out = ops.mixup_meansub(src, mixup_type, lam1.cuda(), lam2.cuda())
+  Bout = xr.shape[0]
+  assert out.shape == (Bout, H + 6, W + 6, 4)
+  _close(out[:, 3:3 + H, 3:3 + W, :3], xr, name='mixed images')
+  halo = out.clone()
+  halo[:, 3:3 + H, 3:3 + W, :3] = 0
+  assert int((halo.view(torch.int16) != 0).sum()) == 0
+  yo = ops.mixup_labels(y.cuda(), mixup_type, lam1.cuda(), lam2.cuda()).cpu()
+  assert torch.allclose(yo, yr, atol=1e-6)
+  if mixup_type:  # lambda = 1 is the identity on the first half (SURVEY 8c pin)
+    one = torch.ones(3)
+    out1 = ops.mixup_meansub(src, 1, one.cuda(), None)
+    _close(out1[:, 3:3 + H, 3:3 + W, :3], x[:3], name='lambda=1')
+
+
+def test_sgd_momentum(hip_lib):
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  n = 1000 * 8 + 5
+  g = torch.Generator().manual_seed(0)
+  w = torch.randn(n, generator=g)
+  a = torch.randn(n, generator=g) * 0.1
+  gr = torch.randn(n, generator=g) * 128.0
+  wd, ad, gd = w.cuda(), a.cuda(), gr.cuda()
+  wb = torch.empty(n, dtype=BF, device='cuda')
+  ops.sgd_momentum(wd, ad, gd, wb, 0.1, 0.9, 1e-4, 1.0 / 128.0)
+  wr, ar = w.clone(), a.clone()
+  O.momentum_step([wr], [gr / 128.0 + 1e-4 * w], [ar], 0.1, 0.9)
+  assert torch.allclose(wd.cpu(), wr, rtol=1e-5, atol=1e-6)
+  assert torch.allclose(ad.cpu(), ar, rtol=1e-5, atol=1e-6)
+  assert torch.equal(wb.cpu(), wd.cpu().to(BF))
+
+
+def test_elementwise(hip_lib):
+  from assembled_cnn_amd import ops
+  a, b = _rand((1024 * 8,), 1), _rand((1024 * 8,), 2)
+  assert torch.equal(ops.add_bf16(a.cuda(), b.cuda()).cpu(), (a.float() + b.float()).to(BF))
+  y = ops.relu_fwd(a.cuda())
+  assert torch.equal(y.cpu(), a.clamp(min=0))
+  assert torch.equal(ops.relu_bwd(b.cuda(), y).cpu(), torch.where(a > 0, b, torch.zeros_like(b)))
+  z = torch.randn(7, 16)
+  bias = torch.randn(10)
+  zd = z.cuda()
+  ops.bias_add_f32(zd, bias.cuda(), 7, 10, 16)
+  ref = z.clone()
+  ref[:, :10] += bias
+  assert torch.allclose(zd.cpu(), ref)
+  dz = _rand((7, 16), 3)
+  db = torch.empty(10, device='cuda')
+  ops.bias_grad_bf16(dz.cuda(), 7, 10, 16, db)
+  assert torch.allclose(db.cpu(), dz.float()[:, :10].sum(0), rtol=1e-5, atol=1e-5)

@@ -1,0 +1,74 @@
+"""Host logic of assembled_cnn_amd (arenas, tape, topology walker, trainer) driven through the CPU test
+double of the C ABI and compared with the oracle.  No GPU; the HIP kernels themselves are covered by the
+-m gpu tier."""
+import pytest
+import torch
+
+from tests import model_parity as mp
+
+
+@pytest.mark.parametrize('name', ['r50v1', 'a-r50-d', 'se-proj'])
+def test_forward_train_mode(cpu_double, name):
+  mp.check_forward(name, 'cpu', 8, 64, True, 6e-2)
+
+
+def test_forward_eval_mode_uses_moving_stats(cpu_double):
+  mp.check_forward('a-r50', 'cpu', 4, 64, False, 4e-2)
+
+
+@pytest.mark.parametrize('name', ['a-r50', 'r50v1-d'])
+def test_backward_tape_vs_autograd(cpu_double, name):
+  mp.check_backward(name, 'cpu', 8, 64)
+
+
+def test_train_steps_mixup_label_smoothing(cpu_double):
+  mp.check_train_steps('a-r50', 'cpu', 4, 64, 3, dict(base_learning_rate=0.001, weight_decay=1e-4, label_smoothing=0.1),
+                       mixup_type=1, rel_tol=3e-2)
+
+
+def test_train_steps_kd(cpu_double):
+  mp.check_train_steps('r50v1', 'cpu', 4, 64, 2, dict(base_learning_rate=0.001, weight_decay=1e-4), kd_temp=1.0,
+                       rel_tol=3e-2)
+
+
+def test_variable_names_counts_and_flag_errors(cpu_double):
+  from assembled_cnn_amd.model import Model
+  m = Model(50, num_classes=1001, device='cpu', resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
+            anti_alias_filter_size=3)
+  m.build((64, 64))
+  assert m.num_params() == 41848489 and len(m.arena.specs) == 306
+  assert list(m.arena.specs)[0] == 'resnet_model/stage0/conv2d/kernel'
+  assert 'resnet_model/stage1/big1/sk_block/sk_fc_1/kernel' in m.arena.specs
+  with pytest.raises(ValueError):
+    Model(50, num_classes=10, resnet_version=3)
+  with pytest.raises(ValueError):
+    Model(77, num_classes=10)
+  with pytest.raises(NotImplementedError):
+    Model(18, num_classes=10)
+  with pytest.raises(NotImplementedError):
+    Model(50, num_classes=10, dtype='fp32')
+  with pytest.raises(ValueError):
+    Model(50, num_classes=10, dtype='int8')
+  with pytest.raises(NotImplementedError):
+    Model(50, num_classes=10, pool_type='nope')
+  with pytest.raises(ValueError):
+    m(torch.zeros(1, 64, 64, 3), False, use_resnet_d=True)   # variables were created without the D stem
+
+
+def test_lr_schedule_and_hparams_match_reference_defaults():
+  from assembled_cnn_amd import train
+  from oracle import assembled_oracle as O
+  p = train.HParams()
+  assert (p.resnet_version, p.bn_momentum, p.weight_decay, p.momentum, p.base_learning_rate,
+          p.learning_rate_decay_type, p.bl_alpha, p.bl_beta, p.mixup_type, p.kd_temp, p.label_smoothing) == (
+              1, 0.997, 4e-5, 0.9, 0.01, 'exponential', 2, 4, 0, 0.0, 0.0)
+  assert p.get_loss_scale() == 1.0 and train.HParams(dtype='fp16').get_loss_scale() == 128.0
+  assert train.HParams(loss_scale=64).get_loss_scale() == 64.0
+  for kind in ('exponential', 'fixed', 'polynomial', 'piecewise', 'cosine'):
+    args = (kind, 1024, 1024, 1281167, 2.0, 0.94, 1e-4, [30, 60, 80, 90], [1, .1, .01, .001, 1e-4], 0.4)
+    a = train.learning_rate_with_decay(*args, warmup_epochs=5, train_epochs=120)
+    b = O.learning_rate_with_decay(*args, warmup_epochs=5, train_epochs=120)
+    for step in (0, 1, 100, 6255, 6256, 40000, 75000, 150000, 10 ** 7):
+      assert abs(a(step) - b(step)) <= 1e-12, (kind, step)
+  with pytest.raises(NotImplementedError):
+    train.learning_rate_with_decay('nope', 1, 1, 1, 1, 1, 1, [], [], 1)
