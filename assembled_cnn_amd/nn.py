@@ -434,9 +434,9 @@ def conv_plain(ctx: Ctx, x: Var, conv: ConvKernel, out_f32: bool, ldy: int = 0):
 
   def bwd(dy: torch.Tensor):
     # dy: bf16 with channel stride == ldy (or cout)
-    dd = d
-    if ldy and ldy != conv.cout:
-      dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo, ldy=ldy)
+    # the backward descriptor is always a bf16 one; dy's row stride is ldy when the logits were padded
+    dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo,
+                            ldy=ldy if (ldy and ldy != conv.cout) else 0)
     dx = conv.backward(dd, x_t, dy, x.needs_grad)
     if dx is not None:
       accum_grad(x, dx, True)

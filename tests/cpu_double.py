@@ -79,8 +79,23 @@ class CpuDouble(object):
     d = _desc(d)
     return (d.N * d.Ho * d.Wo + 127) // 128
 
+  @staticmethod
+  def _validate(d, what):
+    """the argument checks of csrc/conv_igemm.hip / conv_wgrad.hip, so host-side misuse fails on CPU too"""
+    assert d.C % 8 == 0 and d.stride in (1, 2) and d.Ho > 0 and d.Wo > 0 and 0 <= d.pad < 64, what
+    ldy = d.ldy if d.ldy else d.K
+    if what == 'fprop':
+      assert ldy % (4 if d.out_f32 else 8) == 0 and ldy >= d.K, 'fprop: bad ldy'
+    elif what == 'dgrad':
+      assert d.K % 8 == 0 and not d.out_f32 and not d.x_img_pitch and not d.x_row_pitch and not d.x_pix_pitch, \
+          'dgrad: custom pitches / f32 output / unpadded K not supported'
+    else:
+      assert ldy % 8 == 0 and ldy >= d.K and not d.out_f32, 'wgrad: bad dy row stride'
+
   def asm_conv2d_fprop(self, d, x, w, y, stats, stream):
     d = _desc(d)
+    self._validate(d, 'fprop')
+    assert not (stats and d.out_f32)
     ldy = d.ldy if d.ldy else d.K
     wt = T(w, (d.K, d.R, d.S, d.C), 'bf16').float()
     acc = torch.zeros(d.N, d.Ho, d.Wo, d.K)
@@ -102,6 +117,7 @@ class CpuDouble(object):
 
   def asm_conv2d_dgrad(self, d, dy, wt, dx, stream):
     d = _desc(d)
+    self._validate(d, 'dgrad')
     g = T(dy, (d.N, d.Ho, d.Wo, d.K), 'bf16').float()
     w_crsk = T(wt, (d.C, d.R, d.S, d.K), 'bf16').float()
     w_oihw = w_crsk.permute(3, 0, 1, 2)  # [K, C, R, S]
@@ -119,6 +135,7 @@ class CpuDouble(object):
 
   def asm_conv2d_wgrad(self, d, x, dy, dw, ws, ws_bytes, stream):
     d = _desc(d)
+    self._validate(d, 'wgrad')
     ldy = d.ldy if d.ldy else d.K
     g = T(dy, (d.N * d.Ho * d.Wo, ldy), 'bf16').float()[:, :d.K]
     out = T(dw, (d.K, d.R, d.S, d.C), 'f32')
