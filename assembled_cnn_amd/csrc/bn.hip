@@ -122,6 +122,32 @@ __device__ __forceinline__ void sum_partials(const float* partial, int blocks, i
     }
 }
 
+// partial compaction: [blocks][2][C] -> [groups][2][C]; each output group sums a contiguous range of
+// input blocks (fp64 accumulate).  Keeps the finalize kernels short when a conv epilogue emitted
+// thousands of 128-row partials (25088 for the 112x112 stem at batch 256).
+__global__ __launch_bounds__(256) void partials_compact_kernel(const float* __restrict__ in, int blocks, int C,
+                                                               float* __restrict__ out, int per_group) {
+  __shared__ double red[2][16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cx;
+  const int b0 = blockIdx.y * per_group;
+  const int b1 = min(blocks, b0 + per_group);
+  double s0 = 0.0, s1 = 0.0;
+  if (ch < C)
+    for (int b = b0 + ry; b < b1; b += 16) {
+      s0 += (double)in[((size_t)b * 2 + 0) * C + ch];
+      s1 += (double)in[((size_t)b * 2 + 1) * C + ch];
+    }
+  red[0][ry][cx] = s0;
+  red[1][ry][cx] = s1;
+  __syncthreads();
+  if (ry < 2 && ch < C) {
+    double t = 0.0;
+    for (int r = 0; r < 16; ++r) t += red[ry][r][cx];
+    out[((size_t)blockIdx.y * 2 + ry) * C + ch] = (float)t;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, int M, int C,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float momentum,
@@ -300,6 +326,17 @@ extern "C" int asm_bn_stats(const void* x, int M, int C, float* stats_partial, v
   hipLaunchKernelGGL((rowreduce_kernel<0>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, nullptr, nullptr, 0, M, C, nullptr, nullptr, t, stats_partial);
   ASM_CHECK_LAUNCH("bn_stats");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_partials_compact(const float* partial, int blocks, int C, float* out, int groups,
+                                       void* stream) {
+  ASM_REQUIRE(partial && out && blocks > 0 && C > 0 && groups > 0 && groups <= blocks, "bn_partials_compact: bad arguments");
+  const int per_group = cdiv(blocks, groups);
+  ASM_REQUIRE(cdiv(blocks, per_group) == groups, "bn_partials_compact: groups=%d does not tile blocks=%d", groups, blocks);
+  hipLaunchKernelGGL(partials_compact_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, (hipStream_t)stream, partial,
+                     blocks, C, out, per_group);
+  ASM_CHECK_LAUNCH("bn_partials_compact");
   return ASM_OK;
 }
 

@@ -58,9 +58,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int TN = BN / 64;           // 32-wide filter tiles per wave
   constexpr int TM = 2;                 // 32-wide pixel tiles per wave
-  static_assert(2 * STAGE <= LDS_BYTES, "lds");
+  // LDS is sized per instantiation (main-loop double buffer vs the epilogue's output tile) so that
+  // the small-tile variants run 3-6 workgroups per CU: the short-K layers are latency-bound and
+  // need the extra waves to hide the global-load round trip of every K-step.
+  constexpr int LDO = BN * 2 + 16;  // padded output-tile row (bytes)
+  constexpr int EPI = OUT_F32 ? 0 : BM * LDO;
+  constexpr int LDS = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  static_assert(LDS <= LDS_BYTES, "lds");
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -231,11 +237,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
         }
       }
   } else {
-    constexpr int LDO = BN * 2 + 16;  // padded output-tile row (bytes)
     constexpr int CPO = BN / 8;       // 16-byte chunks per output row
     constexpr int RPO = 256 / CPO;    // rows per pass
     constexpr int OP = BM / RPO;      // passes
-    static_assert(BM * LDO + (STATS ? RPO * BN * 2 * 4 : 0) <= LDS_BYTES, "lds epilogue");
+    static_assert(RPO * BN * 2 * 4 <= BM * LDO, "stats scratch aliases the output tile");
     unsigned char* os = smem;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -276,7 +281,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
       }
     }
     if constexpr (STATS) {
-      float* red = reinterpret_cast<float*>(smem + BM * LDO);  // [RPO][2][BN]
+      float* red = reinterpret_cast<float*>(smem);  // [RPO][2][BN], aliases the (now consumed) output tile
+      __syncthreads();
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         red[(orow * 2 + 0) * BN + oc * 8 + e] = s[e];
@@ -310,7 +316,9 @@ int launch_cfg(const IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
 
 int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   const int bn = (a.Co <= 64) ? 64 : 128;
-  const int bk = (a.Ci % 64 == 0) ? 64 : 32;
+  // BK=64 halves the barrier count for the MFMA-heavy 3x3 / 7x7 layers; the 1x1 layers are HBM-bound
+  // with very short K loops, where the smaller BK=32 footprint (3-6 workgroups per CU) hides latency better
+  const int bk = (a.Ci % 64 == 0 && a.R * a.S > 1) ? 64 : 32;
   a.n_tiles_n = cdiv(a.Co, bn);
   a.n_blocks = cdiv(a.M, BM) * a.n_tiles_n;
   a.kchunks = cdiv(a.Ci, bk);

@@ -34,10 +34,10 @@ struct WgradArgs {
   int HoWo, Wo;
 };
 
-constexpr int WT = 128;   // tile edge (channels)
+constexpr int WT = 128;   // column-tile edge: (tap, channel) columns per block
 constexpr int WPX = 64;   // pixels per step
 constexpr int WROWB = WT * 2;
-constexpr int WTILE = WPX * WROWB;  // 16 KiB per operand per stage
+constexpr int WTILE = WPX * WROWB;  // 16 KiB: the x tile of one stage
 
 __device__ __forceinline__ bf16x4 ds_read_tr(const unsigned char* p) {
   typedef __attribute__((ext_vector_type(4))) short s4;
@@ -45,13 +45,34 @@ __device__ __forceinline__ bf16x4 ds_read_tr(const unsigned char* p) {
       (__attribute__((address_space(3))) s4*)(const_cast<unsigned char*>(p)));
 }
 
+// 16-byte-chunk XOR swizzle for an LDS tile whose rows are RB bytes: the 4 pixel rows x 64 bytes one
+// transposing read touches must cover all 64 banks exactly once.
+template <int RB>
+__device__ __forceinline__ int tr_swz(int row) {
+  return RB == 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0);
+}
+
+// BNW = output-channel (dy) tile width: 128 / 64 / 32, so narrow layers (K = 32 / 64 at 112x112 and
+// 56x56, where the pixel count is largest) neither waste MFMAs on zero rows nor LDS on empty tiles.
+template <int BNW>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WTILE];  // 2 stages x (dy, x)
+  constexpr int YROWB = BNW * 2;            // dy tile row bytes
+  constexpr int YTILE = WPX * YROWB;
+  constexpr int STAGE = YTILE + WTILE;
+  constexpr int CY = BNW / 8;               // 16-byte chunks per dy row
+  constexpr int YRP = 256 / CY;             // dy rows staged per pass
+  constexpr int YP = WPX / YRP;             // dy passes (4 / 2 / 1)
+  constexpr int NT = BNW >= 64 ? 2 : 1;     // 32-row dy tiles per wave
+  constexpr int CT = BNW == 128 ? 2 : 1;    // 32-col x tiles per wave
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wn = wave >> 1, wc = wave & 1;
+  const int wn = BNW == 128 ? (wave >> 1) : 0;
+  const int wc = BNW == 128 ? (wave & 1) : wave;
+  const int nbase = wn * 64;                       // wave's first dy channel within the tile
+  const int cbase = wc * (BNW == 128 ? 64 : 32);   // wave's first column within the tile
 
   // block -> (split, tile_n, tile_c): tiles of one split adjacent (they re-read the same pixels)
   int bid = blockIdx.x;
@@ -64,8 +85,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
 
-  const int chunk = tid & 15;  // 16-byte chunk (8 channels) within the 128-channel tile row
-  const int prow = tid >> 4;   // pixel row 0..15 (+16 per pass)
+  const int chunk = tid & 15;  // x tile: 16-byte chunk (8 columns) within the 128-column row
+  const int prow = tid >> 4;   // x tile: pixel row 0..15 (+16 per pass)
+  const int ychunk = tid % CY;
+  const int yrow = tid / CY;
 
   // this thread's fixed column group of the x tile: tap + channel
   const int j0 = tile_c * WT + chunk * 8;
@@ -77,21 +100,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     tap_r = t / p.S;
     tap_s = t - tap_r * p.S;
   }
-  const int n0 = tile_n * WT + chunk * 8;
+  const int n0 = tile_n * BNW + ychunk * 8;
   const bool n_ok = n0 < p.Co;
 
   const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int steps = (m_end - m_begin + WPX - 1) / WPX;
 
-  u32x4 ry[4], rxv[4];
+  u32x4 ry[YP], rxv[4];
   auto load_tile = [&](int step) {
+#pragma unroll
+    for (int j = 0; j < YP; ++j) {
+      const int m = m_begin + step * WPX + yrow + YRP * j;
+      const unsigned offy = ((unsigned)m * (unsigned)p.ldy + (unsigned)n0) * 2u;
+      ry[j] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (m < m_end && n_ok) ? offy : ASM_OOB, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m_begin + step * WPX + prow + 16 * j;
       const bool mok = m < m_end;
-      const unsigned offy = ((unsigned)m * (unsigned)p.ldy + (unsigned)n0) * 2u;
-      ry[j] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (mok && n_ok) ? offy : ASM_OOB, 0, 0);
       const unsigned um = mok ? (unsigned)m : 0u;
       const unsigned img = fd_div(um, p.fd_howo);
       const unsigned rem = um - img * (unsigned)p.HoWo;
@@ -106,22 +133,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
   };
   auto store_tile = [&](int stage) {
-    unsigned char* ys = smem + stage * 2 * WTILE;
-    unsigned char* xs = ys + WTILE;
+    unsigned char* ys = smem + stage * STAGE;
+    unsigned char* xs = ys + YTILE;
+#pragma unroll
+    for (int j = 0; j < YP; ++j) {
+      const int row = yrow + YRP * j;
+      *reinterpret_cast<u32x4*>(ys + row * YROWB + ((ychunk ^ tr_swz<YROWB>(row)) << 4)) = ry[j];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = prow + 16 * j;
-      const int sc = (chunk ^ ((row & 3) << 2)) << 4;
-      *reinterpret_cast<u32x4*>(ys + row * WROWB + sc) = ry[j];
-      *reinterpret_cast<u32x4*>(xs + row * WROWB + sc) = rxv[j];
+      *reinterpret_cast<u32x4*>(xs + row * WROWB + ((chunk ^ tr_swz<WROWB>(row)) << 4)) = rxv[j];
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[NT][CT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < CT; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
@@ -136,38 +166,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const int g = lane >> 4;            // group 0..3
   const int colsel = (g & 1) * 16;    // which 16 of the fragment's 32 channels
   const int pgrp = (g >> 1) * 8;      // reduction offset 0 / 8
-  const int trow = t16 >> 2;          // pixel row within the 4-row block (== (row & 3))
+  const int trow = t16 >> 2;          // pixel row within the 4-row block
   const int tcol = (t16 & 3) * 4;     // channel offset of this lane's 4-element source
 
   for (int step = 0; step < steps; ++step) {
     const int cur = step & 1;
     if (step + 1 < steps) load_tile(step + 1);
-    const unsigned char* ys = smem + cur * 2 * WTILE;
-    const unsigned char* xs = ys + WTILE;
+    const unsigned char* ys = smem + cur * STAGE;
+    const unsigned char* xs = ys + YTILE;
 #pragma unroll
     for (int kk = 0; kk < WPX / 16; ++kk) {
-      bf16x8 fy[2], fx[2];
+      const int row = kk * 16 + pgrp + trow;
+      const int row2 = row + 4;
+      bf16x8 fy[NT], fx[CT];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int cy = wn * 64 + a * 32 + colsel + tcol;  // channel (element) index in the dy row
-        const int cx = wc * 64 + a * 32 + colsel + tcol;
-        bf16x4 y0, y1, x0, x1;
-        {
-          const int row = kk * 16 + pgrp + trow;
-          const int sw = (trow << 2);
-          y0 = ds_read_tr(ys + row * WROWB + ((((cy >> 3) ^ sw) << 4) | ((cy & 4) << 1)));
-          x0 = ds_read_tr(xs + row * WROWB + ((((cx >> 3) ^ sw) << 4) | ((cx & 4) << 1)));
-          const int row2 = row + 4;
-          y1 = ds_read_tr(ys + row2 * WROWB + ((((cy >> 3) ^ sw) << 4) | ((cy & 4) << 1)));
-          x1 = ds_read_tr(xs + row2 * WROWB + ((((cx >> 3) ^ sw) << 4) | ((cx & 4) << 1)));
-        }
+      for (int a = 0; a < NT; ++a) {
+        const int cy = nbase + a * 32 + colsel + tcol;  // channel (element) index in the dy row
+        const int o = ((cy & 4) << 1);
+        const bf16x4 y0 = ds_read_tr(ys + row * YROWB + ((((cy >> 3) ^ tr_swz<YROWB>(row)) << 4) | o));
+        const bf16x4 y1 = ds_read_tr(ys + row2 * YROWB + ((((cy >> 3) ^ tr_swz<YROWB>(row2)) << 4) | o));
         fy[a] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
-        fx[a] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < CT; ++b) {
+        const int cx = cbase + b * 32 + colsel + tcol;
+        const int o = ((cx & 4) << 1);
+        const bf16x4 x0 = ds_read_tr(xs + row * WROWB + ((((cx >> 3) ^ tr_swz<WROWB>(row)) << 4) | o));
+        const bf16x4 x1 = ds_read_tr(xs + row2 * WROWB + ((((cx >> 3) ^ tr_swz<WROWB>(row2)) << 4) | o));
+        fx[b] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
     }
     if (step + 1 < steps) store_tile(cur ^ 1);
@@ -178,14 +209,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   float* out = p.out + (size_t)split * p.Co * p.cols;
   const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int col = tile_c * WT + wc * 64 + b * 32 + l31;
+    for (int b = 0; b < CT; ++b) {
+      const int col = tile_c * WT + cbase + b * 32 + l31;
       if (col < p.cols) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int n = tile_n * WT + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const int n = tile_n * BNW + nbase + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           if (n < p.Co) out[(size_t)n * p.cols + col] = acc[a][b][r];
         }
       }
@@ -210,18 +241,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, fl
 }
 
 struct Plan {
-  int tiles_n, tiles_c, splits, m_per_split;
+  int bnw, tiles_n, tiles_c, splits, m_per_split;
 };
 
 Plan make_plan(const asm_conv_desc* d) {
   Plan pl;
   const int M = d->N * d->Ho * d->Wo;
   const int cols = d->R * d->S * d->C;
-  pl.tiles_n = cdiv(d->K, WT);
+  pl.bnw = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);
+  pl.tiles_n = cdiv(d->K, pl.bnw);
   pl.tiles_c = cdiv(cols, WT);
   const int tiles = pl.tiles_n * pl.tiles_c;
   const int msteps = cdiv(M, WPX);
-  int splits = cdiv(512, tiles);           // ~2 resident blocks per CU
+  int splits = cdiv(pl.bnw == 128 ? 512 : 768, tiles);   // ~2-3 resident blocks per CU
   splits = splits < 1 ? 1 : splits;
   const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;  // at least 4 steps per block
   if (splits > max_splits) splits = max_splits;
@@ -273,7 +305,10 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   a.fd_howo = make_fastdiv((unsigned)a.HoWo);
   a.fd_wo = make_fastdiv((unsigned)a.Wo);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(pl.tiles_n * pl.tiles_c * pl.splits), dim3(256), 0, st, a);
+  const dim3 grid(pl.tiles_n * pl.tiles_c * pl.splits), block(256);
+  if (pl.bnw == 128) hipLaunchKernelGGL(wgrad_kernel<128>, grid, block, 0, st, a);
+  else if (pl.bnw == 64) hipLaunchKernelGGL(wgrad_kernel<64>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(wgrad_kernel<32>, grid, block, 0, st, a);
   ASM_CHECK_LAUNCH("wgrad_kernel");
   if (pl.splits > 1) {
     const size_t n = (size_t)d->K * a.cols;

@@ -50,6 +50,7 @@ SIGNATURES = {
     'asm_stem_pad_input': (_I, [_P, _I, _P, _I, _I, _I, _P]),
     'asm_bn_stats_blocks': (_I, [_I, _I]),
     'asm_bn_stats': (_I, [_P, _I, _I, _P, _P]),
+    'asm_bn_partials_compact': (_I, [_P, _I, _I, _P, _I, _P]),
     'asm_bn_finalize': (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     'asm_bn_infer_coeffs': (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     'asm_bn_apply': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),

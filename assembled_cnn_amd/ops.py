@@ -203,8 +203,21 @@ def bn_stats(x2d: torch.Tensor, M: int, Cn: int) -> torch.Tensor:
   return part
 
 
+def _compact(part: torch.Tensor, Cn: int) -> torch.Tensor:
+  """Thousands of partial rows (conv epilogue at high resolution) -> <= 32 rows, fully parallel."""
+  blocks = part.shape[0]
+  if blocks <= 64:
+    return part
+  per = -(-blocks // 32)
+  groups = -(-blocks // per)
+  out = empty((groups, 2, Cn), F32, part)
+  check(L().asm_bn_partials_compact(_ptr(part), blocks, Cn, _ptr(out), groups, _stream()), 'bn_partials_compact')
+  return out
+
+
 def bn_finalize(part, M, Cn, gamma, beta, eps, momentum, mm, mv):
   """-> mean, invstd, scale, shift (each [C] f32); updates moving stats in place when given."""
+  part = _compact(part, Cn)
   co = empty((4, Cn), F32, part)
   check(L().asm_bn_finalize(_ptr(part), part.shape[0], M, Cn, _ptr(gamma), _ptr(beta), eps, momentum,
                             _ptr(mm), _ptr(mv), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _ptr(co[3]),
@@ -232,6 +245,8 @@ def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz
   part = empty((blocks, 2, Cn), F32, dy)
   check(L().asm_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(yout if relu else None), 1 if relu else 0, M, Cn,
                               _ptr(mean), _ptr(invstd), _ptr(part), _stream()), 'bn_bwd_reduce')
+  part = _compact(part, Cn)
+  blocks = part.shape[0]
   co = empty((3, Cn), F32, dy)
   check(L().asm_bn_bwd_finalize(_ptr(part), blocks, M, Cn, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma),
                                 _ptr(dbeta), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _stream()), 'bn_bwd_finalize')

@@ -113,6 +113,9 @@ int asm_stem_pad_input(const void* x, int x_is_f32, void* xp, int N, int H, int 
 int asm_bn_stats_blocks(int M, int C);
 /* stand-alone partial statistics (same [blocks][2][C] layout as the conv epilogue) */
 int asm_bn_stats(const void* x, int M, int C, float* stats_partial, void* stream);
+/* [blocks][2][C] partials -> [groups][2][C] (group g sums blocks [g*ceil(blocks/groups), ...)); groups must
+ * equal ceil(blocks / ceil(blocks/groups)).  Used before the finalize kernels when blocks is large. */
+int asm_bn_partials_compact(const float* partial, int blocks, int C, float* out, int groups, void* stream);
 /* partials -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; moving stats update
  * m <- m*momentum + (1-momentum)*batch  (variance Bessel-corrected for the moving average). */
 int asm_bn_finalize(const float* stats_partial, int blocks, int M, int C, const float* gamma,

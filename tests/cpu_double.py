@@ -188,6 +188,15 @@ class CpuDouble(object):
       st[b, 1] = (blk * blk).sum(0)
     return 0
 
+  def asm_bn_partials_compact(self, part, blocks, Cn, out, groups, stream):
+    per = -(-blocks // groups)
+    assert -(-blocks // per) == groups
+    src = T(part, (blocks, 2, Cn), 'f32')
+    dst = T(out, (groups, 2, Cn), 'f32')
+    for g in range(groups):
+      dst[g] = src[g * per:(g + 1) * per].double().sum(0).float()
+    return 0
+
   def asm_bn_finalize(self, part, blocks, M, Cn, gamma, beta, eps, momentum, mm, mv, mean, invstd, scale, shift,
                       stream):
     st = T(part, (blocks, 2, Cn), 'f32').double().sum(0)

@@ -1,0 +1,93 @@
+"""Data-parallel path on CPU: world_size 2 over gloo, host code driven through the C-ABI test double.
+
+Invariants: after a DP step every replica holds identical weights; the exchanged gradient
+is the SUM over replicas of the per-shard gradients (BN statistics stay per replica), divided by the
+number of replicas inside the optimiser; buckets are launched by the backward watermark."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _worker(rank, world, port, out_dir):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  torch.set_num_threads(2)
+  from assembled_cnn_amd import dp, ops
+  from assembled_cnn_amd.train import HParams, Trainer
+  from tests.cpu_double import CpuDouble
+  from tests import model_parity as mpar
+  ops.set_library(CpuDouble(), is_double=True)
+  dp.init_process_group_from_env('gloo')
+  hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
+               zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01, weight_decay=1e-4,
+               batch_size=2 * world)
+  B, S = 2, 64
+  img, _, labels = mpar.inputs(B * world, S)
+
+  # reference: per-shard gradients computed locally, without any exchange
+  ref = Trainer(hp, seed=0, device='cpu')
+  ref.model.build((S, S))
+  shard_grads = []
+  for r in range(world):
+    x, onehot, _ = ref.prepare_inputs(img[r * B:(r + 1) * B], labels[r * B:(r + 1) * B])
+    ref.model(x, True, prepadded=True)
+    rows, dz = ops.softmax_ce(ref.model.logits_padded, ref.model.ldc, onehot, None, B, 1001, 0.0, 0.0, 1.0,
+                              ref.model.ldc)
+    ref.model.backward(dz)
+    shard_grads.append(ref.model.arena.g32.clone())
+  w0 = ref.model.arena.w32.clone()
+
+  tr = Trainer(hp, seed=0, device='cpu', world_size=world)
+  tr.model.build((S, S))
+  sync = dp.GradSync(tr.model.arena, bucket_bytes=8 << 20)
+  launched = []
+  orig = sync._launch
+  sync._launch = lambda s, i: (launched.append((s, i, len(tr.model._ctx.tape) if tr.model._ctx else -1)), orig(s, i))[1]
+  tr.grad_sync = sync
+  assert torch.equal(tr.model.arena.w32, w0)
+  tr.train_step(img[rank * B:(rank + 1) * B], labels[rank * B:(rank + 1) * B])
+
+  g_sum = shard_grads[0] + shard_grads[1]
+  assert torch.equal(tr.model.arena.g32, g_sum), 'exchanged gradient must be the SUM of the shard gradients'
+  assert len(launched) == sum(len(b) for b in sync.segments) and len(sync.segments[0]) >= 4
+  # identical weights on every replica
+  gathered = [torch.empty_like(tr.model.arena.w32) for _ in range(world)]
+  dist.all_gather(gathered, tr.model.arena.w32)
+  assert torch.equal(gathered[0], gathered[1])
+  # and they equal one momentum-SGD step on the mean gradient
+  nd = tr.model.arena.decay_elems
+  g = g_sum / world
+  exp = w0.clone()
+  exp[:nd] -= 0.01 * (g[:nd] + 1e-4 * w0[:nd])
+  exp[nd:] -= 0.01 * g[nd:]
+  assert torch.allclose(tr.model.arena.w32, exp, rtol=1e-5, atol=1e-7)
+  if rank == 0:
+    open(os.path.join(out_dir, 'ok'), 'w').write('%d buckets' % len(launched))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_dp_world2_gloo(tmp_path):
+  port = _free_port()
+  mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  assert (tmp_path / 'ok').exists()
+
+
+def test_per_device_batch_size():
+  """official/utils/misc/distribution_utils_test.py:54-64."""
+  from assembled_cnn_amd.dp import per_device_batch_size
+  assert per_device_batch_size(147, 7) == 21
+  assert per_device_batch_size(32, 1) == 32 and per_device_batch_size(32, 0) == 32
+  with pytest.raises(ValueError):
+    per_device_batch_size(147, 5)
