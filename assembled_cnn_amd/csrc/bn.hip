@@ -20,7 +20,7 @@ RowTiling make_tiling(int M, int C) {
   t.vcols = C / 8;
   t.vcb = t.vcols < 256 ? t.vcols : 256;
   t.rpb = 256 / t.vcb;
-  int rows = cdiv(M, 2048);
+  int rows = cdiv(M, 512);   // <= 512 partial rows: the finalize kernels read them without a compaction pass
   rows = cdiv(rows, t.rpb) * t.rpb;
   if (rows < t.rpb * 4) rows = t.rpb * 4;
   t.rows_per_block = rows;
@@ -58,32 +58,52 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
           is[e] = invstd[vc * 8 + e];
         }
       }
-      for (int row = row_begin + rr; row < row_end; row += t.rpb) {
-        const size_t off = (size_t)row * C + vc * 8;
-        const u32x4 va = *reinterpret_cast<const u32x4*>(a + off);
-        float fa[8];
-        unpack8(va, fa);
-        if (MODE == 0) {
+      // 4 rows per trip: all loads of a trip are issued before any is consumed (the reduction is
+      // bandwidth-bound only if enough bytes are in flight per CU)
+      constexpr int U = 4;
+      for (int row = row_begin + rr; row < row_end; row += U * t.rpb) {
+        u32x4 va[U], vb[U], vy[U];
+        unsigned mk[U];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s[e] += fa[e];
-            ss[e] += fa[e] * fa[e];
+        for (int u = 0; u < U; ++u) {
+          const int r = row + u * t.rpb;
+          const bool ok = r < row_end;
+          const size_t off = (size_t)(ok ? r : row) * C + vc * 8;
+          va[u] = *reinterpret_cast<const u32x4*>(a + off);
+          if (MODE == 1) {
+            vb[u] = *reinterpret_cast<const u32x4*>(b + off);
+            if (relu == 1) vy[u] = *reinterpret_cast<const u32x4*>(c + off);
+            if (relu == 2) mk[u] = reinterpret_cast<const uint8_t*>(c)[(size_t)(ok ? r : row) * t.vcols + vc];
           }
-        } else {
-          const u32x4 vb = *reinterpret_cast<const u32x4*>(b + off);
-          float fb[8];
-          unpack8(vb, fb);
-          if (relu) {
-            const u32x4 vy = *reinterpret_cast<const u32x4*>(c + off);
-            float fy[8];
-            unpack8(vy, fy);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fa[e] = fy[e] > 0.f ? fa[e] : 0.f;
-          }
+        for (int u = 0; u < U; ++u) {
+          if (row + u * t.rpb >= row_end) break;
+          float fa[8];
+          unpack8(va[u], fa);
+          if (MODE == 0) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s[e] += fa[e];
-            ss[e] += fa[e] * ((fb[e] - mu[e]) * is[e]);
+            for (int e = 0; e < 8; ++e) {
+              s[e] += fa[e];
+              ss[e] += fa[e] * fa[e];
+            }
+          } else {
+            float fb[8];
+            unpack8(vb[u], fb);
+            if (relu == 1) {
+              float fy[8];
+              unpack8(vy[u], fy);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) fa[e] = fy[e] > 0.f ? fa[e] : 0.f;
+            } else if (relu == 2) {  // packed ReLU mask: one byte per 8-channel vector
+#pragma unroll
+              for (int e = 0; e < 8; ++e) fa[e] = ((mk[u] >> e) & 1u) ? fa[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              s[e] += fa[e];
+              ss[e] += fa[e] * ((fb[e] - mu[e]) * is[e]);
+            }
           }
         }
       }
@@ -115,11 +135,22 @@ __device__ __forceinline__ void sum_partials(const float* partial, int blocks, i
                                              double& s0, double& s1) {
   s0 = 0.0;
   s1 = 0.0;
-  if (ch < C)
-    for (int b = ry; b < blocks; b += 16) {
-      s0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
-      s1 += (double)partial[((size_t)b * 2 + 1) * C + ch];
+  if (ch < C) {
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    int b = ry;
+    for (; b + 16 < blocks; b += 32) {   // two independent chains: loads overlap
+      a0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
+      b0 += (double)partial[((size_t)b * 2 + 1) * C + ch];
+      a1 += (double)partial[((size_t)(b + 16) * 2 + 0) * C + ch];
+      b1 += (double)partial[((size_t)(b + 16) * 2 + 1) * C + ch];
     }
+    if (b < blocks) {
+      a0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
+      b0 += (double)partial[((size_t)b * 2 + 1) * C + ch];
+    }
+    s0 = a0 + a1;
+    s1 = b0 + b1;
+  }
 }
 
 // partial compaction: [blocks][2][C] -> [groups][2][C]; each output group sums a contiguous range of
@@ -234,7 +265,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const bf16_t* __restrict__ res, FastDiv fd_w, FastDiv fd_h,
-                                                       int H, int W) {
+                                                       int H, int W, uint8_t* __restrict__ mask) {
   const int vcols = C >> 3;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const unsigned m = fd_div((unsigned)i, fd_vcols);
@@ -269,6 +300,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
       for (int e = 0; e < 8; ++e) f[e] += r[e];
     }
     if (RELU) {
+      if (mask) {
+        unsigned mk = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mk |= (f[e] > 0.f ? 1u : 0u) << e;
+        mask[i] = (uint8_t)mk;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
     }
@@ -277,7 +314,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
 }
 
 // ---- backward apply: dx = A*dz + B*x + C ; dz = dy * [yout > 0] -----------------------------------
-template <bool RELU, bool WRITE_DZ>
+template <int RELU, bool WRITE_DZ>  // RELU: 0 none, 1 mask from the bf16 forward output, 2 packed bitmask
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                            const bf16_t* __restrict__ yout, size_t nvec, int C,
                                                            FastDiv fd_vcols, const float* __restrict__ cA,
@@ -291,11 +328,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     float g[8], fx[8];
     unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
     unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), fx);
-    if (RELU) {
+    if (RELU == 1) {
       float fy[8];
       unpack8(*reinterpret_cast<const u32x4*>(yout + i * 8), fy);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = fy[e] > 0.f ? g[e] : 0.f;
+    } else if (RELU == 2) {
+      const unsigned mk = reinterpret_cast<const uint8_t*>(yout)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
     }
     if (WRITE_DZ) *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(g);
     float o[8];
@@ -363,7 +404,8 @@ extern "C" int asm_bn_infer_coeffs(int C, const float* gamma, const float* beta,
 }
 
 extern "C" int asm_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift,
-                            const void* residual, int res_mode, int relu, int H, int W, void* stream) {
+                            const void* residual, int res_mode, int relu, int H, int W, uint8_t* relu_mask_out,
+                            void* stream) {
   ASM_REQUIRE(x && y && scale && shift && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
   ASM_REQUIRE(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bn_apply: bad residual mode");
   ASM_REQUIRE((size_t)M * (C / 8) < 0x7fffffffull, "bn_apply: tensor too large");
@@ -376,7 +418,7 @@ extern "C" int asm_bn_apply(const void* x, void* y, int M, int C, const float* s
   const dim3 grid(ew_grid(nvec)), block(256);
 #define LAUNCH_APPLY(RES, RELU)                                                                          \
   hipLaunchKernelGGL((bn_apply_kernel<RES, RELU>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, nvec, C, fv, \
-                     scale, shift, (const bf16_t*)residual, fw, fh, H, W)
+                     scale, shift, (const bf16_t*)residual, fw, fh, H, W, relu_mask_out)
   if (res_mode == 0) { if (relu) LAUNCH_APPLY(0, true); else LAUNCH_APPLY(0, false); }
   else if (res_mode == 1) { if (relu) LAUNCH_APPLY(1, true); else LAUNCH_APPLY(1, false); }
   else { if (relu) LAUNCH_APPLY(2, true); else LAUNCH_APPLY(2, false); }
@@ -388,7 +430,7 @@ extern "C" int asm_bn_apply(const void* x, void* y, int M, int C, const float* s
 extern "C" int asm_bn_bwd_reduce(const void* dy, const void* x, const void* yout, int relu, int M, int C,
                                  const float* mean, const float* invstd, float* partial, void* stream) {
   ASM_REQUIRE(dy && x && mean && invstd && partial && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
-  ASM_REQUIRE(!relu || yout, "bn_bwd_reduce: relu mask needs the forward output");
+  ASM_REQUIRE(relu >= 0 && relu <= 2 && (!relu || yout), "bn_bwd_reduce: relu mask needs the forward output / bitmask");
   RowTiling t = make_tiling(M, C);
   hipLaunchKernelGGL((rowreduce_kernel<1>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (const bf16_t*)x, (const bf16_t*)yout, relu, M, C, mean, invstd, t, partial);
@@ -411,7 +453,7 @@ extern "C" int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout,
                                 const float* coefA, const float* coefB, const float* coefC, void* dx,
                                 void* dz_out, void* stream) {
   ASM_REQUIRE(dy && x && dx && coefA && coefB && coefC && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad arguments");
-  ASM_REQUIRE(!relu || yout, "bn_bwd_apply: relu mask needs the forward output");
+  ASM_REQUIRE(relu >= 0 && relu <= 2 && (!relu || yout), "bn_bwd_apply: relu mask needs the forward output / bitmask");
   ASM_REQUIRE((size_t)M * (C / 8) < 0x7fffffffull, "bn_bwd_apply: tensor too large");
   const size_t nvec = (size_t)M * (C / 8);
   const FastDiv fv = make_fastdiv((unsigned)(C / 8));
@@ -420,8 +462,9 @@ extern "C" int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout,
 #define LAUNCH_BWD(RELU, DZ)                                                                              \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<RELU, DZ>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, \
                      (const bf16_t*)yout, nvec, C, fv, coefA, coefB, coefC, (bf16_t*)dx, (bf16_t*)dz_out)
-  if (relu) { if (dz_out) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
-  else { if (dz_out) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
+  if (relu == 1) { if (dz_out) LAUNCH_BWD(1, true); else LAUNCH_BWD(1, false); }
+  else if (relu == 2) { if (dz_out) LAUNCH_BWD(2, true); else LAUNCH_BWD(2, false); }
+  else { if (dz_out) LAUNCH_BWD(0, true); else LAUNCH_BWD(0, false); }
 #undef LAUNCH_BWD
   ASM_CHECK_LAUNCH("bn_bwd_apply");
   return ASM_OK;

@@ -24,6 +24,7 @@ struct IGemmArgs {
   const void* x;
   const void* w;
   void* y;
+  const void* addend;  // optional bf16 [M][ldy] added to the result (gradient accumulation, dgrad)
   float* stats;
   unsigned x_bytes, w_bytes;
   int M;           // number of output rows
@@ -38,8 +39,10 @@ struct IGemmArgs {
   int n_tiles_n, n_blocks, kchunks;
 };
 
-constexpr int BM = 128;
-constexpr int LDS_BYTES = 65536;
+// 16 zero bytes: the source of every masked lane of an LDS-DMA load (global_load_lds has no bounds check)
+__device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+constexpr int STATS_BM = 128;  // rows per statistics partial (asm_conv2d_stats_blocks)
 
 template <int BK>
 __device__ __forceinline__ int swz(int row) {
@@ -48,30 +51,50 @@ __device__ __forceinline__ int swz(int row) {
   return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-template <int BN, int BK, bool OUT_F32, bool STATS>
-__global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
-  constexpr int CPR = BK / 8;           // 16-byte chunks per tile row
-  constexpr int RPP = 256 / CPR;        // rows staged per pass by the 256 threads
-  constexpr int XP = BM / RPP;          // passes for the activation tile
-  constexpr int WP = BN / RPP;          // passes for the filter tile
-  constexpr int ROWB = BK * 2;          // bytes per tile row
-  constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int TN = BN / 64;           // 32-wide filter tiles per wave
-  constexpr int TM = 2;                 // 32-wide pixel tiles per wave
-  // LDS is sized per instantiation (main-loop double buffer vs the epilogue's output tile) so that
-  // the small-tile variants run 3-6 workgroups per CU: the short-K layers are latency-bound and
-  // need the extra waves to hide the global-load round trip of every K-step.
-  constexpr int LDO = BN * 2 + 16;  // padded output-tile row (bytes)
-  constexpr int EPI = OUT_F32 ? 0 : BM * LDO;
-  constexpr int LDS = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
-  static_assert(LDS <= LDS_BYTES, "lds");
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
+// Tile configuration: BM x BN x BK block tile, WGM x WGN waves, each wave (BM/WGM) x (BN/WGN) as
+// 32x32 MFMA tiles.  Arithmetic intensity against the L2->LDS path is 2*BM*BN/((BM+BN)*2) FLOP/B:
+// 64 for 128x128, 85 for 256x128, 128 for 256x256 -- the MFMA-bound layers need the big tiles, the
+// HBM-bound ones the small footprints (more workgroups per CU).
+// MODE: 0 = register-staged, 1-deep prefetch; 1 = register-staged, 2-deep prefetch (two register tile sets);
+//       2 = LDS-DMA staging (global_load_lds_dwordx4: no VGPR round trip, no ds_write), 1-deep.
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE>
+struct Cfg {
+  static constexpr int NT = 64 * WGM * WGN;
+  static constexpr int CPR = BK / 8;            // 16-byte chunks per tile row
+  static constexpr int RPP = NT / CPR;          // rows staged per pass
+  static constexpr int XP = BM / RPP;           // passes for the activation tile
+  static constexpr int WP = cmax(1, BN / RPP);  // passes for the filter tile
+  static constexpr int ROWB = BK * 2;
+  static constexpr int STAGE = (BM + BN) * ROWB;
+  static constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  static constexpr int TM = WTM / 32, TN = WTN / 32;
+  static constexpr int LDO = BN * 2 + 16;       // padded output-tile row (bytes)
+  static constexpr int CPO = BN / 8;            // 16-byte chunks per output row
+  static constexpr int RPO = NT / CPO;          // output rows per pass
+  static constexpr int OP = BM / RPO;
+  static constexpr int EPI = OUT_F32 ? 0 : BM * LDO;
+  static constexpr int RED = STATS ? RPO * BN * 2 * 4 : 0;
+  static constexpr int LDS = cmax(cmax(2 * STAGE, EPI), RED);
+  static_assert(BM % RPP == 0 && (BN % RPP == 0 || BN < RPP), "loader tiling");
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPO == 0, "wave tiling");
+  static_assert(LDS <= 160 * 1024, "lds");
+  static_assert(!STATS || BM % STATS_BM == 0, "stats granularity");
+};
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE>
+__global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
+  using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE>;
+  constexpr int NT = C::NT, CPR = C::CPR, RPP = C::RPP, XP = C::XP, WP = C::WP, ROWB = C::ROWB, STAGE = C::STAGE;
+  constexpr int TM = C::TM, TN = C::TN, WTM = C::WTM, WTN = C::WTN;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
 
   // XCD-aware bijective remap: each XCD (bid % 8) gets a contiguous range of logical tiles, and
   // the N-tiles of one M-tile are adjacent, so the activation tile is re-read from that XCD's L2.
@@ -110,18 +133,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
     }
   }
   int wb[WP];
+  bool wrow_ok[WP];
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
-    const int n = tile_n * BN + r0 + j * RPP;
-    wb[j] = (n < p.Co) ? n * p.w_row_pitch : -1;
+    const int row = r0 + j * RPP;
+    const int n = tile_n * BN + row;
+    wrow_ok[j] = row < BN;
+    wb[j] = (wrow_ok[j] && n < p.Co) ? n * p.w_row_pitch : -1;
   }
 
-  u32x4 xr[XP], wr[WP];
+  // Register tile sets.  DEEP: while tile kt is consumed from LDS, tile kt+1 sits in one set (being
+  // written to the other LDS stage) and the loads of tile kt+2 are already in flight in the other set.
+  constexpr bool DEEP = MODE == 1;
+  u32x4 xa[XP], wa[WP], xb2[DEEP ? XP : 1], wb2[DEEP ? WP : 1];
   int kt_r = 0, kt_s = 0, kt_c = 0;  // tap / channel-chunk cursor of the NEXT tile to load
 
-  auto load_tile = [&]() {
+  auto load_tile = [&](u32x4* xr, u32x4* wr, bool live) {
     const int c = kt_c * BK + chunk * 8;
-    const bool cok = c < p.Ci;
+    const bool cok = live && c < p.Ci;
     const int th = p.tsign * kt_r, tw = p.tsign * kt_s;
 #pragma unroll
     for (int j = 0; j < XP; ++j) {
@@ -154,7 +183,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
     }
   };
 
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage, const u32x4* xr, const u32x4* wr) {
     unsigned char* xs = smem + stage * STAGE;
     unsigned char* ws = xs + BM * ROWB;
 #pragma unroll
@@ -165,7 +194,58 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
 #pragma unroll
     for (int j = 0; j < WP; ++j) {
       const int row = r0 + j * RPP;
-      *reinterpret_cast<u32x4*>(ws + row * ROWB + ((chunk ^ swz<BK>(row)) << 4)) = wr[j];
+      if (wrow_ok[j]) *reinterpret_cast<u32x4*>(ws + row * ROWB + ((chunk ^ swz<BK>(row)) << 4)) = wr[j];
+    }
+  };
+
+  // LDS-DMA staging: the thread -> (row, chunk) map above is already lane-linear per wave and pass (a wave
+  // covers 64/CPR whole rows = 1 KiB), which is what global_load_lds requires of its destination; the XOR
+  // swizzle therefore moves to the SOURCE side: the lane sitting at LDS chunk position `chunk` of row r fetches
+  // global chunk (chunk ^ swz(r)).  Masked lanes read 16 zero bytes.
+  auto issue_tile = [&](int stage, bool live) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    unsigned char* xs = smem + stage * STAGE;
+    unsigned char* ws = xs + BM * ROWB;
+    const int th = p.tsign * kt_r, tw = p.tsign * kt_s;
+    const int wrow0 = (tid >> 6) * (64 / CPR);
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int row = r0 + j * RPP;
+      const int c = kt_c * BK + ((chunk ^ swz<BK>(row)) << 3);
+      int nh = bh[j] + th, nw = bw[j] + tw;
+      bool ok = live && c < p.Ci;
+      if (p.sd == 2) {
+        ok = ok && (((nh | nw) & 1) == 0);
+        nh >>= 1;
+        nw >>= 1;
+      }
+      ok = ok && ((unsigned)nh < (unsigned)p.Hi) && ((unsigned)nw < (unsigned)p.Wi);
+      const unsigned off = ((unsigned)xb[j] + (unsigned)nh * (unsigned)p.x_row_pitch +
+                            (unsigned)nw * (unsigned)p.x_pix_pitch + (unsigned)c) * 2u;
+      const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(p.x) + off
+                                    : reinterpret_cast<const unsigned char*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + (j * RPP + wrow0) * ROWB), 16, 0, 0);
+    }
+    const int tap0 = (kt_r * p.S + kt_s) * p.Ci + kt_c * BK;
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const int row = r0 + j * RPP;
+      if (j * RPP + wrow0 < BN) {  // wave-uniform: rows past the filter tile are never written
+        const int c = ((chunk ^ swz<BK>(row)) << 3);
+        const bool ok = live && (kt_c * BK + c < p.Ci) && (wb[j] >= 0);
+        const unsigned off = (unsigned)(wb[j] + tap0 + c) * 2u;
+        const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(p.w) + off
+                                      : reinterpret_cast<const unsigned char*>(g_zero16);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + (j * RPP + wrow0) * ROWB), 16, 0, 0);
+      }
+    }
+    if (++kt_c == p.kchunks) {
+      kt_c = 0;
+      if (++kt_s == p.S) {
+        kt_s = 0;
+        ++kt_r;
+      }
     }
   };
 
@@ -178,17 +258,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
   const int KT = p.R * p.S * p.kchunks;
-
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-
   const int l31 = lane & 31, lhi = lane >> 5;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) load_tile();
 
-    const unsigned char* xs = smem + cur * STAGE;
+  auto compute = [&](int stage) {
+    const unsigned char* xs = smem + stage * STAGE;
     const unsigned char* ws = xs + BM * ROWB;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -196,12 +269,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
       bf16x8 fw[TN], fx[TM];
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
-        const int row = wn * (BN / 2) + a * 32 + l31;
+        const int row = wn * WTN + a * 32 + l31;
         fw[a] = *reinterpret_cast<const bf16x8*>(ws + row * ROWB + ((ch ^ swz<BK>(row)) << 4));
       }
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int row = wm * 64 + b * 32 + l31;
+        const int row = wm * WTM + b * 32 + l31;
         fx[b] = *reinterpret_cast<const bf16x8*>(xs + row * ROWB + ((ch ^ swz<BK>(row)) << 4));
       }
 #pragma unroll
@@ -210,13 +283,56 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
         for (int b = 0; b < TM; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a], fx[b], acc[a][b], 0, 0, 0);
     }
+  };
 
-    if (kt + 1 < KT) store_tile(cur ^ 1);
+  if constexpr (MODE == 2) {
+    issue_tile(0, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < KT) issue_tile(cur ^ 1, true);   // DMA of tile kt+1 runs under the MFMAs of tile kt
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else if constexpr (DEEP) {
+    load_tile(xa, wa, true);              // tile 0
+    store_tile(0, xa, wa);
+    load_tile(xa, wa, KT > 1);            // tile 1 in flight in set A (zeros if there is none)
+    __syncthreads();
+    // With an odd KT the last odd step multiplies a zero tile (its loads are predicated off), which keeps
+    // the loop body branch-free around the MFMA blocks.
+#pragma unroll 1
+    for (int kt = 0; kt < KT; kt += 2) {
+      // even step: LDS stage 0 holds tile kt, set A holds tile kt+1
+      load_tile(xb2, wb2, kt + 2 < KT);                // tile kt+2 -> set B
+      compute(0);
+      store_tile(1, xa, wa);                           // waits only for set A (loads retire in order)
+      __syncthreads();
+      // odd step: LDS stage 1 holds tile kt+1 (zeros past the end), set B holds tile kt+2
+      load_tile(xa, wa, kt + 3 < KT);                  // tile kt+3 -> set A
+      compute(1);
+      store_tile(0, xb2, wb2);
+      __syncthreads();
+    }
+  } else {
+    load_tile(xa, wa, true);
+    store_tile(0, xa, wa);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1;
+      load_tile(xa, wa, kt + 1 < KT);
+      compute(cur);
+      store_tile(cur ^ 1, xa, wa);
+      __syncthreads();
+    }
   }
 
   // ---------------- epilogue ----------------
-  // acc[a][b][reg]: n_local = wn*(BN/2) + a*32 + (reg&3) + 8*(reg>>2) + 4*lhi ; m_local = wm*64 + b*32 + l31
+  // acc[a][b][reg]: n_local = wn*WTN + a*32 + (reg&3) + 8*(reg>>2) + 4*lhi ; m_local = wm*WTM + b*32 + l31
   if constexpr (OUT_F32) {
     float* y = reinterpret_cast<float*>(p.y);
     const int co4 = (p.Co + 3) & ~3;
@@ -224,11 +340,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int m = tile_m * BM + wm * 64 + b * 32 + l31;
+        const int m = tile_m * BM + wm * WTM + b * 32 + l31;
         if (m < p.M) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int n = tile_n * BN + wn * (BN / 2) + a * 32 + 8 * g + 4 * lhi;
+            const int n = tile_n * BN + wn * WTN + a * 32 + 8 * g + 4 * lhi;
             if (n < co4) {
               f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
               *reinterpret_cast<f32x4*>(y + (size_t)m * p.ldy + n) = v;
@@ -237,19 +353,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
         }
       }
   } else {
-    constexpr int CPO = BN / 8;       // 16-byte chunks per output row
-    constexpr int RPO = 256 / CPO;    // rows per pass
-    constexpr int OP = BM / RPO;      // passes
-    static_assert(RPO * BN * 2 * 4 <= BM * LDO, "stats scratch aliases the output tile");
+    constexpr int LDO = C::LDO, CPO = C::CPO, RPO = C::RPO, OP = C::OP;
     unsigned char* os = smem;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int ml = wm * 64 + b * 32 + l31;
+        const int ml = wm * WTM + b * 32 + l31;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int nl = wn * (BN / 2) + a * 32 + 8 * g + 4 * lhi;
+          const int nl = wn * WTN + a * 32 + 8 * g + 4 * lhi;
           u32x2 v;
           v.x = pack2bf(acc[a][b][4 * g], acc[a][b][4 * g + 1]);
           v.y = pack2bf(acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
@@ -261,71 +374,129 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs p) {
     const int oc = tid % CPO, orow = tid / CPO;
     const int n0 = tile_n * BN + oc * 8;
     const int co8 = (p.Co + 7) & ~7;
-    float s[8], ss[8];
+    // statistics partials are per STATS_BM (=128) rows: a 256-row tile emits two of them
+    constexpr int SG = STATS ? BM / STATS_BM : 1;
+    float s[SG][8], ss[SG][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    for (int q = 0; q < SG; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[q][e] = ss[q][e] = 0.f;
 #pragma unroll
     for (int ps = 0; ps < OP; ++ps) {
       const int row = ps * RPO + orow;
       const int m = tile_m * BM + row;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
-      if (m < p.M && n0 < co8) *reinterpret_cast<u32x4*>(y + (size_t)m * p.ldy + n0) = v;
+      u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
+      if (m < p.M && n0 < co8) {
+        if (p.addend) {
+          const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) +
+                                                           (size_t)m * p.ldy + n0);
+          float fv[8], fa[8];
+          unpack8(v, fv);
+          unpack8(av, fa);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += fa[e];
+          v = pack8(fv);
+        }
+        *reinterpret_cast<u32x4*>(y + (size_t)m * p.ldy + n0) = v;
+      }
       if constexpr (STATS) {
+        constexpr int PPG = OP / SG;   // passes per statistics group (rows are pass-major)
         float f[8];
         unpack8(v, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          s[e] += f[e];
-          ss[e] += f[e] * f[e];
+          s[ps / PPG][e] += f[e];
+          ss[ps / PPG][e] += f[e] * f[e];
         }
       }
     }
     if constexpr (STATS) {
       float* red = reinterpret_cast<float*>(smem);  // [RPO][2][BN], aliases the (now consumed) output tile
-      __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[(orow * 2 + 0) * BN + oc * 8 + e] = s[e];
-        red[(orow * 2 + 1) * BN + oc * 8 + e] = ss[e];
-      }
-      __syncthreads();
-      if (tid < 2 * BN) {
-        const int which = tid / BN, nl = tid - which * BN;
-        float t = 0.f;
+      for (int q = 0; q < SG; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[(orow * 2 + 0) * BN + oc * 8 + e] = s[q][e];
+          red[(orow * 2 + 1) * BN + oc * 8 + e] = ss[q][e];
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+          const int which = tid / BN, nl = tid - which * BN;
+          float t = 0.f;
 #pragma unroll 8
-        for (int g = 0; g < RPO; ++g) t += red[(g * 2 + which) * BN + nl];
-        const int n = tile_n * BN + nl;
-        if (n < p.Co) p.stats[((size_t)tile_m * 2 + which) * p.Co + n] = t;
+          for (int g = 0; g < RPO; ++g) t += red[(g * 2 + which) * BN + nl];
+          const int n = tile_n * BN + nl;
+          const int mb = tile_m * SG + q;   // 128-row statistics block index
+          if (n < p.Co && mb * STATS_BM < p.M) p.stats[((size_t)mb * 2 + which) * p.Co + n] = t;
+        }
       }
     }
   }
 }
 
-template <int BN, int BK>
-int launch_cfg(const IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
-  dim3 grid(a.n_blocks), block(256);
-  if (out_f32)
-    hipLaunchKernelGGL((igemm_kernel<BN, BK, true, false>), grid, block, 0, st, a);
-  else if (stats)
-    hipLaunchKernelGGL((igemm_kernel<BN, BK, false, true>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((igemm_kernel<BN, BK, false, false>), grid, block, 0, st, a);
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE>
+int launch_one(const IGemmArgs& a, hipStream_t st) {
+  using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE>;
+  auto kern = igemm_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in (idempotent; benign race)
+    if (C::LDS > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(C::NT), C::LDS, st, a);
   ASM_CHECK_LAUNCH("igemm_kernel");
   return ASM_OK;
 }
 
-int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
-  const int bn = (a.Co <= 64) ? 64 : 128;
-  // BK=64 halves the barrier count for the MFMA-heavy 3x3 / 7x7 layers; the 1x1 layers are HBM-bound
-  // with very short K loops, where the smaller BK=32 footprint (3-6 workgroups per CU) hides latency better
-  const int bk = (a.Ci % 64 == 0 && a.R * a.S > 1) ? 64 : 32;
-  a.n_tiles_n = cdiv(a.Co, bn);
+template <int BM, int BN, int BK, int WGM, int WGN, int MODE>
+int launch_mode(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
+  a.n_tiles_n = cdiv(a.Co, BN);
   a.n_blocks = cdiv(a.M, BM) * a.n_tiles_n;
-  a.kchunks = cdiv(a.Ci, bk);
-  if (bn == 64 && bk == 64) return launch_cfg<64, 64>(a, out_f32, stats, st);
-  if (bn == 64 && bk == 32) return launch_cfg<64, 32>(a, out_f32, stats, st);
-  if (bn == 128 && bk == 64) return launch_cfg<128, 64>(a, out_f32, stats, st);
-  return launch_cfg<128, 32>(a, out_f32, stats, st);
+  a.kchunks = cdiv(a.Ci, BK);
+  if (out_f32) return launch_one<BM, BN, BK, WGM, WGN, true, false, MODE>(a, st);
+  if (stats) return launch_one<BM, BN, BK, WGM, WGN, false, true, MODE>(a, st);
+  return launch_one<BM, BN, BK, WGM, WGN, false, false, MODE>(a, st);
+}
+
+// staging: 1 = register-staged 2-deep prefetch, 2 = LDS-DMA (see Cfg); 0 = per-layer heuristic.
+// ASM_IGEMM_MODE / ASM_IGEMM_TILE (1 = 128-row tiles, 3 = 256x256) force a choice (tests, tuning).
+int env_int(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool ALLOW_DEEP = true>
+int launch_cfg(IGemmArgs& a, bool out_f32, bool stats, int mode, hipStream_t st) {
+  if (mode == 2) return launch_mode<BM, BN, BK, WGM, WGN, 2>(a, out_f32, stats, st);
+  if (ALLOW_DEEP) return launch_mode<BM, BN, BK, WGM, WGN, 1>(a, out_f32, stats, st);
+  return launch_mode<BM, BN, BK, WGM, WGN, 0>(a, out_f32, stats, st);
+}
+
+int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
+  // Measured on MI355X (tools/conv_bench.py, Assemble-ResNet-50 shapes, batch 256):
+  //  * HBM-bound layers (1x1, and everything at 112x112): LDS-DMA staging + the smallest footprint wins
+  //    (3-8 workgroups per CU hide the load round trip of the very short K loops);
+  //  * MFMA-bound layers (K = R*S*C >= 512): register staging with a 2-deep prefetch wins at 128x128,
+  //    and 256x256 / 8 waves / LDS-DMA wins once there are >= 192 such tiles (C>=256 outputs).
+  const bool bk64 = (a.Ci % 64 == 0 && a.R * a.S > 1);
+  const bool heavy = a.Ci % 64 == 0 && (long long)a.R * a.S * a.Ci >= 512;
+  const int fmode = env_int("ASM_IGEMM_MODE"), ftile = env_int("ASM_IGEMM_TILE");
+  int mode = heavy ? 1 : 2;
+  if (fmode == 1 || fmode == 2) mode = fmode;
+  if (a.Co <= 32) return bk64 ? launch_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, mode, st)
+                              : launch_cfg<128, 32, 32, 4, 1>(a, out_f32, stats, mode, st);
+  if (a.Co <= 64) return bk64 ? launch_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, mode, st)
+                              : launch_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, mode, st);
+  const long long b256 = (long long)cdiv(a.M, 256) * cdiv(a.Co, 256);
+  bool big = heavy && a.Co >= 256 && b256 >= 192;
+  if (ftile == 1) big = false;
+  if (ftile == 3 && a.Ci % 64 == 0) big = true;
+  if (ftile == 2 && a.Ci % 64 == 0) return launch_cfg<256, 128, 64, 4, 2>(a, out_f32, stats, mode, st);
+  if (big) return launch_cfg<256, 256, 64, 4, 2, false>(a, out_f32, stats, (fmode == 1) ? 1 : 2, st);
+  return bk64 ? launch_cfg<128, 128, 64, 2, 2>(a, out_f32, stats, mode, st)
+              : launch_cfg<128, 128, 32, 2, 2>(a, out_f32, stats, mode, st);
 }
 
 int check_desc(const asm_conv_desc* d) {
@@ -349,7 +520,7 @@ static inline int pix_pitch(const asm_conv_desc* d) { return d->x_pix_pitch ? d-
 
 extern "C" int asm_conv2d_stats_blocks(const asm_conv_desc* d) {
   if (!d) return ASM_EINVAL;
-  return cdiv(d->N * d->Ho * d->Wo, BM);
+  return cdiv(d->N * d->Ho * d->Wo, STATS_BM);
 }
 
 extern "C" int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const void* w, void* y,
@@ -362,7 +533,7 @@ extern "C" int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const voi
   ASM_REQUIRE(ldy % (d->out_f32 ? 4 : 8) == 0 && ldy >= d->K, "conv fprop: bad ldy %d", ldy);
   ASM_REQUIRE(!(stats_partial && d->out_f32), "conv fprop: fused statistics need bf16 output");
   IGemmArgs a;
-  a.x = x; a.w = w; a.y = y; a.stats = stats_partial;
+  a.x = x; a.w = w; a.y = y; a.addend = nullptr; a.stats = stats_partial;
   a.x_bytes = (unsigned)(xelems * 2);
   a.w_bytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
   a.M = d->N * d->Ho * d->Wo;
@@ -376,8 +547,8 @@ extern "C" int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const voi
   return launch(a, d->out_f32 != 0, stats_partial != nullptr, (hipStream_t)stream);
 }
 
-extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, void* dx,
-                                void* stream) {
+extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                                void* dx, void* stream) {
   if (int e = check_desc(d)) return e;
   ASM_REQUIRE(dy && wt && dx, "conv dgrad: null pointer");
   ASM_REQUIRE(d->K % 8 == 0, "conv dgrad: K=%d must be a multiple of 8 (pad dy)", d->K);
@@ -386,7 +557,7 @@ extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const vo
   const int64_t dyelems = (int64_t)d->N * d->Ho * d->Wo * d->K;
   ASM_REQUIRE(dyelems * 2 < (int64_t)ASM_OOB, "conv dgrad: dy larger than 2 GiB");
   IGemmArgs a;
-  a.x = dy; a.w = wt; a.y = dx; a.stats = nullptr;
+  a.x = dy; a.w = wt; a.y = dx; a.addend = addend; a.stats = nullptr;
   a.x_bytes = (unsigned)(dyelems * 2);
   a.w_bytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
   a.M = d->N * d->H * d->W;

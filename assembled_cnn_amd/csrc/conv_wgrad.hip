@@ -107,8 +107,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int steps = (m_end - m_begin + WPX - 1) / WPX;
 
-  u32x4 ry[YP], rxv[4];
-  auto load_tile = [&](int step) {
+  // two register tile sets: 2-deep global prefetch (see conv_igemm.hip)
+  u32x4 ya[YP], xa[4], yb[YP], xb[4];
+  auto load_tile = [&](int step, u32x4(&ry)[YP], u32x4(&rxv)[4]) {
 #pragma unroll
     for (int j = 0; j < YP; ++j) {
       const int m = m_begin + step * WPX + yrow + YRP * j;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? offx : ASM_OOB, 0, 0);
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage, const u32x4(&ry)[YP], const u32x4(&rxv)[4]) {
     unsigned char* ys = smem + stage * STAGE;
     unsigned char* xs = ys + YTILE;
 #pragma unroll
@@ -155,12 +156,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  if (steps > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-
   // transposing-read lane geometry (32x32x16 fragment: channel = lane&31, reduction group = lane>>5)
   const int t16 = lane & 15;          // lane within its 16-lane group
   const int g = lane >> 4;            // group 0..3
@@ -169,10 +164,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const int trow = t16 >> 2;          // pixel row within the 4-row block
   const int tcol = (t16 & 3) * 4;     // channel offset of this lane's 4-element source
 
-  for (int step = 0; step < steps; ++step) {
-    const int cur = step & 1;
-    if (step + 1 < steps) load_tile(step + 1);
-    const unsigned char* ys = smem + cur * STAGE;
+  auto compute = [&](int stage) {
+    const unsigned char* ys = smem + stage * STAGE;
     const unsigned char* xs = ys + YTILE;
 #pragma unroll
     for (int kk = 0; kk < WPX / 16; ++kk) {
@@ -201,7 +194,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
         for (int b = 0; b < CT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
     }
-    if (step + 1 < steps) store_tile(cur ^ 1);
+  };
+
+  // steps beyond the range load nothing (m >= m_end -> zeros), so the pair loop needs no tail branch
+  load_tile(0, ya, xa);
+  store_tile(0, ya, xa);
+  load_tile(1, ya, xa);
+  __syncthreads();
+#pragma unroll 1
+  for (int step = 0; step < steps; step += 2) {
+    load_tile(step + 2, yb, xb);
+    compute(0);
+    store_tile(1, ya, xa);
+    __syncthreads();
+    load_tile(step + 3, ya, xa);
+    compute(1);
+    store_tile(0, yb, xb);
     __syncthreads();
   }
 
@@ -223,20 +231,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, float* dw, size_t n,
-                                                           int splits) {
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 4 <= n) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(slab + i);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slab + (size_t)k * n + i);
-    *reinterpret_cast<f32x4*>(dw + i) = s;
-  } else {
-    for (size_t e = i; e < n; ++e) {
-      float s = slab[e];
-      for (int k = 1; k < splits; ++k) s += slab[(size_t)k * n + e];
-      dw[e] = s;
+// slab reduce: dw[i] = sum_k slab[k][i].  256 threads = 32 float4 columns x 8 split-lanes; every lane keeps 4
+// independent loads in flight (the serial-k version was latency-bound), partial sums meet in LDS in a fixed
+// order, so the result stays bit-reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           size_t n, int splits) {
+  __shared__ f32x4 red[8][32];
+  const int cx = threadIdx.x & 31, ky = threadIdx.x >> 5;
+  const size_t i = ((size_t)blockIdx.x * 32 + cx) * 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (i < n) {  // n is a multiple of 8 (C % 8 == 0)
+    int k = ky;
+    for (; k + 24 < splits; k += 32) {
+      s0 += *reinterpret_cast<const f32x4*>(slab + (size_t)k * n + i);
+      s1 += *reinterpret_cast<const f32x4*>(slab + (size_t)(k + 8) * n + i);
+      s2 += *reinterpret_cast<const f32x4*>(slab + (size_t)(k + 16) * n + i);
+      s3 += *reinterpret_cast<const f32x4*>(slab + (size_t)(k + 24) * n + i);
     }
+    for (; k < splits; k += 8) s0 += *reinterpret_cast<const f32x4*>(slab + (size_t)k * n + i);
+  }
+  red[ky][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ky == 0 && i < n) {
+    f32x4 t = red[0][cx];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) t += red[r][cx];
+    *reinterpret_cast<f32x4*>(dw + i) = t;
   }
 }
 
@@ -254,6 +274,11 @@ Plan make_plan(const asm_conv_desc* d) {
   const int tiles = pl.tiles_n * pl.tiles_c;
   const int msteps = cdiv(M, WPX);
   int splits = cdiv(pl.bnw == 128 ? 512 : 768, tiles);   // ~2-3 resident blocks per CU
+  if (tiles >= 192) splits = 1;                            // enough tiles to fill the chip: no slabs at all
+  // the slab reduce moves (splits + 1) x |dW| fp32: cap the slab footprint at 48 MiB
+  const size_t wbytes = (size_t)d->K * cols * sizeof(float);
+  const int cap = (int)((48u << 20) / wbytes) > 1 ? (int)((48u << 20) / wbytes) : 1;
+  if (splits > cap) splits = cap;
   splits = splits < 1 ? 1 : splits;
   const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;  // at least 4 steps per block
   if (splits > max_splits) splits = max_splits;
@@ -312,7 +337,7 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   ASM_CHECK_LAUNCH("wgrad_kernel");
   if (pl.splits > 1) {
     const size_t n = (size_t)d->K * a.cols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 1024)), dim3(256), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 128)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(workspace), dw, n, pl.splits);
     ASM_CHECK_LAUNCH("wgrad_reduce_kernel");
   }

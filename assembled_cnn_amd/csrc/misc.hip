@@ -314,6 +314,29 @@ __global__ void filter_transpose_kernel(const bf16_t* w, bf16_t* wt, int K, int 
   const int c = (int)(r / RS);
   wt[((size_t)c * RS + t) * ldk + k] = w[((size_t)k * RS + t) * C + c];
 }
+// all KRSC -> CRSK copies of a model in ONE launch: table[l] = {src_off, dst_off, K, RS, C, ldk, elem_begin, 0}
+// (offsets in elements inside the two flat bf16 arenas); thread e handles flat source element e.
+__global__ __launch_bounds__(256) void filter_transpose_batched_kernel(const bf16_t* __restrict__ w,
+                                                                       bf16_t* __restrict__ wt,
+                                                                       const int* __restrict__ table, int nl,
+                                                                       long long total) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  int lo = 0, hi = nl - 1;
+  while (lo < hi) {  // last layer whose elem_begin <= e
+    const int mid = (lo + hi + 1) >> 1;
+    if ((long long)table[mid * 8 + 6] <= e) lo = mid; else hi = mid - 1;
+  }
+  const int* t = table + lo * 8;
+  const int K = t[2], RS = t[3], C = t[4], ldk = t[5];
+  const int local = (int)(e - t[6]);
+  const int c = local % C;
+  const int r = local / C;
+  const int tap = r % RS;
+  const int k = r / RS;
+  wt[(size_t)t[1] + ((size_t)c * RS + tap) * ldk + k] = w[(size_t)t[0] + local];
+}
+
 __global__ void stem_pack_kernel(const float* w, bf16_t* wp, int K, int ks, int L) {  // [K][k][k][3] -> [K][k][L]
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= K * ks * L) return;
@@ -616,5 +639,15 @@ extern "C" int asm_debug_tr_probe(void* out256_i16, void* stream) {
   ASM_REQUIRE(out256_i16, "tr_probe: null pointer");
   hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (short*)out256_i16);
   ASM_CHECK_LAUNCH("tr_probe");
+  return ASM_OK;
+}
+
+extern "C" int asm_filter_transpose_batched(const void* w_arena, void* wt_arena, const int32_t* table, int nlayers,
+                                            long long total_elems, void* stream) {
+  ASM_REQUIRE(w_arena && wt_arena && table && nlayers > 0 && total_elems > 0, "filter_transpose_batched: bad arguments");
+  hipLaunchKernelGGL(filter_transpose_batched_kernel, dim3((unsigned)cdivz((size_t)total_elems, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)w_arena, (bf16_t*)wt_arena, (const int*)table, nlayers,
+                     total_elems);
+  ASM_CHECK_LAUNCH("filter_transpose_batched");
   return ASM_OK;
 }

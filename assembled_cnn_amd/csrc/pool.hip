@@ -18,14 +18,17 @@ __device__ __forceinline__ u32x4 ldv(const bf16_t* p, size_t elem_off) {
 struct Pix {
   int n, h, w, vc;
 };
-__device__ __forceinline__ Pix decode(size_t i, int H, int W, int vcols) {
+__device__ __forceinline__ Pix decode(size_t i64, int H, int W, int vcols) {
+  // 32-bit index math (every launcher bounds the vector count below 2^31): 64-bit div/mod costs ~10x
+  const unsigned i = (unsigned)i64;
   Pix p;
-  p.vc = (int)(i % vcols);
-  size_t m = i / vcols;
-  p.w = (int)(m % W);
-  m /= W;
-  p.h = (int)(m % H);
-  p.n = (int)(m / H);
+  unsigned m = i / (unsigned)vcols;
+  p.vc = (int)(i - m * (unsigned)vcols);
+  unsigned q = m / (unsigned)W;
+  p.w = (int)(m - q * (unsigned)W);
+  const unsigned n = q / (unsigned)H;
+  p.h = (int)(q - n * (unsigned)H);
+  p.n = (int)n;
   return p;
 }
 
@@ -348,8 +351,9 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const bf16_t* __restrict__
   const size_t nvec = (size_t)N * HW * vcols;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
-  const int vc = (int)(i % vcols);
-  const int n = (int)(i / ((size_t)HW * vcols));
+  const unsigned iu = (unsigned)i;
+  const int vc = (int)(iu % (unsigned)vcols);
+  const int n = (int)(iu / ((unsigned)HW * (unsigned)vcols));
   float g[8];
   unpack8(ldv(dy, (size_t)n * C + vc * 8), g);
   const float inv = 1.0f / (float)HW;
@@ -377,6 +381,7 @@ extern "C" int asm_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int
   same_pad(H, 3, 2, &Ho, &ph);
   same_pad(W, 3, 2, &Wo, &pw);
   const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)y, argmax, N, H, W, C, Ho, Wo, ph, pw);
   ASM_CHECK_LAUNCH("maxpool_fwd");
@@ -391,6 +396,7 @@ extern "C" int asm_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void*
   same_pad(H, 3, 2, &Ho, &ph);
   same_pad(W, 3, 2, &Wo, &pw);
   const size_t nvec = (size_t)N * H * W * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      argmax, (bf16_t*)dx, N, H, W, C, Ho, Wo, ph, pw);
   ASM_CHECK_LAUNCH("maxpool_bwd");
@@ -402,6 +408,7 @@ extern "C" int asm_avgpool_fwd(const void* x, void* y, int N, int H, int W, int 
   POOL_ARGS_OK("avgpool_fwd");
   ASM_REQUIRE(x && y && k >= 1 && k <= 7 && stride >= 1 && pad >= 0 && Ho > 0 && Wo > 0, "avgpool_fwd: bad arguments");
   const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)y, N, H, W, C, k, stride, pad, Ho, Wo, count_valid);
   ASM_CHECK_LAUNCH("avgpool_fwd");
@@ -413,6 +420,7 @@ extern "C" int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, in
   POOL_ARGS_OK("avgpool_bwd");
   ASM_REQUIRE(dy && dx && k >= 1 && k <= 7 && stride >= 1 && pad >= 0 && Ho > 0 && Wo > 0, "avgpool_bwd: bad arguments");
   const size_t nvec = (size_t)N * H * W * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (bf16_t*)dx, N, H, W, C, k, stride, pad, Ho, Wo, count_valid);
   ASM_CHECK_LAUNCH("avgpool_bwd");
@@ -422,6 +430,7 @@ extern "C" int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, in
 extern "C" int asm_upsample2x_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int C, void* stream) {
   ASM_REQUIRE(dy && dx && N > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0, "upsample2x_bwd: bad arguments");
   const size_t nvec = (size_t)N * Hs * Ws * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (bf16_t*)dx, N, Hs, Ws, C);
   ASM_CHECK_LAUNCH("upsample2x_bwd");
@@ -436,6 +445,7 @@ extern "C" int asm_blurpool_fwd(const void* x, void* y, int N, int H, int W, int
   ASM_REQUIRE((k - 1) / 2 < H && (k - 1) / 2 < W, "blurpool_fwd: REFLECT pad needs pad < size");
   const int Ho = blur_out(H, k, stride), Wo = blur_out(W, k, stride);
   const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(blur_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)y, N, H, W, C, k, stride, Ho, Wo, blur_coef(k));
   ASM_CHECK_LAUNCH("blurpool_fwd");
@@ -448,6 +458,7 @@ extern "C" int asm_blurpool_bwd(const void* dy, void* dx, int N, int H, int W, i
   ASM_REQUIRE(dy && dx && k >= 2 && k <= 7 && stride >= 1, "blurpool_bwd: filter size %d not supported", k);
   const int Ho = blur_out(H, k, stride), Wo = blur_out(W, k, stride);
   const size_t nvec = (size_t)N * H * W * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(blur_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (bf16_t*)dx, N, H, W, C, k, stride, Ho, Wo, blur_coef(k));
   ASM_CHECK_LAUNCH("blurpool_bwd");
@@ -475,6 +486,7 @@ extern "C" int asm_sk_gap(const void* f, void* s, int N, int HW, int F, void* st
 extern "C" int asm_gap_bwd(const void* dy, void* dx, int N, int HW, int C, void* stream) {
   ASM_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_bwd: bad arguments");
   const size_t nvec = (size_t)N * HW * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (bf16_t*)dx, N, HW, C);
   ASM_CHECK_LAUNCH("gap_bwd");

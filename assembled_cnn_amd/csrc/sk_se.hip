@@ -28,9 +28,11 @@ __global__ __launch_bounds__(256) void sk_select_fwd_kernel(const bf16_t* __rest
   const size_t nvec = (size_t)N * HW * vcols;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
-  const int vc = (int)(i % vcols);
-  const size_t m = i / vcols;
-  const int n = (int)(m / HW);
+  const unsigned iu = (unsigned)i;
+  const unsigned mu = iu / (unsigned)vcols;
+  const int vc = (int)(iu - mu * (unsigned)vcols);
+  const size_t m = mu;
+  const int n = (int)(mu / (unsigned)HW);
   float a0[8], f0[8], f1[8], o[8];
   gate8(att, n, F, vc * 8, a0);
   unpack8(ldv(f, m * 2 * F + vc * 8), f0);
@@ -88,9 +90,11 @@ __global__ __launch_bounds__(256) void sk_bwd_f_kernel(const bf16_t* __restrict_
   const size_t nvec = (size_t)N * HW * vcols;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
-  const int vc = (int)(i % vcols);
-  const size_t m = i / vcols;
-  const int n = (int)(m / HW);
+  const unsigned iu = (unsigned)i;
+  const unsigned mu = iu / (unsigned)vcols;
+  const int vc = (int)(iu - mu * (unsigned)vcols);
+  const size_t m = mu;
+  const int n = (int)(mu / (unsigned)HW);
   float a0[8], g[8], s[8], o0[8], o1[8];
   gate8(att, n, F, vc * 8, a0);
   unpack8(ldv(dv, m * F + vc * 8), g);
@@ -115,8 +119,9 @@ __global__ __launch_bounds__(256) void se_scale_fwd_kernel(const bf16_t* __restr
   const size_t nvec = (size_t)N * HW * vcols;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
-  const int vc = (int)(i % vcols);
-  const int n = (int)(i / ((size_t)HW * vcols));
+  const unsigned iu = (unsigned)i;
+  const int vc = (int)(iu % (unsigned)vcols);
+  const int n = (int)(iu / ((unsigned)HW * (unsigned)vcols));
   float f[8];
   unpack8(ldv(x, i * 8), f);
 #pragma unroll
@@ -168,8 +173,9 @@ __global__ __launch_bounds__(256) void se_bwd_x_kernel(const bf16_t* __restrict_
   const size_t nvec = (size_t)N * HW * vcols;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
-  const int vc = (int)(i % vcols);
-  const int n = (int)(i / ((size_t)HW * vcols));
+  const unsigned iu = (unsigned)i;
+  const int vc = (int)(iu % (unsigned)vcols);
+  const int n = (int)(iu / ((unsigned)HW * (unsigned)vcols));
   float g[8], q[8];
   unpack8(ldv(dy, i * 8), g);
   unpack8(ldv(dsq, (size_t)n * C + vc * 8), q);
@@ -187,6 +193,7 @@ extern "C" int asm_sk_select_fwd(const void* f, const float* att, void* v, int N
   SK_OK("sk_select_fwd");
   ASM_REQUIRE(f && att && v, "sk_select_fwd: null pointer");
   const size_t nvec = (size_t)N * HW * (F / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "sk/se: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(sk_select_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)f,
                      att, (bf16_t*)v, N, HW, F);
   ASM_CHECK_LAUNCH("sk_select_fwd");
@@ -209,6 +216,7 @@ extern "C" int asm_sk_select_bwd_f(const void* dv, const float* att, const void*
   SK_OK("sk_select_bwd_f");
   ASM_REQUIRE(dv && att && ds && df, "sk_select_bwd_f: null pointer");
   const size_t nvec = (size_t)N * HW * (F / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "sk/se: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(sk_bwd_f_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dv, att,
                      (const bf16_t*)ds, (bf16_t*)df, N, HW, F);
   ASM_CHECK_LAUNCH("sk_select_bwd_f");
@@ -218,6 +226,7 @@ extern "C" int asm_sk_select_bwd_f(const void* dv, const float* att, const void*
 extern "C" int asm_se_scale_fwd(const void* x, const float* e, void* y, int N, int HW, int C, void* stream) {
   ASM_REQUIRE(x && e && y && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale_fwd: bad arguments");
   const size_t nvec = (size_t)N * HW * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "sk/se: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(se_scale_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, e,
                      (bf16_t*)y, N, HW, C);
   ASM_CHECK_LAUNCH("se_scale_fwd");
@@ -238,6 +247,7 @@ extern "C" int asm_se_scale_bwd_x(const void* dy, const float* e, const void* ds
                                   void* stream) {
   ASM_REQUIRE(dy && e && dsq && dx && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale_bwd_x: bad arguments");
   const size_t nvec = (size_t)N * HW * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "sk/se: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(se_bwd_x_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, e,
                      (const bf16_t*)dsq, (bf16_t*)dx, N, HW, C);
   ASM_CHECK_LAUNCH("se_scale_bwd_x");

@@ -37,10 +37,11 @@ SIGNATURES = {
     'asm_abi_version': (_I, []),
     'asm_conv2d_fprop': (_I, [_D, _P, _P, _P, _P, _P]),
     'asm_conv2d_stats_blocks': (_I, [_D]),
-    'asm_conv2d_dgrad': (_I, [_D, _P, _P, _P, _P]),
+    'asm_conv2d_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
     'asm_conv2d_wgrad_workspace_bytes': (_Z, [_D]),
     'asm_conv2d_wgrad': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
     'asm_filter_transpose': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'asm_filter_transpose_batched': (_I, [_P, _P, _P, _I, C.c_longlong, _P]),
     'asm_conv2d_fprop_naive': (_I, [_D, _P, _P, _P, _P]),
     'asm_conv2d_dgrad_naive': (_I, [_D, _P, _P, _P, _P]),
     'asm_conv2d_wgrad_naive': (_I, [_D, _P, _P, _P, _P]),
@@ -53,7 +54,7 @@ SIGNATURES = {
     'asm_bn_partials_compact': (_I, [_P, _I, _I, _P, _I, _P]),
     'asm_bn_finalize': (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     'asm_bn_infer_coeffs': (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
-    'asm_bn_apply': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'asm_bn_apply': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'asm_bn_bwd_reduce': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'asm_bn_bwd_finalize': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_bn_bwd_apply': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

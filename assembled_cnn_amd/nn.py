@@ -59,6 +59,9 @@ class ParamArena(object):
     self.w32 = self.g32 = self.m32 = self.w16 = self.state = None
     self.derived: List[Callable[[], None]] = []  # refresh hooks (CRSK copies, stem packing)
     self.on_grad: Optional[Callable[[int], None]] = None  # dp.GradSync.notify (gradient-ready watermark)
+    self.wt_specs: List[dict] = []   # CRSK (dgrad operand) copies: one flat bf16 arena, one batched launch
+    self.wt16 = None
+    self._wt_table = None
 
   def notify_grad(self, name: str):
     """The gradient slot of ``name`` has been enqueued on the compute stream (backward order is the
@@ -109,6 +112,18 @@ class ParamArena(object):
       soff += _round_up(n, 8)
     self.state_specs = new_specs
     self.state = torch.from_numpy(np.concatenate(shost) if shost else np.zeros((0,), np.float32)).to(device)
+    woff = 0
+    rows = []
+    begin = 0
+    for ws in self.wt_specs:
+      ws['offset'] = woff
+      sp = self.specs[ws['name']]
+      rows.append([sp.offset, woff, ws['K'], ws['RS'], ws['C'], ws['ldk'], begin, 0])
+      begin += sp.numel
+      woff += _round_up(ws['C'] * ws['RS'] * ws['ldk'], 8)
+    self._wt_total = begin
+    self.wt16 = torch.zeros((max(woff, 8),), dtype=torch.bfloat16, device=device)
+    self._wt_table = torch.tensor(rows if rows else [[0] * 8], dtype=torch.int32).to(device)
     self.finalized = True
     self.refresh_shadows()
 
@@ -139,7 +154,18 @@ class ParamArena(object):
     ops.cast_f32_to_bf16(self.w32, self.w16)
     self.refresh_derived()
 
+  def alloc_wt(self, name, K, RS, Cn, ldk) -> dict:
+    ws = dict(name=name, K=K, RS=RS, C=Cn, ldk=ldk, offset=-1)
+    self.wt_specs.append(ws)
+    return ws
+
+  def wt_view(self, ws) -> torch.Tensor:
+    n = ws['C'] * ws['RS'] * ws['ldk']
+    return self.wt16[ws['offset']:ws['offset'] + n]
+
   def refresh_derived(self):
+    if self.wt_specs:
+      ops.filter_transpose_batched(self.w16, self.wt16, self._wt_table, len(self.wt_specs), self._wt_total)
     for fn in self.derived:
       fn()
 
@@ -283,10 +309,13 @@ class ConvKernel(object):
       init = lambda rng: shape_init(rng).reshape(cout, 1, 1, cin)
     ctx.arena.register(self.name, shape, True, init)
     self.kpad = _round_up(cout, 8)  # dy channel stride for the backward of a non-multiple-of-8 Cout
-    self._wt = None
     self._wpack = None
+    self._wts = None
     if not ctx.arena.finalized:
-      ctx.arena.derived.append(self._refresh)
+      if self.stem:
+        ctx.arena.derived.append(self._refresh)
+      if self.need_dgrad:
+        self._wts = ctx.arena.alloc_wt(self.name, cout, k * k, cin, self.kpad)
 
   def _refresh(self):
     a = self.arena
@@ -295,10 +324,6 @@ class ConvKernel(object):
       if self._wpack is None:
         self._wpack = torch.empty((self.cout, self.k, 1, self.stem_len), dtype=torch.bfloat16, device=dev)
       ops.stem_pack_filter(a.w(self.name), self._wpack, self.cout, self.k)
-    if self.need_dgrad:
-      if self._wt is None:
-        self._wt = torch.zeros((self.cin, self.k, self.k, self.kpad), dtype=torch.bfloat16, device=dev)
-      ops.filter_transpose(a.wb(self.name), self._wt, self.cout, self.k, self.k, self.cin, self.kpad)
 
   # descriptors -------------------------------------------------------------------------------------
   def desc(self, N, H, W, stride, out_f32=False, ldy=0):
@@ -328,8 +353,9 @@ class ConvKernel(object):
       x = self._stem_view(x)
     return ops.conv_fprop(d, x, self.weight(), want_stats)
 
-  def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool) -> Optional[torch.Tensor]:
-    """dW into the gradient arena; returns dx (or None)."""
+  def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool,
+               addend: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """dW into the gradient arena; returns dx [+ addend] (or None)."""
     a = self.arena
     if self.stem:
       dwp = torch.empty((self.cout, self.k, self.stem_len), dtype=torch.float32, device=x.device)
@@ -343,8 +369,8 @@ class ConvKernel(object):
       return None
     if self.kpad != self.cout:  # dy carries kpad channels (zero padded)
       dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, self.kpad, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo)
-      return ops.conv_dgrad(dd, dy, self._wt)
-    return ops.conv_dgrad(d, dy, self._wt)
+      return ops.conv_dgrad(dd, dy, a.wt_view(self._wts), addend)
+    return ops.conv_dgrad(d, dy, a.wt_view(self._wts), addend)
 
 
 class BatchNorm(object):
@@ -396,7 +422,12 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
     ctx.taps[tap_pre] = y
   if tap_pre is not None:
     ctx.taps[tap_pre] = y
-  out_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, res_mode if residual is not None else 0, relu, d.Ho, d.Wo)
+  taped = ctx.tape is not None
+  rm = res_mode if residual is not None else 0
+  if taped and relu:   # keep the 1-bit ReLU mask for the backward kernels (16x less traffic than re-reading out)
+    out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, rm, True, d.Ho, d.Wo, want_mask=True)
+  else:
+    out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, rm, relu, d.Ho, d.Wo), None
   out = Var(out_t)
 
   if ctx.tape is not None:
@@ -407,7 +438,8 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
       if dout is None:
         raise RuntimeError('conv_bn backward: no gradient reached this layer')
       want_dz = residual is not None and relu
-      dy, dz = ops.bn_bwd(dout, y, out_t, relu, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), want_dz)
+      dy, dz = ops.bn_bwd(dout, y, mask_t if relu else None, relu, M, Cn, gamma, mean, invstd, a.g(bn.gamma),
+                          a.g(bn.beta), want_dz)
       a.notify_grad(bn.gamma)
       if residual is not None:
         dres = dz if relu else dout
@@ -415,9 +447,9 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
           accum_grad(residual, ops.upsample2x_bwd(dres), True)
         else:
           accum_grad(residual, dres, relu)
-      dx = conv.backward(d, x_t, dy, x.needs_grad)
+      dx = conv.backward(d, x_t, dy, x.needs_grad, addend=x.grad)   # fan-in add fused into the dgrad epilogue
       if dx is not None:
-        accum_grad(x, dx, True)
+        x.grad, x.grad_owned = dx, True
       out.grad = None
     ctx.record(bwd)
   return out
@@ -437,9 +469,9 @@ def conv_plain(ctx: Ctx, x: Var, conv: ConvKernel, out_f32: bool, ldy: int = 0):
     # the backward descriptor is always a bf16 one; dy's row stride is ldy when the logits were padded
     dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo,
                             ldy=ldy if (ldy and ldy != conv.cout) else 0)
-    dx = conv.backward(dd, x_t, dy, x.needs_grad)
+    dx = conv.backward(dd, x_t, dy, x.needs_grad, addend=x.grad)
     if dx is not None:
-      accum_grad(x, dx, True)
+      x.grad, x.grad_owned = dx, True
   return y, bwd, tuple(y.shape)
 
 

@@ -133,10 +133,12 @@ def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool =
   return y, stats
 
 
-def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor) -> torch.Tensor:
+def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional[torch.Tensor] = None
+               ) -> torch.Tensor:
+  """dx = conv_transpose(dy, w) [+ addend]"""
   dx = empty((d.N, d.H, d.W, d.C), BF16, dy)
   ev = _TIMER.start('dgrad', d) if _TIMER is not None else None
-  check(L().asm_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), _stream()), 'conv2d_dgrad')
+  check(L().asm_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(addend), _ptr(dx), _stream()), 'conv2d_dgrad')
   if ev is not None:
     ev.record()
   return dx
@@ -169,6 +171,11 @@ def conv_wgrad(d: ConvDesc, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor)
 
 def filter_transpose(w: torch.Tensor, wt: torch.Tensor, K, R, S, Cin, ldk=0):
   check(L().asm_filter_transpose(_ptr(w), _ptr(wt), K, R, S, Cin, ldk, _stream()), 'filter_transpose')
+
+
+def filter_transpose_batched(w_arena, wt_arena, table, nlayers, total):
+  check(L().asm_filter_transpose_batched(_ptr(w_arena), _ptr(wt_arena), _ptr(table), nlayers, total, _stream()),
+        'filter_transpose_batched')
 
 
 def stem_pack_filter(w32: torch.Tensor, wp: torch.Tensor, K: int, ksize: int):
@@ -206,7 +213,7 @@ def bn_stats(x2d: torch.Tensor, M: int, Cn: int) -> torch.Tensor:
 def _compact(part: torch.Tensor, Cn: int) -> torch.Tensor:
   """Thousands of partial rows (conv epilogue at high resolution) -> <= 32 rows, fully parallel."""
   blocks = part.shape[0]
-  if blocks <= 64:
+  if blocks <= 512:
     return part
   per = -(-blocks // 32)
   groups = -(-blocks // per)
@@ -232,18 +239,22 @@ def bn_infer_coeffs(Cn, gamma, beta, mm, mv, eps):
   return co[0], co[1]
 
 
-def bn_apply(x, M, Cn, scale, shift, residual=None, res_mode=0, relu=False, H=0, W=0):
+def bn_apply(x, M, Cn, scale, shift, residual=None, res_mode=0, relu=False, H=0, W=0, want_mask=False):
+  """-> y, or (y, packed ReLU mask [M, C/8] uint8) with want_mask."""
   y = torch.empty_like(x)
+  mask = empty((M, Cn // 8), torch.uint8, x) if (want_mask and relu) else None
   check(L().asm_bn_apply(_ptr(x), _ptr(y), M, Cn, _ptr(scale), _ptr(shift), _ptr(residual), res_mode,
-                         1 if relu else 0, H, W, _stream()), 'bn_apply')
-  return y
+                         1 if relu else 0, H, W, _ptr(mask), _stream()), 'bn_apply')
+  return (y, mask) if want_mask else y
 
 
 def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz):
-  """-> dx, dz (dz None unless want_dz).  dgamma/dbeta: f32 [C] views, overwritten."""
+  """-> dx, dz (dz None unless want_dz).  dgamma/dbeta: f32 [C] views, overwritten.
+  ``yout`` is the bf16 forward output or (uint8) the packed ReLU mask from bn_apply(want_mask=True)."""
+  rk = 0 if not relu else (2 if yout.dtype == torch.uint8 else 1)
   blocks = L().asm_bn_stats_blocks(M, Cn)
   part = empty((blocks, 2, Cn), F32, dy)
-  check(L().asm_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(yout if relu else None), 1 if relu else 0, M, Cn,
+  check(L().asm_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(yout if relu else None), rk, M, Cn,
                               _ptr(mean), _ptr(invstd), _ptr(part), _stream()), 'bn_bwd_reduce')
   part = _compact(part, Cn)
   blocks = part.shape[0]
@@ -252,7 +263,7 @@ def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz
                                 _ptr(dbeta), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _stream()), 'bn_bwd_finalize')
   dx = torch.empty_like(x)
   dz = torch.empty_like(x) if want_dz else None
-  check(L().asm_bn_bwd_apply(_ptr(dy), _ptr(x), _ptr(yout if relu else None), 1 if relu else 0, M, Cn,
+  check(L().asm_bn_bwd_apply(_ptr(dy), _ptr(x), _ptr(yout if relu else None), rk, M, Cn,
                              _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _ptr(dx), _ptr(dz), _stream()), 'bn_bwd_apply')
   return dx, dz
 

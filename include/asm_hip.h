@@ -74,8 +74,11 @@ int asm_conv2d_stats_blocks(const asm_conv_desc* d);
 
 /* dx = conv_transpose(dy, w).  wt is the filter in [C][R][S][K] layout (asm_filter_transpose).
  * Gradient of tf.layers.conv2d w.r.t. its input, which TF autodiff provides to
- * optimizer.compute_gradients (nets/optimizer_setting.py:30). */
-int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream);
+ * optimizer.compute_gradients (nets/optimizer_setting.py:30).  If addend != NULL (bf16, dx's shape) the kernel
+ * writes dx = conv_transpose(dy, w) + addend: the gradient fan-in add (a tensor consumed by two ops, e.g. a block
+ * input feeding conv1 and the shortcut) fused into the epilogue; addend may alias dx. */
+int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend, void* dx,
+                     void* stream);
 
 /* dw[k][r][s][c] (float32) = sum_{n,ho,wo} dy(n,ho,wo,k) * x(n, ho*stride+r-pad, wo*stride+s-pad, c).
  * Split-K over output pixels; `workspace` holds the per-split slabs. */
@@ -86,6 +89,12 @@ int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const void* dy, floa
 /* KRSC bf16 -> CRSK bf16 (the dgrad operand).  ldk = K-stride of the output rows (0 => K); columns
  * k >= K of a padded output are left untouched (keep them zero). */
 int asm_filter_transpose(const void* w_krsc, void* w_crsk, int K, int R, int S, int C, int ldk, void* stream);
+
+/* Every KRSC -> CRSK copy of a model in one launch.  table: nlayers rows of 8 int32
+ * {src_off, dst_off, K, R*S, C, ldk, elem_begin, 0}: offsets in elements into the flat bf16 arenas, elem_begin =
+ * running sum of K*R*S*C (row 0 starts at 0); total_elems = the final running sum. */
+int asm_filter_transpose_batched(const void* w_arena, void* wt_arena, const int32_t* table, int nlayers,
+                                 long long total_elems, void* stream);
 
 /* Debug / test-only direct convolutions (one thread per output element, fp32 accumulate).  They
  * exist so GPU tests can cross-check the MFMA kernels at sizes the CPU oracle cannot reach. */
@@ -126,11 +135,14 @@ int asm_bn_finalize(const float* stats_partial, int blocks, int M, int C, const 
 int asm_bn_infer_coeffs(int C, const float* gamma, const float* beta, const float* moving_mean,
                         const float* moving_var, float eps, float* scale, float* shift, void* stream);
 /* y = [relu]( x*scale[c] + shift[c] [+ residual] ).  res_mode: 0 none, 1 same shape,
- * 2 residual is [N, H/2, W/2, C] and is nearest-upsampled 2x (needs H, W). */
+ * 2 residual is [N, H/2, W/2, C] and is nearest-upsampled 2x (needs H, W).  With relu, relu_mask_out (optional,
+ * [M][C/8] bytes) receives the packed ReLU mask (bit e of byte v = output channel 8v+e > 0) that the backward
+ * kernels can read instead of the 16x larger bf16 output. */
 int asm_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift,
-                 const void* residual, int res_mode, int relu, int H, int W, void* stream);
-/* backward.  dy: grad of the output y; yout: the forward output (for the ReLU mask; may be NULL
- * when relu == 0).  Pass 1 reduces dgamma/dbeta partials, finalize makes the per-channel
+                 const void* residual, int res_mode, int relu, int H, int W, uint8_t* relu_mask_out,
+                 void* stream);
+/* backward.  dy: grad of the output y; relu: 0 none, 1 yout is the bf16 forward output, 2 yout is the packed
+ * mask written by asm_bn_apply (yout may be NULL when relu == 0).  Pass 1 reduces dgamma/dbeta partials, finalize makes the per-channel
  * coefficients, pass 2 writes dx (and, if dz_out != NULL, the masked gradient dz = dy*[y>0] that
  * also flows to the residual branch). */
 int asm_bn_bwd_reduce(const void* dy, const void* x, const void* yout, int relu, int M, int C,

@@ -115,7 +115,7 @@ class CpuDouble(object):
         st[b, 1] = (blk * blk).sum(0)
     return 0
 
-  def asm_conv2d_dgrad(self, d, dy, wt, dx, stream):
+  def asm_conv2d_dgrad(self, d, dy, wt, addend, dx, stream):
     d = _desc(d)
     self._validate(d, 'dgrad')
     g = T(dy, (d.N, d.Ho, d.Wo, d.K), 'bf16').float()
@@ -127,7 +127,10 @@ class CpuDouble(object):
     yy = F.conv2d(F.pad(x, (d.pad, pad_after_w, d.pad, pad_after_h)), w_oihw, stride=d.stride)
     yy = yy[:, :, :d.Ho, :d.Wo]
     (gx,) = torch.autograd.grad(yy, x, g.permute(0, 3, 1, 2))
-    T(dx, (d.N, d.H, d.W, d.C), 'bf16').copy_(gx.permute(0, 2, 3, 1))
+    gx = gx.permute(0, 2, 3, 1).to(torch.bfloat16).float()
+    if addend:
+      gx = gx + T(addend, (d.N, d.H, d.W, d.C), 'bf16').float()
+    T(dx, (d.N, d.H, d.W, d.C), 'bf16').copy_(gx)
     return 0
 
   def asm_conv2d_wgrad_workspace_bytes(self, d):
@@ -149,6 +152,15 @@ class CpuDouble(object):
     src = T(w, (K, R, S, Cn), 'bf16')
     dst = T(wt, (Cn, R, S, ldk), 'bf16')
     dst[..., :K] = src.permute(3, 1, 2, 0)
+    return 0
+
+  def asm_filter_transpose_batched(self, w, wt, table, nl, total, stream):
+    tab = T(table, (nl, 8), 'i32')
+    for l in range(nl):
+      so, do, K, RS, Cn, ldk, eb, _ = [int(v) for v in tab[l]]
+      src = T(w + 2 * so, (K, RS, Cn), 'bf16')
+      dst = T(wt + 2 * do, (Cn, RS, ldk), 'bf16')
+      dst[..., :K] = src.permute(2, 1, 0)
     return 0
 
   def asm_stem_pack_filter(self, w, wp, K, ks, stream):
@@ -224,7 +236,7 @@ class CpuDouble(object):
     T(shift, (Cn,), 'f32').copy_(b - T(mm, (Cn,), 'f32') * sc)
     return 0
 
-  def asm_bn_apply(self, x, y, M, Cn, scale, shift, residual, res_mode, relu, H, W, stream):
+  def asm_bn_apply(self, x, y, M, Cn, scale, shift, residual, res_mode, relu, H, W, mask_out, stream):
     v = T(x, (M, Cn), 'bf16').float() * T(scale, (Cn,), 'f32') + T(shift, (Cn,), 'f32')
     if res_mode == 1:
       v = v + T(residual, (M, Cn), 'bf16').float()
@@ -234,14 +246,22 @@ class CpuDouble(object):
       r = r.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
       v = v + r.reshape(M, Cn)
     if relu:
+      if mask_out:
+        bits = (v > 0).view(M, Cn // 8, 8).to(torch.int32)
+        packed = (bits << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8)
+        T(mask_out, (M, Cn // 8), 'u8').copy_(packed)
       v = F.relu(v)
     T(y, (M, Cn), 'bf16').copy_(v)
     return 0
 
   def _dz(self, dy, yout, relu, M, Cn):
     g = T(dy, (M, Cn), 'bf16').float()
-    if relu:
+    if relu == 1:
       g = g * (T(yout, (M, Cn), 'bf16').float() > 0)
+    elif relu == 2:
+      mk = T(yout, (M, Cn // 8), 'u8').to(torch.int32)
+      bits = ((mk[:, :, None] >> torch.arange(8, dtype=torch.int32)) & 1).view(M, Cn)
+      g = g * bits
     return g
 
   def asm_bn_bwd_reduce(self, dy, x, yout, relu, M, Cn, mean, invstd, part, stream):

@@ -58,9 +58,11 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize('mode', [2, 1], ids=['lds-dma', 'reg-staged'])
 @pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
-def test_fprop_dgrad_wgrad_vs_oracle(hip_lib, shape):
+def test_fprop_dgrad_wgrad_vs_oracle(hip_lib, shape, mode, monkeypatch):
   from assembled_cnn_amd import ops
+  monkeypatch.setenv('ASM_IGEMM_MODE', str(mode))   # global->LDS staging flavour of the igemm kernel
   N, H, W, Cn, K, k, stride = shape
   x = _rand((N, H, W, Cn), 1)
   w = _rand((K, k, k, Cn), 2, scale=(1.0 / (k * k * Cn)) ** 0.5)
@@ -93,6 +95,9 @@ def test_fprop_dgrad_wgrad_vs_oracle(hip_lib, shape):
   assert torch.equal(wt.cpu(), w.permute(3, 1, 2, 0).contiguous())
   dx = ops.conv_dgrad(d, dy.cuda(), wt)
   _check(dx, gx, name='dgrad')
+  # fused fan-in add: dgrad(dy) + addend, with addend = dgrad(dy) itself -> exactly 2x in bf16
+  dx2 = ops.conv_dgrad(d, dy.cuda(), wt, addend=dx)
+  assert torch.equal(dx2.float(), dx.float() * 2)
 
   dw = torch.empty((K, k, k, Cn), dtype=torch.float32, device='cuda')
   ops.conv_wgrad(d, xd, dy.cuda(), dw)
@@ -215,3 +220,54 @@ def test_error_convention(hip_lib):
     ops.conv_fprop(ops.make_conv_desc(1, 4, 4, 12, 8, 3, 3, 1), x, w)   # C % 8 != 0
   with pytest.raises(ValueError):
     ops.conv_fprop(ops.make_conv_desc(1, 4, 4, 16, 8, 3, 3, 3), x, w)   # stride 3
+
+
+def test_batched_filter_transpose(hip_lib):
+  """all CRSK copies of an arena in one launch == per-layer permutes (incl. a padded-K dense kernel)."""
+  from assembled_cnn_amd import nn
+  dev = torch.device('cuda')
+  arena = nn.ParamArena()
+  c = nn.Ctx(arena, True, True, 0.997, dev, False)
+  convs = [nn.ConvKernel(c, 3, 64, 128), nn.ConvKernel(c, 1, 256, 64), nn.ConvKernel(c, 1, 2048, 1001, dense=True),
+           nn.ConvKernel(c, 3, 32, 32)]
+  arena.finalize(dev, 0)
+  for cv in convs:
+    w = arena.wb(cv.name)
+    wt = arena.wt_view(cv._wts).view(cv.cin, cv.k, cv.k, cv.kpad)
+    assert torch.equal(wt[..., :cv.cout], w.permute(3, 1, 2, 0))
+    assert float(wt[..., cv.cout:].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('mode', [2, 1], ids=['lds-dma', 'reg-staged'])
+@pytest.mark.parametrize('tile', [2, 3])
+@pytest.mark.parametrize('shape', [(3, 7, 7, 256, 512, 3, 1), (2, 16, 16, 64, 128, 3, 1), (4, 20, 20, 128, 320, 1, 1),
+                                   (2, 14, 14, 128, 256, 3, 2)], ids=lambda s: 'x'.join(map(str, s)))
+def test_big_tile_variants(hip_lib, shape, tile, mode, monkeypatch):
+  """the 256x128 / 256x256 (8-wave) tile configurations, forced through ASM_IGEMM_TILE, incl. ragged M, masked N
+  and the two-partials-per-tile statistics epilogue."""
+  from assembled_cnn_amd import ops
+  monkeypatch.setenv('ASM_IGEMM_TILE', str(tile))
+  monkeypatch.setenv('ASM_IGEMM_MODE', str(mode))
+  N, H, W, Cn, K, k, stride = shape
+  x = _rand((N, H, W, Cn), 21)
+  w = _rand((K, k, k, Cn), 22, scale=(1.0 / (k * k * Cn)) ** 0.5)
+  d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
+  y, stats = ops.conv_fprop(d, x.cuda(), w.cuda(), want_stats=True)
+  ref = _ref_conv(x, w, stride)
+  _check(y, ref, name='fprop tile %d' % tile)
+  yb = y.float().view(-1, K)
+  M = yb.shape[0]
+  assert stats.shape[0] == (M + 127) // 128
+  for b in range(stats.shape[0]):
+    blk = yb[b * 128:(b + 1) * 128]
+    assert torch.allclose(stats[b, 0], blk.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(stats[b, 1], (blk * blk).sum(0), rtol=1e-4, atol=1e-2)
+  dy = _rand(tuple(ref.shape), 23)
+  wt = torch.zeros((Cn, k, k, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w.cuda(), wt, K, k, k, Cn)
+  dx = ops.conv_dgrad(d, dy.cuda(), wt)
+  monkeypatch.setenv('ASM_IGEMM_TILE', '1')
+  dx1 = ops.conv_dgrad(d, dy.cuda(), wt)
+  y1, _ = ops.conv_fprop(d, x.cuda(), w.cuda())
+  # same K-order of accumulation in every tile config -> identical bits
+  assert torch.equal(dx, dx1) and torch.equal(y, y1)

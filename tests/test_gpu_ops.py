@@ -96,6 +96,16 @@ def test_bn_train_fwd_bwd(hip_lib, shape, relu, res_mode):
   _close(dx, _nhwc(grads[0]), rel=6e-3, name='bn dx')
   assert util.rel_l2(dgamma.cpu(), grads[1]) <= 2e-3
   assert util.rel_l2(dbeta.cpu(), grads[2]) <= 2e-3
+  if relu:  # the packed 1-bit ReLU mask path must reproduce the bf16-output path bit for bit
+    y2, mask = ops.bn_apply(xd, M, Cn, scale, shift, res.cuda() if res is not None else None, res_mode, True, H, W,
+                            want_mask=True)
+    assert torch.equal(y2, y) and mask.shape == (M, Cn // 8)
+    bits = ((mask.cpu().to(torch.int32)[:, :, None] >> torch.arange(8, dtype=torch.int32)) & 1).view(M, Cn)
+    assert torch.equal(bits.bool(), (y.float().cpu().view(M, Cn) > 0))
+    dg2, db2 = torch.empty(Cn, device='cuda'), torch.empty(Cn, device='cuda')
+    dx2, dz2 = ops.bn_bwd(dout.cuda(), xd, mask, True, M, Cn, gd, mean, invstd, dg2, db2, want_dz)
+    assert torch.equal(dx2, dx) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
+    assert (dz2 is None and dz is None) or torch.equal(dz2, dz)
   if want_dz:
     dres_ref = _nhwc(grads[3])
     if res_mode == 2:
