@@ -14,6 +14,7 @@
 // [split][Co][cols]; asm_wgrad_reduce sums the slabs in a fixed order (no atomics ->
 // bit-reproducible).  With one split the tile goes straight to dW.
 #include "common.h"
+#include <math.h>
 
 namespace {
 
@@ -75,7 +76,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const int cbase = wc * (BNW == 128 ? 64 : 32);   // wave's first column within the tile
 
   // block -> (split, tile_n, tile_c): tiles of one split adjacent (they re-read the same pixels)
-  int bid = blockIdx.x;
+  // XCD-aware bijective remap (block b runs on XCD b % 8, each XCD has its own L2): give every XCD a
+  // contiguous range of logical blocks, i.e. whole pixel ranges (splits) / whole dy row-tiles, so the tiles
+  // that share operands hit the same L2 instead of every XCD re-fetching every operand from HBM.
+  int bid;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int tiles = p.tiles_n * p.tiles_c;
   const int split = bid / tiles;
   bid -= split * tiles;
@@ -273,15 +282,29 @@ Plan make_plan(const asm_conv_desc* d) {
   pl.tiles_c = cdiv(cols, WT);
   const int tiles = pl.tiles_n * pl.tiles_c;
   const int msteps = cdiv(M, WPX);
-  int splits = cdiv(pl.bnw == 128 ? 512 : 768, tiles);   // ~2-3 resident blocks per CU
-  if (tiles >= 192) splits = 1;                            // enough tiles to fill the chip: no slabs at all
-  // the slab reduce moves (splits + 1) x |dW| fp32: cap the slab footprint at 48 MiB
+  // Split count from a small cost model (microseconds): the MFMA/stream time scales with how evenly
+  // tiles*splits blocks fill the resident slots (256 CUs x 2..4 workgroups), the slab path costs
+  // (splits + 1) x |dW| of fp32 traffic.  With the XCD-contiguous block order every split's pixel range stays
+  // on one XCD's L2, so extra splits do not add HBM reads of x / dy.
   const size_t wbytes = (size_t)d->K * cols * sizeof(float);
-  const int cap = (int)((48u << 20) / wbytes) > 1 ? (int)((48u << 20) / wbytes) : 1;
-  if (splits > cap) splits = cap;
-  splits = splits < 1 ? 1 : splits;
-  const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;  // at least 4 steps per block
-  if (splits > max_splits) splits = max_splits;
+  const double flops = 2.0 * (double)M * d->K * cols;
+  const double io_bytes = 2.0 * ((double)M * d->C + (double)M * d->K);
+  const double work_us = fmax(flops / 6.0e8, io_bytes / 4.0e6);      // ~600 TFLOP/s or ~4 TB/s
+  const int slots = 256 * (pl.bnw == 128 ? 2 : (pl.bnw == 64 ? 3 : 4));
+  const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;            // at least 4 steps per block
+  int splits = 1;
+  double best = 1e30;
+  for (int sp = 1; sp <= 256 && sp <= max_splits; ++sp) {
+    const double blocks = (double)tiles * sp;
+    const double fill = ceil(blocks / slots) / (blocks / slots);      // >= 1: quantisation of the last round
+    const double under = blocks < slots ? (double)slots / blocks * 0.5 + 0.5 : 1.0;  // too few blocks: less overlap
+    const double slab = sp > 1 ? (double)(sp + 1) * wbytes / 4.0e6 + 4.0 : 0.0;
+    const double est = work_us * (blocks < slots ? under : fill) + slab;
+    if (est < best) {
+      best = est;
+      splits = sp;
+    }
+  }
   int steps_per = cdiv(msteps, splits);
   pl.m_per_split = steps_per * WPX;
   pl.splits = cdiv(M, pl.m_per_split);
