@@ -173,12 +173,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
       const unsigned off = (unsigned)(wb[j] + tap_off) * 2u;
       wr[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? off : ASM_OOB, 0, 0);
     }
-    // advance cursor
-    if (++kt_c == p.kchunks) {
-      kt_c = 0;
-      if (++kt_s == p.S) {
-        kt_s = 0;
-        ++kt_r;
+    // advance cursor: taps innermost, channel chunk outermost.  Consecutive K-steps then re-read (almost)
+    // the same pixels shifted by one tap, which hit L1/L2; with the chunk loop innermost the 9 tap passes of
+    // a 3x3 layer were a whole activation tile apart and each re-fetched it from HBM (PMC: 4.5x over-fetch).
+    if (++kt_s == p.S) {
+      kt_s = 0;
+      if (++kt_r == p.R) {
+        kt_r = 0;
+        ++kt_c;
       }
     }
   };
@@ -240,11 +242,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + (j * RPP + wrow0) * ROWB), 16, 0, 0);
       }
     }
-    if (++kt_c == p.kchunks) {
-      kt_c = 0;
-      if (++kt_s == p.S) {
-        kt_s = 0;
-        ++kt_r;
+    if (++kt_s == p.S) {
+      kt_s = 0;
+      if (++kt_r == p.R) {
+        kt_r = 0;
+        ++kt_c;
       }
     }
   };

@@ -217,9 +217,16 @@ def main():
       n, ms = timer.summary()[dominant]
       fl = conv_flops(dominant)
       ach = fl / (ms / n * 1e-3) / 1e12
+      kname = 'conv %s N%d %dx%dx%d -> %d, %dx%d/%d' % dominant
+      traffic = None
+      try:  # PMC traffic of this kernel class from the committed rocprofv3 --pmc passes (profiles/)
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')))
+        traffic = pmc.get(kname, {}).get('traffic_bytes')
+      except (OSError, ValueError):
+        pass
       out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
-                         'kernel': 'conv %s N%d %dx%dx%d -> %d, %dx%d/%d' % dominant,
+                         'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
+                         'kernel': kname,
                          'launches_timed': n, 'avg_launch_ms': round(ms / n, 4), 'flops_per_launch': fl}
     if world == 1 and not args.no_cpu_baseline:
       try:
