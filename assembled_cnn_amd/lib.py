@@ -86,6 +86,13 @@ SIGNATURES = {
     'asm_mean_f32': (_I, [_P, _I, _P, _P]),
     'asm_mixup_meansub': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'asm_mixup_labels': (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    'asm_sigmoid_ce': (_I, [_P, _I, _P, _I, _I, _F, _P, _P, _P, _I, _P]),
+    'asm_gem_fwd': (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    'asm_gem_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    'asm_dropblock_mask': (_I, [_P, _F, _I, _I, _I, _I, _P, _P, _P]),
+    'asm_dropblock_apply': (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    'asm_eval_rows': (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    'asm_eval_accumulate': (_I, [_P, _P, _P, _I, _P, _P]),
     'asm_sgd_momentum': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P]),
 }
 

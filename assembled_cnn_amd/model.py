@@ -58,9 +58,7 @@ class Model(object):
       raise NotImplementedError('the MI355X path computes in bf16 (fp32 master weights); got dtype=%s' % dtype)
     if data_format not in (None, 'channels_last'):
       raise NotImplementedError('the MI355X path is NHWC (channels_last) only')
-    if pool_type != 'gap':
-      if pool_type in ('gem', 'flatten'):
-        raise NotImplementedError('pool_type=%s is not implemented on the HIP path yet' % pool_type)
+    if pool_type not in ('gap', 'gem', 'flatten'):
       raise NotImplementedError
     if loss_type == 'softmax':
       self.dense_bias_init = 0.0
@@ -99,6 +97,7 @@ class Model(object):
     self.taps: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     self.ldc = nn._round_up(num_classes, 8) if num_classes else 0
     self._ctx: Optional[Ctx] = None
+    self._db_rng = None
 
   # -----------------------------------------------------------------------------------------------
   def build(self, input_hw=(224, 224), use_resnet_d=False, batch=2):
@@ -106,18 +105,20 @@ class Model(object):
     if self.arena.finalized:
       return
     ctx = Ctx(self.arena, True, True, self.bn_momentum, self.device, False, self._layers)
+    ctx.keep_prob = 1.0
     x = Var(None, (batch, input_hw[0] + 6, input_hw[1] + 6, 4), needs_grad=False)
     self._walk(ctx, x, use_resnet_d, False)
     self._built_with_d = use_resnet_d
     self.arena.finalize(self.device, self.seed)
 
   def __call__(self, inputs, training, reuse=False, use_resnet_d=False, keep_prob=1.0, return_embedding=False,
-               record_tape=None, prepadded=False):
+               record_tape=None, prepadded=False, dropblock_uniforms=None):
     """inputs: [N, H, W, 3] float32 / bfloat16 NHWC (already mean-subtracted), or with ``prepadded`` the
     zero-haloed [N, H+6, W+6, 4] bf16 buffer produced by ops.mixup_meansub.  Returns float32 logits
     [N, num_classes] (a view of the padded logits buffer)."""
-    if isinstance(keep_prob, float) and keep_prob != 1.0 and training:
-      raise NotImplementedError('DropBlock (keep_prob < 1) is not implemented on the HIP path yet')
+    keep_prob = float(keep_prob)
+    if not 0.0 < keep_prob <= 1.0:   # nets/blocks.py:218-220
+      raise ValueError('keep_prob must be a scalar tensor or a float in the range (0, 1], got %g' % keep_prob)
     if prepadded:
       xp = inputs
       hw = (inputs.shape[1] - 6, inputs.shape[2] - 6)
@@ -131,6 +132,14 @@ class Model(object):
       xp = ops.stem_pad_input(inputs.contiguous())
     tape = training if record_tape is None else record_tape
     ctx = Ctx(self.arena, training, False, self.bn_momentum, self.device, tape, self._layers)
+    # blocks.dropblock is the identity unless training with keep_prob < 1 (nets/blocks.py:208-213)
+    ctx.keep_prob = keep_prob if (training and keep_prob < 1.0) else 1.0
+    ctx.uniforms = iter(dropblock_uniforms) if dropblock_uniforms is not None else None
+    if ctx.keep_prob < 1.0 and ctx.uniforms is None:
+      if self._db_rng is None:
+        self._db_rng = torch.Generator(device=self.device)
+        self._db_rng.manual_seed(self.seed + 12345)
+      ctx.rng = self._db_rng
     out = self._walk(ctx, Var(xp, needs_grad=False), use_resnet_d, return_embedding)
     self.taps = ctx.taps
     self._ctx = ctx
@@ -146,28 +155,46 @@ class Model(object):
 
   # -----------------------------------------------------------------------------------------------
   def _bottleneck(self, ctx: Ctx, x: Var, filters, projection, strides, zero_gamma, aa_size, aa_type,
-                  last_relu=True, expansion=4) -> Var:
-    """_bottleneck_block_v1 (nets/resnet_model.py:35-97)."""
+                  last_relu=True, expansion=4, db_gamma_scale=None) -> Var:
+    """_bottleneck_block_v1 (nets/resnet_model.py:35-97).  db_gamma_scale: DropBlock gamma multiplier of this
+    stage (0.25 / 1.0 for stages 3 / 4, :434-453) or None; active only while training with keep_prob < 1."""
     L = ctx.layer
     cin = x.shape[3]
+    db = db_gamma_scale if (db_gamma_scale is not None and getattr(ctx, 'keep_prob', 1.0) < 1.0) else None
+    kp = getattr(ctx, 'keep_prob', 1.0)
     shortcut = x
     if projection is not None:
       shortcut = projection(x)
-    h = conv_bn(ctx, x, L(lambda: ConvKernel(ctx, 1, cin, filters)), L(lambda: BatchNorm(ctx, filters)), 1, relu=True)
+      if db is not None:
+        shortcut = nn.dropblock(ctx, shortcut, kp, db, relu=False)                      # :46-47
+    c1, b1 = L(lambda: ConvKernel(ctx, 1, cin, filters)), L(lambda: BatchNorm(ctx, filters))
+    if db is None:
+      h = conv_bn(ctx, x, c1, b1, 1, relu=True)
+    else:
+      h = nn.dropblock(ctx, conv_bn(ctx, x, c1, b1, 1, relu=False), kp, db, relu=True)   # BN -> dropblock -> relu
     s3 = 1 if 'sconv' in aa_type else strides
     if self.use_sk_block:
       h = L(lambda: SKUnit(ctx, filters, filters))(ctx, h, s3)
+      if db is not None:
+        h = nn.dropblock(ctx, h, kp, db, relu=False)                                     # :62-63
     else:
-      h = conv_bn(ctx, h, L(lambda: ConvKernel(ctx, 3, filters, filters)), L(lambda: BatchNorm(ctx, filters)), s3,
-                  relu=True)
+      c2, b2 = L(lambda: ConvKernel(ctx, 3, filters, filters)), L(lambda: BatchNorm(ctx, filters))
+      if db is None:
+        h = conv_bn(ctx, h, c2, b2, s3, relu=True)
+      else:
+        h = nn.dropblock(ctx, conv_bn(ctx, h, c2, b2, s3, relu=False), kp, db, relu=True)
     if 'sconv' in aa_type and strides != 1:
       h = nn.blur_pool(ctx, h, aa_size, strides)
     cout = expansion * filters
     conv3 = L(lambda: ConvKernel(ctx, 1, filters, cout))
     bn3 = L(lambda: BatchNorm(ctx, cout, zero_gamma=zero_gamma))
-    if self.use_se_block:
+    se = L(lambda: SEUnit(ctx, cout)) if self.use_se_block else None
+    if se is not None or db is not None:
       h = conv_bn(ctx, h, conv3, bn3, 1, relu=False)
-      h = L(lambda: SEUnit(ctx, cout))(ctx, h)
+      if db is not None:
+        h = nn.dropblock(ctx, h, kp, db, relu=False)                                     # :86-87
+      if se is not None:
+        h = se(ctx, h)
       return self._add_relu(ctx, h, shortcut, last_relu)
     return conv_bn(ctx, h, conv3, bn3, 1, relu=last_relu, residual=shortcut, res_mode=1)
 
@@ -187,7 +214,7 @@ class Model(object):
     return out
 
   def _block_layer(self, ctx: Ctx, x: Var, filters, num_blocks, strides, name, use_resnet_d=False,
-                   use_bl=False, last_relu=True, expansion=4) -> Var:
+                   use_bl=False, last_relu=True, expansion=4, db_gamma_scale=None) -> Var:
     """block_layer (nets/resnet_model.py:99-163)."""
     L = ctx.layer
     filters_out = filters * expansion
@@ -223,10 +250,11 @@ class Model(object):
       proj = projection_shortcut
 
     # first block: projection + stride + anti-alias args; last_relu is NOT forwarded (:151-155)
-    x = self._bottleneck(ctx, x, filters, proj, strides, self.zero_gamma, aa_size, aa_type, True, expansion)
+    x = self._bottleneck(ctx, x, filters, proj, strides, self.zero_gamma, aa_size, aa_type, True, expansion,
+                         db_gamma_scale)
     for i in range(1, num_blocks):     # :157-161
       x = self._bottleneck(ctx, x, filters, None, 1, self.zero_gamma, 0, "",
-                           last_relu if i == num_blocks - 1 else True, expansion)
+                           last_relu if i == num_blocks - 1 else True, expansion, db_gamma_scale)
     ctx.tap(name, x)
     return x
 
@@ -289,15 +317,16 @@ class Model(object):
     # ---- stages ----------------------------------------------------------------------------------
     for i, num_blocks in enumerate(self.block_sizes):
       num_filters = nf * (2 ** i)
+      dbs = {2: 0.25, 3: 1.0}.get(i)                       # dropblock_for_group3 / 4 (:434-453)
       if v2 and i < 3:                                    # :455-516
         ctx.push_scope('stage{}'.format(i + 1))
         ctx.push_scope('big{}'.format(i + 1))
         big = self._block_layer(ctx, x, num_filters, num_blocks - 1, 2, 'big{}'.format(i + 1),
-                                use_bl=True, last_relu=False)
+                                use_bl=True, last_relu=False, db_gamma_scale=dbs)
         ctx.pop_scope()
         ctx.push_scope('little{}'.format(i + 1))
         little = self._block_layer(ctx, x, num_filters // self.alpha, max(1, num_blocks // self.beta - 1), 1,
-                                   'little{}'.format(i + 1), use_bl=True)
+                                   'little{}'.format(i + 1), use_bl=True, db_gamma_scale=dbs)
         cin_l = little.shape[3]
         ce = L(lambda: ConvKernel(ctx, 1, cin_l, num_filters * 4))
         be = L(lambda: BatchNorm(ctx, num_filters * 4))
@@ -305,20 +334,27 @@ class Model(object):
         # relu(BN(little_e) + UpSampling2D(big)) :493-501
         x = conv_bn(ctx, little, ce, be, 1, relu=True, residual=big, res_mode=2)
         ctx.push_scope('merge{}'.format(i + 1))
-        x = self._block_layer(ctx, x, num_filters, 1, self.block_strides[i], 'merge{}'.format(i + 1), use_bl=True)
+        x = self._block_layer(ctx, x, num_filters, 1, self.block_strides[i], 'merge{}'.format(i + 1), use_bl=True,
+                              db_gamma_scale=dbs)
         ctx.pop_scope()
         ctx.pop_scope()
       elif v2 and i == 3:                                 # :518-534
         ctx.push_scope('stage{}'.format(i + 1))
         x = self._block_layer(ctx, x, num_filters, num_blocks, self.block_strides[i],
-                              'block_layer{}'.format(i + 1), use_resnet_d=use_resnet_d, use_bl=True)
+                              'block_layer{}'.format(i + 1), use_resnet_d=use_resnet_d, use_bl=True,
+                              db_gamma_scale=dbs)
         ctx.pop_scope()
       else:                                               # :536-549
         x = self._block_layer(ctx, x, num_filters, num_blocks, self.block_strides[i],
-                              'block_layer{}'.format(i + 1), use_resnet_d=use_resnet_d)
+                              'block_layer{}'.format(i + 1), use_resnet_d=use_resnet_d, db_gamma_scale=dbs)
 
     # ---- head :555-599 ---------------------------------------------------------------------------
-    x = nn.global_avg_pool(ctx, x)
+    if self.pool_type == 'gap':                           # :560-569
+      x = nn.global_avg_pool(ctx, x)
+    elif self.pool_type == 'gem':
+      x = nn.gem_pool(ctx, x)
+    else:
+      x = nn.flatten_pool(ctx, x)
     ctx.tap('final_reduce_mean', x)
     if self.embedding_size > 0:
       cin_e = x.shape[3]

@@ -237,6 +237,8 @@ class Ctx(object):
     self.layers = layers if layers is not None else []
     self._cursor = 0
     self.dlogits = None
+    self.uniforms = None      # iterator of DropBlock uniform draws supplied by the caller (tests)
+    self.rng = None           # torch.Generator for DropBlock when none are supplied
     self.training = training
     self.dry = dry
     self.bn_momentum = bn_momentum
@@ -245,6 +247,15 @@ class Ctx(object):
     self.taps: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     self._scope: List[str] = []
     self._counters: Dict[Tuple[str, str], int] = {}
+
+  def next_uniform(self, shape):
+    """tf.random_uniform draw of one DropBlock call: float32 [H-6, W-6, C]."""
+    if self.uniforms is not None:
+      u = next(self.uniforms)
+      if tuple(u.shape) != tuple(shape):
+        raise ValueError('dropblock uniform has shape %s, expected %s' % (tuple(u.shape), tuple(shape)))
+      return u.contiguous()
+    return torch.rand(shape, generator=self.rng, device=self.device, dtype=torch.float32)
 
   def layer(self, factory):
     """Layer objects are created once (in walk order, during the shape-only build pass) and re-used."""
@@ -612,6 +623,71 @@ def global_avg_pool(ctx: Ctx, x: Var) -> Var:
   if ctx.tape is not None:
     def bwd():
       accum_grad(x, ops.gap_bwd(y.grad, x.shape), True)
+      y.grad = None
+    ctx.record(bwd)
+  return y
+
+
+def gem_pool(ctx: Ctx, x: Var, p: float = 3.0) -> Var:
+  """blocks.generalized_mean_pooling (nets/blocks.py:22-42)."""
+  N, H, W, Cn = x.shape
+  if ctx.dry:
+    return Var(None, (N, 1, 1, Cn))
+  y_t, ssum = ops.gem_fwd(x.data, p)
+  y = Var(y_t)
+  if ctx.tape is not None:
+    x_t = x.data
+
+    def bwd():
+      accum_grad(x, ops.gem_bwd(x_t, y.grad, ssum, p), True)
+      y.grad = None
+    ctx.record(bwd)
+  return y
+
+
+def flatten_pool(ctx: Ctx, x: Var) -> Var:
+  """pool_type == 'flatten' (nets/resnet_model.py:565-569): NHWC flatten, kept as a [N,1,1,H*W*C] tensor."""
+  N, H, W, Cn = x.shape
+  if ctx.dry:
+    return Var(None, (N, 1, 1, H * W * Cn))
+  y = Var(x.data.view(N, 1, 1, H * W * Cn))
+  if ctx.tape is not None:
+    def bwd():
+      accum_grad(x, y.grad.view(N, H, W, Cn), False)
+      y.grad = None
+    ctx.record(bwd)
+  return y
+
+
+DROPBLOCK_SIZE = 7  # nets/resnet_model.py:434-439
+
+
+def dropblock(ctx: Ctx, x: Var, keep_prob: float, gamma_scale: float, relu: bool) -> Var:
+  """blocks.dropblock (nets/blocks.py:191-251) [+ the tf.nn.relu that follows it in the block].
+  One Bernoulli seed mask per call, shared by the whole batch; draws come from ctx.next_uniform."""
+  N, H, W, Cn = x.shape
+  if ctx.dry:
+    return Var(None, x.shape)
+  bs = DROPBLOCK_SIZE
+  gamma = gamma_scale * (1. - keep_prob) * (W * H) / (bs ** 2) / ((W - bs + 1) * (H - bs + 1))
+  u = ctx.next_uniform((H - bs + 1, W - bs + 1, Cn))
+  keep, scale = ops.dropblock_mask(u, float(gamma), H, W, Cn, bs)
+  y = Var(ops.dropblock_apply(x.data, keep, scale, relu=relu))
+  if ctx.tape is not None:
+    def bwd():
+      accum_grad(x, ops.dropblock_apply(y.grad, keep, scale, relu_mask_from=y.data if relu else None), True)
+      y.grad = None
+    ctx.record(bwd)
+  return y
+
+
+def relu_layer(ctx: Ctx, x: Var) -> Var:
+  if ctx.dry:
+    return Var(None, x.shape)
+  y = Var(ops.relu_fwd(x.data))
+  if ctx.tape is not None:
+    def bwd():
+      accum_grad(x, ops.relu_bwd(y.grad, y.data), True)
       y.grad = None
     ctx.record(bwd)
   return y

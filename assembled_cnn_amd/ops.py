@@ -484,3 +484,60 @@ def mixup_labels(y, mixup_type, lam1, lam2):
 def sgd_momentum(w, accum, grad, w_bf16, lr, momentum, weight_decay, grad_scale):
   check(L().asm_sgd_momentum(_ptr(w), _ptr(accum), _ptr(grad), _ptr(w_bf16), w.numel(), lr, momentum, weight_decay,
                              grad_scale, _stream()), 'sgd_momentum')
+
+
+# ---------------------------------------------------------------------------------------------------
+# sigmoid loss, GeM, DropBlock, evaluation metrics
+# ---------------------------------------------------------------------------------------------------
+def sigmoid_ce(logits, ld, targets, B, Cn, loss_scale, ld_out, want_grad=True):
+  """-> (loss_out [2] = {loss, sum(onehot)}, dlogits bf16 [B,1,1,ld_out])"""
+  rows = empty((B, 2), F32, logits)
+  out = empty((2,), F32, logits)
+  dz = empty((B, 1, 1, ld_out), BF16, logits) if want_grad else None
+  check(L().asm_sigmoid_ce(_ptr(logits), ld, _ptr(targets), B, Cn, loss_scale, _ptr(rows), _ptr(out), _ptr(dz), ld_out,
+                           _stream()), 'sigmoid_ce')
+  return out, dz
+
+
+def gem_fwd(x, p=3.0):
+  N, H, W, Cn = x.shape
+  y = empty((N, 1, 1, Cn), BF16, x)
+  ssum = empty((N, Cn), F32, x)
+  check(L().asm_gem_fwd(_ptr(x), _ptr(y), _ptr(ssum), N, H * W, Cn, p, _stream()), 'gem_fwd')
+  return y, ssum
+
+
+def gem_bwd(x, dy, ssum, p=3.0):
+  N, H, W, Cn = x.shape
+  dx = torch.empty_like(x)
+  check(L().asm_gem_bwd(_ptr(x), _ptr(dy), _ptr(ssum), _ptr(dx), N, H * W, Cn, p, _stream()), 'gem_bwd')
+  return dx
+
+
+def dropblock_mask(uniform, gamma, H, W, Cn, block_size):
+  keep = empty((H, W, Cn), F32, uniform)
+  scale = empty((1,), F32, uniform)
+  check(L().asm_dropblock_mask(_ptr(uniform), gamma, H, W, Cn, block_size, _ptr(keep), _ptr(scale), _stream()),
+        'dropblock_mask')
+  return keep, scale
+
+
+def dropblock_apply(x, keep, scale, relu=False, relu_mask_from=None):
+  N = x.shape[0]
+  y = torch.empty_like(x)
+  check(L().asm_dropblock_apply(_ptr(x), _ptr(keep), _ptr(scale), _ptr(relu_mask_from), 1 if relu else 0, _ptr(y), N,
+                                x.numel() // N, _stream()), 'dropblock_apply')
+  return y
+
+
+def eval_rows(logits, ld, labels_i32, B, Cn):
+  pred = empty((B,), torch.int32, logits)
+  vals = empty((3, B), F32, logits)
+  check(L().asm_eval_rows(_ptr(logits), ld, _ptr(labels_i32), B, Cn, _ptr(pred), _ptr(vals[0]), _ptr(vals[1]),
+                          _ptr(vals[2]), _stream()), 'eval_rows')
+  return pred, vals[0], vals[1], vals[2]
+
+
+def eval_accumulate(conf, top1, top5, state33):
+  check(L().asm_eval_accumulate(_ptr(conf), _ptr(top1), _ptr(top5), conf.numel(), _ptr(state33), _stream()),
+        'eval_accumulate')

@@ -121,6 +121,22 @@ def learning_rate_with_decay(learning_rate_decay_type, batch_size, batch_denom, 
   return learning_rate_fn
 
 
+def keep_prob_decay(starter_kp: float, end_kp: float, decay_steps: int) -> Callable[[int], float]:
+  """functions/model_fns.py:26-33: tf.train.polynomial_decay(power=1, cycle=False) of the DropBlock keep_prob."""
+  def keep_prob_decay_fn(global_step: int) -> float:
+    s = min(global_step, decay_steps)
+    return (starter_kp - end_kp) * (1.0 - s / decay_steps) + end_kp
+  return keep_prob_decay_fn
+
+
+def keep_prob_fn_from_hparams(p: "HParams") -> Optional[Callable[[int], float]]:
+  """model_fn_cls wiring (functions/model_fns.py:221-226)."""
+  if not p.use_dropblock:
+    return None
+  batches_per_epoch = p.num_images_train / p.batch_size
+  return keep_prob_decay(p.dropblock_kp[0], p.dropblock_kp[1], int(p.train_epochs * batches_per_epoch))
+
+
 def lr_fn_from_hparams(p: HParams) -> Callable[[int], float]:
   """model_fn_cls wiring (functions/model_fns.py:208-219): batch_denom == batch_size."""
   return learning_rate_with_decay(p.learning_rate_decay_type, p.batch_size, p.batch_size, p.num_images_train,
@@ -137,7 +153,9 @@ class Trainer(object):
     self.p = hparams
     self.model = hparams.make_model(seed, device)
     self.lr_fn = lr_fn_from_hparams(hparams)
+    self.keep_prob_fn = keep_prob_fn_from_hparams(hparams)
     self.global_step = 0
+    self.eval_state = None
     self.grad_sync = grad_sync
     self.world_size = world_size
     self.last = {}
@@ -165,13 +183,19 @@ class Trainer(object):
       raise ValueError('mixup needs the Beta(0.2, 0.2) draws (lam1 [, lam2])')
     x = ops.mixup_meansub(images.contiguous(), mt, lam1, lam2)
     if mt:
+      onehot_src = onehot
       onehot = ops.mixup_labels(onehot, mt, lam1, lam2)
       if teacher is not None:
         if mt == 2:
-          # the reference mixes the second-half teacher targets from the HARD labels y1 (data_util.py:154);
-          # reproduce: first half from teacher, second half = lam2*y1 + (1-lam2)*reverse(y2_t)
-          raise NotImplementedError('mixup_type=2 together with KD is not implemented on the HIP path')
-        teacher = ops.mixup_labels(teacher, mt, lam1, lam2)
+          # the reference mixes the second-half teacher targets from the HARD labels y1, not y1_t
+          # (utils/data_util.py:154).  Reproduced: first half = type-1 mix of the teacher; second half = the
+          # type-2 mix of [y1 ; y2_t], whose second half is lam2*y1 + (1-lam2)*reverse(y2_t).
+          half = Bin // 2
+          first = ops.mixup_labels(teacher, 1, lam1, None)
+          second = ops.mixup_labels(torch.cat([onehot_src[:half], teacher[half:]], 0).contiguous(), 2, lam1, lam2)
+          teacher = torch.cat([first, second[half:]], 0).contiguous()
+        else:
+          teacher = ops.mixup_labels(teacher, mt, lam1, lam2)
     return x, onehot, teacher
 
   def sample_mixup_lambdas(self, n: int, alpha: float = 0.2, rng=None):
@@ -182,17 +206,27 @@ class Trainer(object):
     return torch.from_numpy(lam).to(self.model.device)
 
   # -----------------------------------------------------------------------------------------------
-  def train_step(self, images, labels, lam1=None, lam2=None, lr: Optional[float] = None):
+  def train_step(self, images, labels, lam1=None, lam2=None, lr: Optional[float] = None,
+                 dropblock_uniforms=None):
     p = self.p
     m = self.model
     x, onehot, teacher = self.prepare_inputs(images, labels, lam1, lam2)
     B = x.shape[0]
-    m(x, True, use_resnet_d=p.use_resnet_d, prepadded=True)
-    if p.cls_loss_type != 'softmax':
-      raise NotImplementedError('cls_loss_type=%s is not implemented on the HIP path' % p.cls_loss_type)
+    keep_prob = self.keep_prob_fn(self.global_step) if self.keep_prob_fn else 1.0
+    m(x, True, use_resnet_d=p.use_resnet_d, prepadded=True, keep_prob=keep_prob,
+      dropblock_uniforms=dropblock_uniforms)
     loss_scale = p.get_loss_scale()
-    loss_rows, dlogits = ops.softmax_ce(m.logits_padded, m.ldc, onehot, teacher, B, p.num_classes,
-                                        p.label_smoothing, p.kd_temp, loss_scale, m.ldc)
+    sig = None
+    if p.cls_loss_type == 'softmax':      # losses/cls_losses.py:27-33 (+ KD, run_loop_classification.py:156-162)
+      loss_rows, dlogits = ops.softmax_ce(m.logits_padded, m.ldc, onehot, teacher, B, p.num_classes,
+                                          p.label_smoothing, p.kd_temp, loss_scale, m.ldc)
+    elif p.cls_loss_type == 'sigmoid':    # losses/cls_losses.py:34-38
+      if teacher is not None:
+        raise NotImplementedError('KD on top of the sigmoid loss is not implemented on the HIP path')
+      sig, dlogits = ops.sigmoid_ce(m.logits_padded, m.ldc, onehot, B, p.num_classes, loss_scale, m.ldc)
+      loss_rows = sig[:1]
+    else:
+      raise AssertionError('cross_entropy is None')   # losses/cls_losses.py:40
     m.backward(dlogits)
     a = m.arena
     if self.grad_sync is not None:
@@ -206,7 +240,7 @@ class Trainer(object):
       ops.sgd_momentum(a.w32[nd:], a.m32[nd:], a.g32[nd:], a.w16[nd:], lr, p.momentum, 0.0, gs)
     a.refresh_derived()
     self.global_step += 1
-    self.last = {'loss_rows': loss_rows, 'lr': lr}
+    self.last = {'loss_rows': loss_rows, 'lr': lr, 'keep_prob': keep_prob}
     return loss_rows
 
   def cross_entropy(self) -> torch.Tensor:
@@ -222,3 +256,30 @@ class Trainer(object):
   def eval_logits(self, images_meansub_nhwc: torch.Tensor) -> torch.Tensor:
     """Inference forward (BN moving statistics), logits float32 [B, C]."""
     return self.model(images_meansub_nhwc, False, use_resnet_d=self.p.use_resnet_d)
+
+  # ---- evaluation metrics on device (nets/run_loop_classification.py:208-219) ----------------------
+  def eval_reset(self):
+    self.eval_state = torch.zeros((33,), dtype=torch.float32, device=self.model.device)
+
+  def eval_step(self, images_meansub_nhwc: torch.Tensor, labels: torch.Tensor):
+    """One evaluation batch: forward with moving statistics, then accuracy / top-5 / ECE-bin accumulation
+    on the device.  Returns the predicted classes (int32)."""
+    if self.eval_state is None:
+      self.eval_reset()
+    m = self.model
+    self.eval_logits(images_meansub_nhwc)
+    B = images_meansub_nhwc.shape[0]
+    pred, conf, top1, top5 = ops.eval_rows(m.logits_padded, m.ldc, labels.to(torch.int32).contiguous(), B,
+                                           self.p.num_classes)
+    ops.eval_accumulate(conf, top1, top5, self.eval_state)
+    return pred
+
+  def eval_result(self) -> dict:
+    """{'accuracy', 'accuracy_top_5', 'ece'} from the running state (metric/ece_metric.py:271-279)."""
+    st = self.eval_state.double().cpu()
+    n = float(st[2])
+    correct, conf, cnt = st[3:13], st[13:23], st[23:33]
+    eps = 1e-7
+    ece = float(((cnt / cnt.sum()) * ((correct / (eps + cnt)) - (conf / (eps + cnt))).abs()).sum()) if n else 0.0
+    return {'accuracy': float(st[0]) / n if n else 0.0, 'accuracy_top_5': float(st[1]) / n if n else 0.0, 'ece': ece,
+            'count': n}

@@ -243,6 +243,35 @@ int asm_mixup_labels(const float* y, int Bin, int C, int mixup_type, const float
 int asm_sgd_momentum(float* w, float* accum, const float* grad, void* w_bf16, size_t n, float lr,
                      float momentum, float weight_decay, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Remaining loss / pooling variants and the "next" rows of the scope table
+ * ---------------------------------------------------------------------------------------------- */
+/* cls_loss_type == 'sigmoid' (losses/cls_losses.py:34-38): loss_out[0] = sum(sigmoid_ce) / sum(onehot),
+ * loss_out[1] = sum(onehot); dlogits bf16 [B][ld_out] = loss_scale * (sigmoid(z) - y) / sum(onehot).
+ * rows_ws: float32 [B][2] scratch. */
+int asm_sigmoid_ce(const float* logits, int ld, const float* targets, int B, int C, float loss_scale,
+                   float* rows_ws, float* loss_out, void* dlogits, int ld_out, void* stream);
+/* blocks.generalized_mean_pooling (nets/blocks.py:22-42): [N,HW,C] -> [N,C]; ssum [N,C] float32 is kept for
+ * the backward pass. */
+int asm_gem_fwd(const void* x, void* y, float* ssum, int N, int HW, int C, float p, void* stream);
+int asm_gem_bwd(const void* x, const void* dy, const float* ssum, void* dx, int N, int HW, int C, float p,
+                void* stream);
+/* blocks.dropblock (nets/blocks.py:191-251).  uniform: float32 [H-bs+1, W-bs+1, C] draws of tf.random_uniform
+ * (ONE mask for the whole batch); keep: float32 [H,W,C] = 1 - maxpool_bs(pad(relu(sign(gamma - u))));
+ * scale[0] = H*W*C / (sum(keep) + 1e-8).  apply: y = [relu](x * keep * scale); for the backward pass call it
+ * on dy with relu_mask_from = the forward output (dx = dy * keep * scale * [y > 0]) or NULL (no fused ReLU). */
+int asm_dropblock_mask(const float* uniform, float gamma, int H, int W, int C, int block_size, float* keep,
+                       float* scale, void* stream);
+int asm_dropblock_apply(const void* x, const float* keep, const float* scale, const void* relu_mask_from, int relu,
+                        void* y, int N, int HWC, void* stream);
+/* Evaluation metrics (nets/run_loop_classification.py:208-219): per row arg-max, max softmax probability,
+ * top-1 hit and tf.nn.in_top_k(k=5) hit; accumulate adds a batch into the 33-float running state
+ * {sum top1, sum top5, count, correct[10], confidence[10], count[10]} of metric/ece_metric.py:171-298. */
+int asm_eval_rows(const float* logits, int ld, const int32_t* labels, int B, int C, int32_t* pred, float* conf,
+                  float* top1, float* top5, void* stream);
+int asm_eval_accumulate(const float* conf, const float* top1, const float* top5, int B, float* state33,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

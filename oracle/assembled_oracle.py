@@ -603,14 +603,19 @@ class Model(object):
         ctx.tap('initial_max_pool', x)
 
     se_fn = (lambda t: se_block(ctx, t, ratio=16)) if self.use_se_block else None
-    db_iter = iter(dropblock_uniforms) if dropblock_uniforms is not None else None
+    # DropBlock draws: an iterable of [1, C, H-6, W-6] tensors, or a callable shape -> tensor
+    db_iter = (iter(dropblock_uniforms) if (dropblock_uniforms is not None and not callable(dropblock_uniforms))
+               else None)
 
     def make_dropblock(gamma_scale):
       if not training or (isinstance(keep_prob, float) and keep_prob == 1.0):
         return None  # blocks.dropblock returns x unchanged (:208-213)
 
       def fn(t):
-        u = next(db_iter)
+        if callable(dropblock_uniforms):
+          u = dropblock_uniforms((1, t.shape[1], t.shape[2] - 6, t.shape[3] - 6))
+        else:
+          u = next(db_iter)
         return dropblock(t, keep_prob, 7, gamma_scale, True, u)
       return fn
 

@@ -542,3 +542,82 @@ class CpuDouble(object):
     if wb:
       T(wb, (n,), 'bf16').copy_(tw)
     return 0
+
+  # ---- sigmoid loss / GeM / DropBlock / eval metrics ---------------------------------------------------
+  def asm_sigmoid_ce(self, logits, ld, targets, B, Cn, loss_scale, rows, out, dlogits, ld_out, stream):
+    z = T(logits, (B, ld), 'f32')[:, :Cn].clone().requires_grad_(True)
+    y = T(targets, (B, Cn), 'f32')
+    ce = F.binary_cross_entropy_with_logits(z, y, reduction='sum')
+    ys = y.sum()
+    loss = ce / ys
+    o = T(out, (2,), 'f32')
+    o[0] = loss.detach()
+    o[1] = ys
+    if dlogits:
+      (g,) = torch.autograd.grad(loss * loss_scale, z)
+      d = T(dlogits, (B, ld_out), 'bf16')
+      d.zero_()
+      d[:, :Cn] = g.to(torch.bfloat16)
+    return 0
+
+  def asm_gem_fwd(self, x, y, ssum, N, HW, Cn, p, stream):
+    v = T(x, (N, HW, Cn), 'bf16').float().clamp(1e-6, 1e12)
+    s = (v ** p).sum(1).clamp(min=1e-6)
+    T(ssum, (N, Cn), 'f32').copy_(s)
+    T(y, (N, Cn), 'bf16').copy_((HW ** (-1.0 / p)) * s ** (1.0 / p))
+    return 0
+
+  def asm_gem_bwd(self, x, dy, ssum, dx, N, HW, Cn, p, stream):
+    v = T(x, (N, HW, Cn), 'bf16').float().requires_grad_(True)
+    out = (HW ** (-1.0 / p)) * ((v.clamp(1e-6, 1e12) ** p).sum(1).clamp(min=1e-6)) ** (1.0 / p)
+    (g,) = torch.autograd.grad(out, v, T(dy, (N, Cn), 'bf16').float())
+    T(dx, (N, HW, Cn), 'bf16').copy_(g)
+    return 0
+
+  def asm_dropblock_mask(self, uniform, gamma, H, W, Cn, bs, keep, scale, stream):
+    u = T(uniform, (H - bs + 1, W - bs + 1, Cn), 'f32').permute(2, 0, 1)[None]
+    br = (bs - 1) // 2
+    tl = (bs - 1) - br
+    m = F.relu(torch.sign(gamma - u))
+    m = F.pad(m, (tl, br, tl, br))
+    pb = (bs - 1) // 2
+    m = F.max_pool2d(F.pad(m, (pb, bs - 1 - pb, pb, bs - 1 - pb), value=float('-inf')), bs, 1)
+    k = (1 - m)[0].permute(1, 2, 0).contiguous()
+    T(keep, (H, W, Cn), 'f32').copy_(k)
+    T(scale, (1,), 'f32').copy_((k.numel() / (k.sum() + 1e-8)).view(1))
+    return 0
+
+  def asm_dropblock_apply(self, x, keep, scale, relu_mask_from, relu, y, N, HWC, stream):
+    v = T(x, (N, HWC), 'bf16').float() * T(keep, (HWC,), 'f32') * T(scale, (1,), 'f32')
+    if relu_mask_from:
+      v = v * (T(relu_mask_from, (N, HWC), 'bf16').float() > 0)
+    elif relu:
+      v = F.relu(v)
+    T(y, (N, HWC), 'bf16').copy_(v)
+    return 0
+
+  def asm_eval_rows(self, logits, ld, labels, B, Cn, pred, conf, top1, top5, stream):
+    z = T(logits, (B, ld), 'f32')[:, :Cn]
+    lab = T(labels, (B,), 'i32').long()
+    p = z.argmax(1)
+    T(pred, (B,), 'i32').copy_(p.to(torch.int32))
+    T(conf, (B,), 'f32').copy_(torch.softmax(z, 1).max(1).values)
+    T(top1, (B,), 'f32').copy_((p == lab).float())
+    zl = z.gather(1, lab[:, None])
+    T(top5, (B,), 'f32').copy_(((z > zl).sum(1) < 5).float())
+    return 0
+
+  def asm_eval_accumulate(self, conf, top1, top5, B, state, stream):
+    c, t1, t5 = T(conf, (B,), 'f32'), T(top1, (B,), 'f32'), T(top5, (B,), 'f32')
+    st = T(state, (33,), 'f32')
+    st[0] += t1.sum()
+    st[1] += t5.sum()
+    st[2] += B
+    for b in range(10):
+      lo = -1e-7 if b == 0 else b / 10.0
+      hi = 1 + 1e-7 if b == 9 else (b + 1) / 10.0
+      sel = (c > lo) & (c <= hi)
+      st[3 + b] += t1[sel].sum()
+      st[13 + b] += c[sel].sum()
+      st[23 + b] += sel.sum()
+    return 0
