@@ -18,6 +18,14 @@ class AsmError(RuntimeError):
   pass
 
 
+class ImageDesc(C.Structure):
+  """struct asm_image_desc"""
+  _fields_ = [('src_offset', C.c_int64), ('Hs', C.c_int32), ('Ws', C.c_int32),
+              ('crop_y', C.c_int32), ('crop_x', C.c_int32), ('crop_h', C.c_int32), ('crop_w', C.c_int32),
+              ('resize_h', C.c_int32), ('resize_w', C.c_int32), ('out_y', C.c_int32), ('out_x', C.c_int32),
+              ('flip', C.c_int32), ('reserved', C.c_int32)]
+
+
 class ConvDesc(C.Structure):
   """struct asm_conv_desc"""
   _fields_ = [('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32),
@@ -94,6 +102,7 @@ SIGNATURES = {
     'asm_eval_rows': (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     'asm_eval_accumulate': (_I, [_P, _P, _P, _I, _P, _P]),
     'asm_sgd_momentum': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P]),
+    'asm_resize_crop_flip': (_I, [_P, C.c_int64, _P, _I, _I, _I, _I, _P, _P]),
 }
 
 _lib = None

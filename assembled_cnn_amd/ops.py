@@ -541,3 +541,15 @@ def eval_rows(logits, ld, labels_i32, B, Cn):
 def eval_accumulate(conf, top1, top5, state33):
   check(L().asm_eval_accumulate(_ptr(conf), _ptr(top1), _ptr(top5), conf.numel(), _ptr(state33), _stream()),
         'eval_accumulate')
+
+
+def resize_crop_flip(src_u8, descs_dev, n, out_h, out_w, subtract_mean):
+  """src_u8: 1-D uint8 device buffer with the decoded images back to back; descs_dev: uint8 device view of
+  n packed struct asm_image_desc (56 bytes each).  Returns float32 [n, out_h, out_w, 3]."""
+  if descs_dev.numel() != 56 * n:
+    raise ValueError('descriptor table must hold %d bytes' % (56 * n))
+  out = torch.empty((n, out_h, out_w, 3), dtype=torch.float32, device=src_u8.device)
+  if n:
+    check(L().asm_resize_crop_flip(_ptr(src_u8), src_u8.numel(), _ptr(descs_dev), n, out_h, out_w,
+                                   1 if subtract_mean else 0, _ptr(out), _stream()), 'resize_crop_flip')
+  return out

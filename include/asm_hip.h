@@ -272,6 +272,32 @@ int asm_eval_rows(const float* logits, int ld, const int32_t* labels, int B, int
 int asm_eval_accumulate(const float* conf, const float* top1, const float* top5, int B, float* state33,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input-pipeline tail: the tensor work of imagenet_preprocessing.preprocess_image after
+ * JPEG decode (preprocessing/imagenet_preprocessing.py:269-313), for a ragged batch of decoded uint8 images
+ * packed back to back in `src`:
+ *   window  = image[crop_y : crop_y+crop_h, crop_x : crop_x+crop_w]      (train: the sampled box of :57-90 /
+ *             tf.image.decode_and_crop_jpeg; eval: the whole image)
+ *   window  = flip_left_right(window) if flip                            (:94-96)
+ *   resized = tf.image.resize_images(window, [resize_h, resize_w], BILINEAR, align_corners=False)   (:210-225;
+ *             TF-1.14 legacy sampling without half-pixel centres, float32, no fused multiply-add)
+ *   out     = resized[out_y : out_y+out_h, out_x : out_x+out_w]          (central_crop :97-120; train: 0,0)
+ *   out    -= CHANNEL_MEANS if subtract_mean                             (mean_image_subtraction :122-155)
+ * out: float32 [N][out_h][out_w][3].  descs: DEVICE array of N descriptors.  A descriptor whose windows do not
+ * fit (the host mirror rejects those with ValueError) produces zeros for that image, never an out-of-range read.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asm_image_desc {
+  int64_t src_offset;                      /* byte offset of the image's [Hs][Ws][3] uint8 pixels in src   */
+  int32_t Hs, Ws;                          /* decoded size                                                   */
+  int32_t crop_y, crop_x, crop_h, crop_w;  /* window cut from the decoded image before the resize            */
+  int32_t resize_h, resize_w;              /* size the window is resized to                                  */
+  int32_t out_y, out_x;                    /* top-left of the output inside the resized window               */
+  int32_t flip;                            /* 1: window mirrored left-right before the resize                */
+  int32_t reserved;
+} asm_image_desc;                          /* 56 bytes */
+int asm_resize_crop_flip(const uint8_t* src, int64_t src_bytes, const asm_image_desc* descs, int N,
+                         int out_h, int out_w, int subtract_mean, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

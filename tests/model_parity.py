@@ -26,6 +26,8 @@ CONFIGS = {
                   anti_alias_filter_size=3),
     'a-r50-d': dict(resnet_size=50, resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
                     anti_alias_filter_size=3),
+    'a-r152': dict(resnet_size=152, resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
+                   anti_alias_filter_size=3, bl_alpha=1, bl_beta=2),
     'se-proj': dict(resnet_size=50, use_se_block=True, anti_alias_type='proj', anti_alias_filter_size=3),
 }
 

@@ -55,6 +55,23 @@ def test_variable_names_counts_and_flag_errors(cpu_double):
     m(torch.zeros(1, 64, 64, 3), False, use_resnet_d=True)   # variables were created without the D stem
 
 
+def test_assemble_r152_variables_match_oracle(cpu_double):
+  """BASELINE config 5 topology (A-R152, alpha 1, beta 2): same names, order and shapes as the oracle walk."""
+  from assembled_cnn_amd.model import Model, hwio_to_krsc
+  from oracle import assembled_oracle as O
+  kw = mp.CONFIGS['a-r152']
+  om = O.Model(num_classes=1001, **kw)
+  om(torch.zeros(1, 64, 64, 3), True)
+  pm = Model(num_classes=1001, device='cpu', **kw)
+  pm.build((64, 64))
+  assert pm.num_params() == 117006249 and len(pm.arena.specs) == 969
+  assert list(pm.arena.specs) == list(om.vars.trainable)
+  for n, t in om.vars.trainable.items():
+    want = tuple(hwio_to_krsc(t).shape) if t.dim() == 4 else (tuple(t.shape) if t.dim() == 1 else None)
+    if want is not None:
+      assert tuple(pm.arena.w(n).shape) == want, n
+
+
 def test_lr_schedule_and_hparams_match_reference_defaults():
   from assembled_cnn_amd import train
   from oracle import assembled_oracle as O
