@@ -46,7 +46,7 @@ def test_empty_batch_bad_descriptor_and_full_batch_properties(hip_lib):
   good = P.eval_window(50, 60, 32, 32)
   buf, table = P.pack_batch([im, im], [good, good], 32, 32)
   t = table.clone()
-  t.view(torch.int32)[14 + 4] = 9999            # second descriptor: crop_h beyond the image
+  t.view(torch.int32)[14 + 6] = 9999            # second descriptor: crop_h beyond the image
   out = ops.resize_crop_flip(buf.cuda(), t.cuda(), 2, 32, 32, True).cpu()
   assert np.array_equal(out[0].numpy(), IO.preprocess_eval(im, 32, 32)) and float(out[1].abs().max()) == 0.0
   # BASELINE-size batch (256 images): constant images stay constant, flipping twice is the identity,
