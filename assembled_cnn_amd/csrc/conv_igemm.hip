@@ -37,6 +37,7 @@ struct IGemmArgs {
   int x_img_pitch, x_row_pitch, x_pix_pitch;  // elements
   int w_row_pitch;  // elements between consecutive n rows of Wt (= R*S*Ci)
   int n_tiles_n, n_blocks, kchunks;
+  FastDiv fd_howo, fd_wo, fd_ntn;  // m -> (img, ho, wo), block -> (tile_m, tile_n) without integer division (igemm2_kernel)
 };
 
 // 16 zero bytes: the source of every masked lane of an LDS-DMA load (global_load_lds has no bounds check)
@@ -82,6 +83,115 @@ struct Cfg {
   static_assert(LDS <= 160 * 1024, "lds");
   static_assert(!STATS || BM % STATS_BM == 0, "stats granularity");
 };
+
+// Epilogue shared by both kernels.  acc[a][b][reg]: n_local = wn*WTN + a*32 + (reg&3) + 8*(reg>>2) + 4*lhi ;
+// m_local = wm*WTM + b*32 + l31.
+template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS>
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[TN][TM], unsigned char* smem,
+                                               int tile_m, int tile_n, int tid, int wm, int wn, int l31, int lhi) {
+  // ---------------- epilogue ----------------
+  // acc[a][b][reg]: n_local = wn*WTN + a*32 + (reg&3) + 8*(reg>>2) + 4*lhi ; m_local = wm*WTM + b*32 + l31
+  if constexpr (OUT_F32) {
+    float* y = reinterpret_cast<float*>(p.y);
+    const int co4 = (p.Co + 3) & ~3;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = tile_m * BM + wm * WTM + b * 32 + l31;
+        if (m < p.M) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = tile_n * BN + wn * WTN + a * 32 + 8 * g + 4 * lhi;
+            if (n < co4) {
+              f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+              *reinterpret_cast<f32x4*>(y + (size_t)m * p.ldy + n) = v;
+            }
+          }
+        }
+      }
+  } else {
+    constexpr int LDO = C::LDO, CPO = C::CPO, RPO = C::RPO, OP = C::OP;
+    unsigned char* os = smem;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int ml = wm * WTM + b * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn * WTN + a * 32 + 8 * g + 4 * lhi;
+          u32x2 v;
+          v.x = pack2bf(acc[a][b][4 * g], acc[a][b][4 * g + 1]);
+          v.y = pack2bf(acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+          *reinterpret_cast<u32x2*>(os + ml * LDO + nl * 2) = v;
+        }
+      }
+    __syncthreads();
+    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+    const int oc = tid % CPO, orow = tid / CPO;
+    const int n0 = tile_n * BN + oc * 8;
+    const int co8 = (p.Co + 7) & ~7;
+    // statistics partials are per STATS_BM (=128) rows: a 256-row tile emits two of them
+    constexpr int SG = STATS ? BM / STATS_BM : 1;
+    float s[SG][8], ss[SG][8];
+#pragma unroll
+    for (int q = 0; q < SG; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[q][e] = ss[q][e] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < OP; ++ps) {
+      const int row = ps * RPO + orow;
+      const int m = tile_m * BM + row;
+      u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
+      if (m < p.M && n0 < co8) {
+        if (p.addend) {
+          const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) +
+                                                           (size_t)m * p.ldy + n0);
+          float fv[8], fa[8];
+          unpack8(v, fv);
+          unpack8(av, fa);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += fa[e];
+          v = pack8(fv);
+        }
+        *reinterpret_cast<u32x4*>(y + (size_t)m * p.ldy + n0) = v;
+      }
+      if constexpr (STATS) {
+        constexpr int PPG = OP / SG;   // passes per statistics group (rows are pass-major)
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s[ps / PPG][e] += f[e];
+          ss[ps / PPG][e] += f[e] * f[e];
+        }
+      }
+    }
+    if constexpr (STATS) {
+      float* red = reinterpret_cast<float*>(smem);  // [RPO][2][BN], aliases the (now consumed) output tile
+#pragma unroll
+      for (int q = 0; q < SG; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[(orow * 2 + 0) * BN + oc * 8 + e] = s[q][e];
+          red[(orow * 2 + 1) * BN + oc * 8 + e] = ss[q][e];
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+          const int which = tid / BN, nl = tid - which * BN;
+          float t = 0.f;
+#pragma unroll 8
+          for (int g = 0; g < RPO; ++g) t += red[(g * 2 + which) * BN + nl];
+          const int n = tile_n * BN + nl;
+          const int mb = tile_m * SG + q;   // 128-row statistics block index
+          if (n < p.Co && mb * STATS_BM < p.M) p.stats[((size_t)mb * 2 + which) * p.Co + n] = t;
+        }
+      }
+    }
+  }
+}
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
@@ -333,108 +443,221 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
     }
   }
 
-  // ---------------- epilogue ----------------
-  // acc[a][b][reg]: n_local = wn*WTN + a*32 + (reg&3) + 8*(reg>>2) + 4*lhi ; m_local = wm*WTM + b*32 + l31
-  if constexpr (OUT_F32) {
-    float* y = reinterpret_cast<float*>(p.y);
-    const int co4 = (p.Co + 3) & ~3;
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// igemm2_kernel: the same tiling and epilogue with a main loop stripped of per-step address arithmetic.
+// PMC on the register-staged kernel showed ~10 VALU + 5 SALU instructions per MFMA (tap decode, bounds checks,
+// offset selects, exec-mask branches): the waves were issue-bound, not MFMA- or LDS-bound.  Here
+//   * every (staging row, filter tap) byte offset -- zero padding, stride-2 parity, row/channel tails folded in as
+//     the out-of-range offset -- is computed ONCE in the prologue into VGPRs (XP x R*S of them);
+//   * the K loop runs channel chunks outermost and the R*S taps fully unrolled innermost, so a step's loads are
+//     `buffer_load_dwordx4 ... lds` with a pre-computed voffset and the chunk advance in the scalar soffset:
+//     no VALU, no branches, no VGPR round trip (LDS-DMA zero-fills out-of-range lanes -- tools/probes);
+//   * m -> (img, ho, wo) uses multiply-shift division.
+// Requires R x S in {1x1, 3x3, 7x1, 3x1} and (Ci % BK == 0 or a single chunk); the rest stays on igemm_kernel.
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S>
+__global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
+  using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
+  constexpr int CPR = C::CPR, RPP = C::RPP, XP = C::XP, WP = C::WP, ROWB = C::ROWB, STAGE = C::STAGE;
+  constexpr int TM = C::TM, TN = C::TN, WTM = C::WTM, WTN = C::WTN;
+  constexpr int NTAP = R * S;
+  static_assert(RPP % 16 == 0, "the source-side swizzle must not depend on the pass");
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  int logical;
+  {
+    const int nb = p.n_blocks, q = nb >> 3, r = nb & 7;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = (int)fd_div((unsigned)logical, p.fd_ntn);
+  const int tile_n = logical - tile_m * p.n_tiles_n;
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+
+  const int chunk = tid % CPR;
+  const int r0 = tid / CPR;
+  const int csw = (chunk ^ swz<BK>(r0)) << 3;   // channel (element) offset of the 16-byte piece this lane fetches
+  const bool c_ok = csw < p.Ci;                  // only a single-chunk layer can have a channel tail
+
+  // ---- prologue: per-(row, tap) byte offsets of the activation tile, per-row offsets of the filter tile ----
+  unsigned vx[XP][NTAP];
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+  for (int j = 0; j < XP; ++j) {
+    const int m = tile_m * BM + r0 + j * RPP;
+    const bool live = c_ok && m < p.M;
+    const unsigned img = fd_div((unsigned)m, p.fd_howo);
+    const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
+    const unsigned ho = fd_div(rem, p.fd_wo);
+    const unsigned wo = rem - ho * (unsigned)p.Wo;
+    const int bh = (int)ho * p.so - p.pad, bw = (int)wo * p.so - p.pad;
+    const unsigned base = img * (unsigned)p.x_img_pitch + (unsigned)csw;
+    unsigned roff[R], coff[S];
+    bool rok[R], cok[S];
 #pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        const int m = tile_m * BM + wm * WTM + b * 32 + l31;
-        if (m < p.M) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = tile_n * BN + wn * WTN + a * 32 + 8 * g + 4 * lhi;
-            if (n < co4) {
-              f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-              *reinterpret_cast<f32x4*>(y + (size_t)m * p.ldy + n) = v;
-            }
-          }
-        }
+    for (int r = 0; r < R; ++r) {
+      int nh = bh + p.tsign * r;
+      bool ok = live;
+      if (p.sd == 2) {
+        ok = ok && ((nh & 1) == 0);
+        nh >>= 1;
       }
-  } else {
-    constexpr int LDO = C::LDO, CPO = C::CPO, RPO = C::RPO, OP = C::OP;
-    unsigned char* os = smem;
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        const int ml = wm * WTM + b * 32 + l31;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = wn * WTN + a * 32 + 8 * g + 4 * lhi;
-          u32x2 v;
-          v.x = pack2bf(acc[a][b][4 * g], acc[a][b][4 * g + 1]);
-          v.y = pack2bf(acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
-          *reinterpret_cast<u32x2*>(os + ml * LDO + nl * 2) = v;
-        }
-      }
-    __syncthreads();
-    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-    const int oc = tid % CPO, orow = tid / CPO;
-    const int n0 = tile_n * BN + oc * 8;
-    const int co8 = (p.Co + 7) & ~7;
-    // statistics partials are per STATS_BM (=128) rows: a 256-row tile emits two of them
-    constexpr int SG = STATS ? BM / STATS_BM : 1;
-    float s[SG][8], ss[SG][8];
-#pragma unroll
-    for (int q = 0; q < SG; ++q)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s[q][e] = ss[q][e] = 0.f;
-#pragma unroll
-    for (int ps = 0; ps < OP; ++ps) {
-      const int row = ps * RPO + orow;
-      const int m = tile_m * BM + row;
-      u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
-      if (m < p.M && n0 < co8) {
-        if (p.addend) {
-          const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) +
-                                                           (size_t)m * p.ldy + n0);
-          float fv[8], fa[8];
-          unpack8(v, fv);
-          unpack8(av, fa);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) fv[e] += fa[e];
-          v = pack8(fv);
-        }
-        *reinterpret_cast<u32x4*>(y + (size_t)m * p.ldy + n0) = v;
-      }
-      if constexpr (STATS) {
-        constexpr int PPG = OP / SG;   // passes per statistics group (rows are pass-major)
-        float f[8];
-        unpack8(v, f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          s[ps / PPG][e] += f[e];
-          ss[ps / PPG][e] += f[e] * f[e];
-        }
-      }
+      rok[r] = ok && ((unsigned)nh < (unsigned)p.Hi);
+      roff[r] = base + (unsigned)nh * (unsigned)p.x_row_pitch;
     }
-    if constexpr (STATS) {
-      float* red = reinterpret_cast<float*>(smem);  // [RPO][2][BN], aliases the (now consumed) output tile
 #pragma unroll
-      for (int q = 0; q < SG; ++q) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          red[(orow * 2 + 0) * BN + oc * 8 + e] = s[q][e];
-          red[(orow * 2 + 1) * BN + oc * 8 + e] = ss[q][e];
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-          const int which = tid / BN, nl = tid - which * BN;
-          float t = 0.f;
-#pragma unroll 8
-          for (int g = 0; g < RPO; ++g) t += red[(g * 2 + which) * BN + nl];
-          const int n = tile_n * BN + nl;
-          const int mb = tile_m * SG + q;   // 128-row statistics block index
-          if (n < p.Co && mb * STATS_BM < p.M) p.stats[((size_t)mb * 2 + which) * p.Co + n] = t;
-        }
+    for (int q = 0; q < S; ++q) {
+      int nw = bw + p.tsign * q;
+      bool ok = true;
+      if (p.sd == 2) {
+        ok = ((nw & 1) == 0);
+        nw >>= 1;
       }
+      cok[q] = ok && ((unsigned)nw < (unsigned)p.Wi);
+      coff[q] = (unsigned)nw * (unsigned)p.x_pix_pitch;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int q = 0; q < S; ++q) vx[j][r * S + q] = (rok[r] && cok[q]) ? (roff[r] + coff[q]) * 2u : ASM_OOB;
+  }
+  unsigned vw[WP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    const int row = r0 + j * RPP;
+    const int n = tile_n * BN + row;
+    vw[j] = (c_ok && row < BN && n < p.Co) ? ((unsigned)n * (unsigned)p.w_row_pitch + (unsigned)csw) * 2u : ASM_OOB;
+  }
+
+  const int wrow0 = wave * (64 / CPR);
+  auto issue = [&](int stage, const int t, unsigned xso, unsigned wso) {
+    unsigned char* xs = smem + stage * STAGE;
+    unsigned char* ws = xs + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < XP; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (j * RPP + wrow0) * ROWB), 16, (int)vx[j][t], (int)xso, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WP; ++j)
+      if (j * RPP + wrow0 < BN)   // wave-uniform: rows past the filter tile are never written nor read
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(ws + (j * RPP + wrow0) * ROWB), 16, (int)vw[j], (int)wso, 0, 0);
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // fragment byte offsets inside a stage (a = b = 0); +32 rows keeps the swizzle, so the other tiles are immediates
+  unsigned fwo[BK / 16], fxo[BK / 16];
+#pragma unroll
+  for (int kk = 0; kk < BK / 16; ++kk) {
+    const int ch = kk * 2 + lhi;
+    const int rw_ = wn * WTN + l31, rx_ = wm * WTM + l31;
+    fwo[kk] = BM * ROWB + rw_ * ROWB + ((ch ^ swz<BK>(rw_)) << 4);
+    fxo[kk] = rx_ * ROWB + ((ch ^ swz<BK>(rx_)) << 4);
+  }
+  auto compute = [&](int stage) {
+    const unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fw[TN], fx[TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a) fw[a] = *reinterpret_cast<const bf16x8*>(sb + fwo[kk] + a * 32 * ROWB);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) fx[b] = *reinterpret_cast<const bf16x8*>(sb + fxo[kk] + b * 32 * ROWB);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a], fx[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: DMA of step k+1 runs under the MFMAs of step k; one barrier per step ----
+  const unsigned tapw = (unsigned)p.Ci * 2u;   // bytes between consecutive taps of a filter row
+  issue(0, 0, 0u, 0u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  unsigned kcb = 0;                            // byte offset of the current channel chunk
+#pragma unroll 1
+  for (int kc = 0; kc < p.kchunks; ++kc) {
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      if (t + 1 < NTAP) {
+        issue(cur ^ 1, t + 1, kcb, kcb + (unsigned)(t + 1) * tapw);
+      } else if (kc + 1 < p.kchunks) {
+        issue(cur ^ 1, 0, kcb + BK * 2, kcb + BK * 2);
+      }
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+    kcb += BK * 2;
+  }
+
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S>
+int launch2_one(const IGemmArgs& a, hipStream_t st) {
+  using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
+  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (C::LDS > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(C::NT), C::LDS, st, a);
+  ASM_CHECK_LAUNCH("igemm2_kernel");
+  return ASM_OK;
+}
+
+// returns 1 if this (tile, tap shape) has no igemm2 instantiation
+template <int BM, int BN, int BK, int WGM, int WGN>
+int launch2_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
+  a.n_tiles_n = cdiv(a.Co, BN);
+  a.n_blocks = cdiv(a.M, BM) * a.n_tiles_n;
+  a.kchunks = cdiv(a.Ci, BK);
+  a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
+  if (a.Ci % BK != 0 && a.kchunks != 1) return 1;
+  if (a.R == 1 && a.S == 1) {
+    if (out_f32) return launch2_one<BM, BN, BK, WGM, WGN, true, false, 1, 1>(a, st);
+    if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 1, 1>(a, st);
+    return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 1>(a, st);
+  }
+  if (out_f32) return 1;
+  if (a.R == 3 && a.S == 3) {
+    if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 3, 3>(a, st);
+    return launch2_one<BM, BN, BK, WGM, WGN, false, false, 3, 3>(a, st);
+  }
+  if constexpr (BK == 32 && BM == 128 && BN <= 64) {   // the two stems (R = k, S = 1 over the 4-channel halo buffer)
+    if (a.R == 7 && a.S == 1) {
+      if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 7, 1>(a, st);
+      return launch2_one<BM, BN, BK, WGM, WGN, false, false, 7, 1>(a, st);
+    }
+    if (a.R == 3 && a.S == 1) {
+      if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 3, 1>(a, st);
+      return launch2_one<BM, BN, BK, WGM, WGN, false, false, 3, 1>(a, st);
     }
   }
+  return 1;
 }
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE>
@@ -485,6 +708,22 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   const bool bk64 = (a.Ci % 64 == 0 && a.R * a.S > 1);
   const bool heavy = a.Ci % 64 == 0 && (long long)a.R * a.S * a.Ci >= 512;
   const int fmode = env_int("ASM_IGEMM_MODE"), ftile = env_int("ASM_IGEMM_TILE");
+  a.fd_howo = make_fastdiv((unsigned)a.HoWo);
+  a.fd_wo = make_fastdiv((unsigned)a.Wo);
+  static const int v2 = getenv("ASM_IGEMM_V2") ? atoi(getenv("ASM_IGEMM_V2")) : 1;
+  if (v2 && fmode == 0) {
+    int rc;
+    const long long b256v = (long long)cdiv(a.M, 256) * cdiv(a.Co, 256);
+    bool bigv = heavy && a.Co >= 256 && b256v >= 192;
+    if (ftile == 1) bigv = false;
+    if (ftile == 3 && a.Ci % 64 == 0) bigv = true;
+    if (a.Co <= 32) rc = bk64 ? launch2_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, st) : launch2_cfg<128, 32, 32, 4, 1>(a, out_f32, stats, st);
+    else if (a.Co <= 64) rc = bk64 ? launch2_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, st);
+    else if (ftile == 2 && a.Ci % 64 == 0) rc = launch2_cfg<256, 128, 64, 4, 2>(a, out_f32, stats, st);
+    else if (bigv) rc = launch2_cfg<256, 256, 64, 4, 2>(a, out_f32, stats, st);
+    else rc = bk64 ? launch2_cfg<128, 128, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 128, 32, 2, 2>(a, out_f32, stats, st);
+    if (rc != 1) return rc;
+  }
   int mode = heavy ? 1 : 2;
   if (fmode == 1 || fmode == 2) mode = fmode;
   if (a.Co <= 32) return bk64 ? launch_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, mode, st)
