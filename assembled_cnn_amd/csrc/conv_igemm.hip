@@ -457,10 +457,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
 //     no VALU, no branches, no VGPR round trip (LDS-DMA zero-fills out-of-range lanes -- tools/probes);
 //   * m -> (img, ho, wo) uses multiply-shift division.
 // Requires R x S in {1x1, 3x3, 7x1, 3x1} and (Ci % BK == 0 or a single chunk); the rest stays on igemm_kernel.
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int NS>
+struct Cfg2 {
+  using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
+  // NS = LDS stages.  A ring of 3-4 stages with counted vmcnt + raw s_barrier (DMA in flight across the barrier) was
+  // measured at +-2 % over NS = 2 on every layer class, so only the double buffer is instantiated.
+  static constexpr int WROWS = BN;
+  static constexpr int STAGE = (BM + WROWS) * C::ROWB;
+  static constexpr int LDS = cmax(cmax(NS * STAGE, C::EPI), C::RED);
+  static_assert(LDS <= 160 * 1024, "lds");
+};
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
   using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
-  constexpr int CPR = C::CPR, RPP = C::RPP, XP = C::XP, WP = C::WP, ROWB = C::ROWB, STAGE = C::STAGE;
+  using C2 = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
+  constexpr int CPR = C::CPR, RPP = C::RPP, XP = C::XP, WP = C::WP, ROWB = C::ROWB, STAGE = C2::STAGE;
   constexpr int TM = C::TM, TN = C::TN, WTM = C::WTM, WTN = C::WTN;
   constexpr int NTAP = R * S;
   static_assert(RPP % 16 == 0, "the source-side swizzle must not depend on the pass");
@@ -545,11 +557,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
     unsigned char* ws = xs + BM * ROWB;
 #pragma unroll
     for (int j = 0; j < XP; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (j * RPP + wrow0) * ROWB), 16, (int)vx[j][t], (int)xso, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (j * RPP + wrow0) * ROWB), 16,
+                                               (int)vx[j][t], (int)xso, 0, 0);
 #pragma unroll
     for (int j = 0; j < WP; ++j)
       if (j * RPP + wrow0 < BN)   // wave-uniform: rows past the filter tile are never written nor read
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(ws + (j * RPP + wrow0) * ROWB), 16, (int)vw[j], (int)wso, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(ws + (j * RPP + wrow0) * ROWB), 16,
+                                                 (int)vw[j], (int)wso, 0, 0);
   };
 
   f32x16 acc[TN][TM];
@@ -570,61 +584,75 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
     fwo[kk] = BM * ROWB + rw_ * ROWB + ((ch ^ swz<BK>(rw_)) << 4);
     fxo[kk] = rx_ * ROWB + ((ch ^ swz<BK>(rx_)) << 4);
   }
-  auto compute = [&](int stage) {
+  // Fragments are double-buffered in registers: the ds_reads of k-substep kk+1 are issued BEFORE the MFMAs of kk, and
+  // the first fragments of the next stage right after the barrier that publishes it, before the last MFMA group of
+  // the current step -- so LDS latency runs under MFMA execution instead of in front of it (the compiler emitted
+  // read -> wait -> 4 MFMA per substep: ~45 % of every wave's loop time was spent waiting on lgkmcnt).
+  constexpr int KK = BK / 16;
+  bf16x8 fwb[2][TN], fxb[2][TM];
+  auto load_frags = [&](int stage, const int kk, const int buf) {
     const unsigned char* sb = smem + stage * STAGE;
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 fw[TN], fx[TM];
+    for (int a = 0; a < TN; ++a) fwb[buf][a] = *reinterpret_cast<const bf16x8*>(sb + fwo[kk] + a * 32 * ROWB);
 #pragma unroll
-      for (int a = 0; a < TN; ++a) fw[a] = *reinterpret_cast<const bf16x8*>(sb + fwo[kk] + a * 32 * ROWB);
-#pragma unroll
-      for (int b = 0; b < TM; ++b) fx[b] = *reinterpret_cast<const bf16x8*>(sb + fxo[kk] + b * 32 * ROWB);
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a], fx[b], acc[a][b], 0, 0, 0);
-    }
+    for (int b = 0; b < TM; ++b) fxb[buf][b] = *reinterpret_cast<const bf16x8*>(sb + fxo[kk] + b * 32 * ROWB);
   };
-
-  // ---- main loop: DMA of step k+1 runs under the MFMAs of step k; one barrier per step ----
-  const unsigned tapw = (unsigned)p.Ci * 2u;   // bytes between consecutive taps of a filter row
-  issue(0, 0, 0u, 0u);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  unsigned kcb = 0;                            // byte offset of the current channel chunk
-#pragma unroll 1
-  for (int kc = 0; kc < p.kchunks; ++kc) {
+  auto mma = [&](const int buf) {
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t) {
-      if (t + 1 < NTAP) {
-        issue(cur ^ 1, t + 1, kcb, kcb + (unsigned)(t + 1) * tapw);
-      } else if (kc + 1 < p.kchunks) {
-        issue(cur ^ 1, 0, kcb + BK * 2, kcb + BK * 2);
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwb[buf][a], fxb[buf][b], acc[a][b], 0, 0, 0);
+  };
+  const unsigned tapw = (unsigned)p.Ci * 2u;   // bytes between consecutive taps of a filter row
+  {
+    // ---- DMA of step k+1 runs under the MFMAs of step k; one barrier per step ----
+    issue(0, 0, 0u, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_frags(0, 0, 0);
+    int cur = 0;
+    unsigned kcb = 0;                            // byte offset of the current channel chunk
+#pragma unroll 1
+    for (int kc = 0; kc < p.kchunks; ++kc) {
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const bool more = (t + 1 < NTAP) || (kc + 1 < p.kchunks);
+        if (t + 1 < NTAP) {
+          issue(cur ^ 1, t + 1, kcb, kcb + (unsigned)(t + 1) * tapw);
+        } else if (kc + 1 < p.kchunks) {
+          issue(cur ^ 1, 0, kcb + BK * 2, kcb + BK * 2);
+        }
+#pragma unroll
+        for (int kk = 0; kk + 1 < KK; ++kk) {
+          load_frags(cur, kk + 1, (kk + 1) & 1);
+          mma(kk & 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // next tile visible; everyone's reads of this stage are in registers
+        if (more) load_frags(cur ^ 1, 0, 0);
+        mma((KK - 1) & 1);
+        cur ^= 1;
       }
-      compute(cur);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
+      kcb += BK * 2;
     }
-    kcb += BK * 2;
   }
 
   igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2>
 int launch2_one(const IGemmArgs& a, hipStream_t st) {
-  using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
-  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S>;
+  using C = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
+  constexpr int NTHR = 64 * WGM * WGN;
+  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (C::LDS > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(C::NT), C::LDS, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(NTHR), C::LDS, st, a);
   ASM_CHECK_LAUNCH("igemm2_kernel");
   return ASM_OK;
 }

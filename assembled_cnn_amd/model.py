@@ -16,6 +16,8 @@ Variables are created in the reference's creation order with TF-style names
 """
 from __future__ import annotations
 
+import os
+
 import math
 from collections import OrderedDict
 from typing import Optional
@@ -110,6 +112,10 @@ class Model(object):
     self._walk(ctx, x, use_resnet_d, False)
     self._built_with_d = use_resnet_d
     self.arena.finalize(self.device, self.seed)
+    # opt-in: measured +-1 % on one MI355X (both streams' kernels are machine-filling grids), and it costs ~3 ms of
+    # host time per step in stream bookkeeping
+    if os.environ.get('ASM_WGRAD_STREAM', '0') == '1':
+      self.arena.enable_side_stream()     # no-op on the CPU test double
 
   def __call__(self, inputs, training, reuse=False, use_resnet_d=False, keep_prob=1.0, return_embedding=False,
                record_tape=None, prepadded=False, dropblock_uniforms=None):
@@ -152,6 +158,7 @@ class Model(object):
     self._ctx.dlogits = dlogits
     self._ctx.backward()
     self._ctx = None
+    self.arena.join_side_stream()
 
   # -----------------------------------------------------------------------------------------------
   def _bottleneck(self, ctx: Ctx, x: Var, filters, projection, strides, zero_gamma, aa_size, aa_type,

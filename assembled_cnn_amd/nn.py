@@ -62,12 +62,26 @@ class ParamArena(object):
     self.wt_specs: List[dict] = []   # CRSK (dgrad operand) copies: one flat bf16 arena, one batched launch
     self.wt16 = None
     self._wt_table = None
+    # Weight gradients are leaves of the backward graph (only the optimiser / all-reduce consume them), so they run
+    # on a second HIP stream beside the dgrad -> BN-backward chain: MFMA-bound wgrad blocks and HBM-bound
+    # normalisation kernels share the CUs.  None = everything on the compute stream.
+    self.side_stream = None
 
   def notify_grad(self, name: str):
-    """The gradient slot of ``name`` has been enqueued on the compute stream (backward order is the
-    reverse of creation order, so every slot above it in its segment is final too)."""
+    """The gradient slot of ``name`` has been enqueued (on the compute stream, or on the weight-gradient stream
+    for conv kernels); backward order is the reverse of creation order, so every slot above it in its segment has
+    been enqueued too."""
     if self.on_grad is not None:
       self.on_grad(self.specs[name].offset)
+
+  def enable_side_stream(self):
+    if self.w32 is not None and self.w32.is_cuda and self.side_stream is None:
+      self.side_stream = torch.cuda.Stream(device=self.w32.device)
+
+  def join_side_stream(self):
+    """Make the compute stream wait for every weight gradient enqueued so far."""
+    if self.side_stream is not None:
+      torch.cuda.current_stream().wait_stream(self.side_stream)
 
   def register(self, name, shape, decay, init) -> ParamSpec:
     if self.finalized:
@@ -364,18 +378,31 @@ class ConvKernel(object):
       x = self._stem_view(x)
     return ops.conv_fprop(d, x, self.weight(), want_stats)
 
-  def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool,
-               addend: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """dW into the gradient arena; returns dx [+ addend] (or None)."""
+  def _wgrad(self, d, x: torch.Tensor, dy: torch.Tensor):
     a = self.arena
     if self.stem:
       dwp = torch.empty((self.cout, self.k, self.stem_len), dtype=torch.float32, device=x.device)
       ops.conv_wgrad(d, self._stem_view(x), dy, dwp)
       ops.stem_unpack_grad(dwp, a.g(self.name), self.cout, self.k)
-      a.notify_grad(self.name)
-      return None
-    ops.conv_wgrad(d, x, dy, a.g(self.name))
+    else:
+      ops.conv_wgrad(d, x, dy, a.g(self.name))
     a.notify_grad(self.name)
+
+  def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool,
+               addend: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """dW into the gradient arena; returns dx [+ addend] (or None)."""
+    a = self.arena
+    side = a.side_stream
+    if side is not None:
+      side.wait_stream(torch.cuda.current_stream())     # x and dy were produced on the compute stream
+      with torch.cuda.stream(side):
+        self._wgrad(d, x, dy)
+      x.record_stream(side)                               # keep the caching allocator from recycling them early
+      dy.record_stream(side)
+    else:
+      self._wgrad(d, x, dy)
+    if self.stem:
+      return None
     if not need_dx:
       return None
     if self.kpad != self.cout:  # dy carries kpad channels (zero padded)
