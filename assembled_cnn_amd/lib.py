@@ -50,6 +50,7 @@ SIGNATURES = {
     'asm_conv2d_wgrad': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
     'asm_filter_transpose': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     'asm_filter_transpose_batched': (_I, [_P, _P, _P, _I, C.c_longlong, _P]),
+    'asm_filter_transpose_tiled': (_I, [_P, _P, _P, _I, _I, _P]),
     'asm_conv2d_fprop_naive': (_I, [_D, _P, _P, _P, _P]),
     'asm_conv2d_dgrad_naive': (_I, [_D, _P, _P, _P, _P]),
     'asm_conv2d_wgrad_naive': (_I, [_D, _P, _P, _P, _P]),

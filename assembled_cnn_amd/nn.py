@@ -128,14 +128,16 @@ class ParamArena(object):
     self.state = torch.from_numpy(np.concatenate(shost) if shost else np.zeros((0,), np.float32)).to(device)
     woff = 0
     rows = []
-    begin = 0
+    begin = tiles = 0
     for ws in self.wt_specs:
       ws['offset'] = woff
       sp = self.specs[ws['name']]
-      rows.append([sp.offset, woff, ws['K'], ws['RS'], ws['C'], ws['ldk'], begin, 0])
+      rows.append([sp.offset, woff, ws['K'], ws['RS'], ws['C'], ws['ldk'], begin, tiles])
       begin += sp.numel
+      tiles += ws['RS'] * (-(-ws['K'] // 64)) * (-(-ws['C'] // 64))
       woff += _round_up(ws['C'] * ws['RS'] * ws['ldk'], 8)
     self._wt_total = begin
+    self._wt_tiles = tiles
     self.wt16 = torch.zeros((max(woff, 8),), dtype=torch.bfloat16, device=device)
     self._wt_table = torch.tensor(rows if rows else [[0] * 8], dtype=torch.int32).to(device)
     self.finalized = True
@@ -179,7 +181,7 @@ class ParamArena(object):
 
   def refresh_derived(self):
     if self.wt_specs:
-      ops.filter_transpose_batched(self.w16, self.wt16, self._wt_table, len(self.wt_specs), self._wt_total)
+      ops.filter_transpose_tiled(self.w16, self.wt16, self._wt_table, len(self.wt_specs), self._wt_tiles)
     for fn in self.derived:
       fn()
 

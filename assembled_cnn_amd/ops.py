@@ -178,6 +178,11 @@ def filter_transpose_batched(w_arena, wt_arena, table, nlayers, total):
         'filter_transpose_batched')
 
 
+def filter_transpose_tiled(w_arena, wt_arena, table, nlayers, total_tiles):
+  check(L().asm_filter_transpose_tiled(_ptr(w_arena), _ptr(wt_arena), _ptr(table), nlayers, total_tiles, _stream()),
+        'filter_transpose_tiled')
+
+
 def stem_pack_filter(w32: torch.Tensor, wp: torch.Tensor, K: int, ksize: int):
   check(L().asm_stem_pack_filter(_ptr(w32), _ptr(wp), K, ksize, _stream()), 'stem_pack_filter')
 

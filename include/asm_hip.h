@@ -95,6 +95,10 @@ int asm_filter_transpose(const void* w_krsc, void* w_crsk, int K, int R, int S, 
  * running sum of K*R*S*C (row 0 starts at 0); total_elems = the final running sum. */
 int asm_filter_transpose_batched(const void* w_arena, void* wt_arena, const int32_t* table, int nlayers,
                                  long long total_elems, void* stream);
+/* Same result through 64x64 LDS tiles (16-byte loads along c, 16-byte stores along k): table[l][7] = index of layer
+ * l's first tile, a layer has RS * ceil(K/64) * ceil(C/64) tiles; columns K..ldk-1 of the copies are zero filled. */
+int asm_filter_transpose_tiled(const void* w_arena, void* wt_arena, const int32_t* table, int nlayers,
+                               int total_tiles, void* stream);
 
 /* Debug / test-only direct convolutions (one thread per output element, fp32 accumulate).  They
  * exist so GPU tests can cross-check the MFMA kernels at sizes the CPU oracle cannot reach. */

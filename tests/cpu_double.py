@@ -163,6 +163,16 @@ class CpuDouble(object):
       dst[..., :K] = src.permute(2, 1, 0)
     return 0
 
+  def asm_filter_transpose_tiled(self, w, wt, table, nl, total_tiles, stream):
+    tab = T(table, (nl, 8), 'i32')
+    for l in range(nl):
+      so, do, K, RS, Cn, ldk, _, _ = [int(v) for v in tab[l]]
+      src = T(w + 2 * so, (K, RS, Cn), 'bf16')
+      dst = T(wt + 2 * do, (Cn, RS, ldk), 'bf16')
+      dst.zero_()
+      dst[..., :K] = src.permute(2, 1, 0)
+    return 0
+
   def asm_stem_pack_filter(self, w, wp, K, ks, stream):
     Lr = (4 * ks + 7) // 8 * 8
     src = T(w, (K, ks, ks, 3), 'f32')

@@ -58,7 +58,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize('mode', [2, 1], ids=['lds-dma', 'reg-staged'])
+@pytest.mark.parametrize('mode', [0, 2, 1], ids=['igemm2', 'v1-lds-dma', 'v1-reg-staged'])
 @pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
 def test_fprop_dgrad_wgrad_vs_oracle(hip_lib, shape, mode, monkeypatch):
   from assembled_cnn_amd import ops
@@ -236,9 +236,15 @@ def test_batched_filter_transpose(hip_lib):
     wt = arena.wt_view(cv._wts).view(cv.cin, cv.k, cv.k, cv.kpad)
     assert torch.equal(wt[..., :cv.cout], w.permute(3, 1, 2, 0))
     assert float(wt[..., cv.cout:].float().abs().sum()) == 0.0
+  # the one-thread-per-element entry point gives the same arena
+  from assembled_cnn_amd import ops
+  tiled = arena.wt16.clone()
+  arena.wt16.zero_()
+  ops.filter_transpose_batched(arena.w16, arena.wt16, arena._wt_table, len(arena.wt_specs), arena._wt_total)
+  assert torch.equal(arena.wt16, tiled)
 
 
-@pytest.mark.parametrize('mode', [2, 1], ids=['lds-dma', 'reg-staged'])
+@pytest.mark.parametrize('mode', [0, 2, 1], ids=['igemm2', 'v1-lds-dma', 'v1-reg-staged'])
 @pytest.mark.parametrize('tile', [2, 3])
 @pytest.mark.parametrize('shape', [(3, 7, 7, 256, 512, 3, 1), (2, 16, 16, 64, 128, 3, 1), (4, 20, 20, 128, 320, 1, 1),
                                    (2, 14, 14, 128, 256, 3, 2)], ids=lambda s: 'x'.join(map(str, s)))
@@ -247,7 +253,8 @@ def test_big_tile_variants(hip_lib, shape, tile, mode, monkeypatch):
   and the two-partials-per-tile statistics epilogue."""
   from assembled_cnn_amd import ops
   monkeypatch.setenv('ASM_IGEMM_TILE', str(tile))
-  monkeypatch.setenv('ASM_IGEMM_MODE', str(mode))
+  if mode:
+    monkeypatch.setenv('ASM_IGEMM_MODE', str(mode))
   N, H, W, Cn, K, k, stride = shape
   x = _rand((N, H, W, Cn), 21)
   w = _rand((K, k, k, Cn), 22, scale=(1.0 / (k * k * Cn)) ** 0.5)
