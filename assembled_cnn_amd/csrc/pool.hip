@@ -153,6 +153,9 @@ __device__ __forceinline__ int valid_taps(int o, int stride, int pad, int k, int
   return c;
 }
 
+// Gather form (no atomics): dx(h, w) = sum over the windows that contain (h, w) of dy / window size.  stride is 1
+// or 2 (checked by the host wrapper), so the window test is a shift / mask instead of an integer division, and the
+// divisor is a per-launch constant unless the reference's "count only valid taps" SAME rule is on.
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
                                                           int N, int H, int W, int C, int k, int stride, int pad,
                                                           int Ho, int Wo, int count_valid) {
@@ -161,23 +164,25 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restri
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
   const Pix p = decode(i, H, W, vcols);
+  const int sh = stride >> 1, msk = stride - 1;   // stride in {1, 2}
+  const float inv_full = 1.0f / (float)(k * k);
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const bf16_t* src = dy + (size_t)p.n * Ho * Wo * C + p.vc * 8;
   for (int r = 0; r < k; ++r) {
     const int th = p.h + pad - r;
-    if (th < 0 || th % stride) continue;
-    const int ho = th / stride;
-    if (ho >= Ho) continue;
+    const int ho = th >> sh;
+    if (th < 0 || (th & msk) || ho >= Ho) continue;
     for (int s = 0; s < k; ++s) {
       const int tw = p.w + pad - s;
-      if (tw < 0 || tw % stride) continue;
-      const int wo = tw / stride;
-      if (wo >= Wo) continue;
+      const int wo = tw >> sh;
+      if (tw < 0 || (tw & msk) || wo >= Wo) continue;
       float g[8];
-      unpack8(ldv(dy, (((size_t)p.n * Ho + ho) * Wo + wo) * C + p.vc * 8), g);
-      const float inv =
-          1.0f / (float)(count_valid ? valid_taps(ho, stride, pad, k, H) * valid_taps(wo, stride, pad, k, W) : k * k);
+      unpack8(ldv(src, (size_t)(ho * Wo + wo) * C), g);
+      const float inv = count_valid
+                            ? 1.0f / (float)(valid_taps(ho, stride, pad, k, H) * valid_taps(wo, stride, pad, k, W))
+                            : inv_full;
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += g[e] * inv;
     }
@@ -301,29 +306,55 @@ __global__ __launch_bounds__(256) void blur_bwd_kernel(const bf16_t* __restrict_
 }
 
 // ---- global average pool: [N, HW, C] -> [N, C]; one block per (n, group of <=32 vector columns) -----
-// 256 threads = (256 / vcb) row-lanes x vcb vector columns, vcb = min(C/8, 32)
-template <bool TWO_BRANCH>
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int HW,
-                                                      int Cin, int Cout, int vcb) {
-  __shared__ float red[256][9];
+// NT threads = (NT / vcb) row-lanes x vcb vector columns, vcb = min(C/8, 32).  One block per (image, 32 vector
+// columns): with 3136 rows per image the 256-thread form walked ~100 dependent trips per lane on 4 waves per CU
+// (2.6 TB/s); the 1024-thread form with 4 rows in flight per trip is used for the large maps.
+template <bool TWO_BRANCH, int NT>
+__global__ __launch_bounds__(NT) void gap_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int HW,
+                                                     int Cin, int Cout, int vcb) {
+  __shared__ float red[NT][9];
   const int vcols = Cout >> 3;
   const int vcl = threadIdx.x % vcb;
   const int rl = threadIdx.x / vcb;
-  const int nrl = 256 / vcb;
+  const int nrl = NT / vcb;
   const int vc = blockIdx.x * vcb + vcl;
   const int n = blockIdx.y;
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   if (vc < vcols && rl < nrl) {
-    for (int r = rl; r < HW; r += nrl) {
-      const size_t off = ((size_t)n * HW + r) * Cin + vc * 8;
+    constexpr int U = 4;
+    const bf16_t* base = x + (size_t)n * HW * Cin + vc * 8;
+    int r = rl;
+    for (; r + (U - 1) * nrl < HW; r += U * nrl) {
+      u32x4 v[U], w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t off = (size_t)(r + u * nrl) * Cin;
+        v[u] = ldv(base, off);
+        if (TWO_BRANCH) w[u] = ldv(base, off + Cout);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        if (TWO_BRANCH) {
+          unpack8(w[u], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+      }
+    }
+    for (; r < HW; r += nrl) {
+      const size_t off = (size_t)r * Cin;
       float f[8];
-      unpack8(ldv(x, off), f);
+      unpack8(ldv(base, off), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += f[e];
       if (TWO_BRANCH) {
-        unpack8(ldv(x, off + Cout), f);
+        unpack8(ldv(base, off + Cout), f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += f[e];
       }
@@ -418,7 +449,8 @@ extern "C" int asm_avgpool_fwd(const void* x, void* y, int N, int H, int W, int 
 extern "C" int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
                                int Ho, int Wo, int count_valid, void* stream) {
   POOL_ARGS_OK("avgpool_bwd");
-  ASM_REQUIRE(dy && dx && k >= 1 && k <= 7 && stride >= 1 && pad >= 0 && Ho > 0 && Wo > 0, "avgpool_bwd: bad arguments");
+  ASM_REQUIRE(dy && dx && k >= 1 && k <= 7 && pad >= 0 && Ho > 0 && Wo > 0, "avgpool_bwd: bad arguments");
+  ASM_REQUIRE(stride == 1 || stride == 2, "avgpool_bwd: stride %d not supported (the shortcut pools use 1 and 2)", stride);
   const size_t nvec = (size_t)N * H * W * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
@@ -468,8 +500,12 @@ extern "C" int asm_blurpool_bwd(const void* dy, void* dx, int N, int H, int W, i
 extern "C" int asm_gap_fwd(const void* x, void* y, int N, int HW, int C, void* stream) {
   ASM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_fwd: bad arguments");
   const int vcb = C / 8 < 32 ? C / 8 : 32;
-  hipLaunchKernelGGL((gap_fwd_kernel<false>), dim3(cdiv(C / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (bf16_t*)y, HW, C, C, vcb);
+  if (HW >= 512)
+    hipLaunchKernelGGL((gap_fwd_kernel<false, 1024>), dim3(cdiv(C / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, HW, C, C, vcb);
+  else
+    hipLaunchKernelGGL((gap_fwd_kernel<false, 256>), dim3(cdiv(C / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, HW, C, C, vcb);
   ASM_CHECK_LAUNCH("gap_fwd");
   return ASM_OK;
 }
@@ -477,8 +513,12 @@ extern "C" int asm_gap_fwd(const void* x, void* y, int N, int HW, int C, void* s
 extern "C" int asm_sk_gap(const void* f, void* s, int N, int HW, int F, void* stream) {
   ASM_REQUIRE(f && s && N > 0 && HW > 0 && F > 0 && F % 8 == 0, "sk_gap: bad arguments");
   const int vcb = F / 8 < 32 ? F / 8 : 32;
-  hipLaunchKernelGGL((gap_fwd_kernel<true>), dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)f, (bf16_t*)s, HW, 2 * F, F, vcb);
+  if (HW >= 512)
+    hipLaunchKernelGGL((gap_fwd_kernel<true, 1024>), dim3(cdiv(F / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
+                       (const bf16_t*)f, (bf16_t*)s, HW, 2 * F, F, vcb);
+  else
+    hipLaunchKernelGGL((gap_fwd_kernel<true, 256>), dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)f, (bf16_t*)s, HW, 2 * F, F, vcb);
   ASM_CHECK_LAUNCH("sk_gap");
   return ASM_OK;
 }
