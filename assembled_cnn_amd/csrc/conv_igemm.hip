@@ -38,6 +38,11 @@ struct IGemmArgs {
   int w_row_pitch;  // elements between consecutive n rows of Wt (= R*S*Ci)
   int n_tiles_n, n_blocks, kchunks;
   FastDiv fd_howo, fd_wo, fd_ntn;  // m -> (img, ho, wo), block -> (tile_m, tile_n) without integer division (igemm2_kernel)
+  // igemm2_kernel only (parity-class decomposition of the stride-2 input gradient, asm_conv2d_dgrad):
+  int pad_w;                       // column pad (== pad except in a parity class)
+  int wt0, wtr, wts;               // filter tap of loop tap (i, j): wt0 + i * wtr + j * wts   (0, S, 1 normally)
+  int y_strided;                   // 1: output row m = (img, ho, wo) goes to y_base + img*y_img + ho*y_row + wo*y_pix
+  int y_base, y_img_pitch, y_row_pitch, y_pix_pitch;   // elements
 };
 
 // 16 zero bytes: the source of every masked lane of an LDS-DMA load (global_load_lds has no bounds check)
@@ -145,9 +150,17 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       const int m = tile_m * BM + row;
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
       if (m < p.M && n0 < co8) {
+        size_t yoff = (size_t)m * p.ldy + n0;
+        if (p.y_strided) {   // workgroup-uniform: rows of a parity class scatter into the full-resolution tensor
+          const unsigned img = fd_div((unsigned)m, p.fd_howo);
+          const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
+          const unsigned ho = fd_div(rem, p.fd_wo);
+          const unsigned wo = rem - ho * (unsigned)p.Wo;
+          yoff = (size_t)p.y_base + (size_t)img * p.y_img_pitch + (size_t)ho * p.y_row_pitch +
+                 (size_t)wo * p.y_pix_pitch + n0;
+        }
         if (p.addend) {
-          const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) +
-                                                           (size_t)m * p.ldy + n0);
+          const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) + yoff);
           float fv[8], fa[8];
           unpack8(v, fv);
           unpack8(av, fa);
@@ -155,7 +168,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
           for (int e = 0; e < 8; ++e) fv[e] += fa[e];
           v = pack8(fv);
         }
-        *reinterpret_cast<u32x4*>(y + (size_t)m * p.ldy + n0) = v;
+        *reinterpret_cast<u32x4*>(y + yoff) = v;
       }
       if constexpr (STATS) {
         constexpr int PPG = OP / SG;   // passes per statistics group (rows are pass-major)
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
     const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
     const unsigned ho = fd_div(rem, p.fd_wo);
     const unsigned wo = rem - ho * (unsigned)p.Wo;
-    const int bh = (int)ho * p.so - p.pad, bw = (int)wo * p.so - p.pad;
+    const int bh = (int)ho * p.so - p.pad, bw = (int)wo * p.so - p.pad_w;
     const unsigned base = img * (unsigned)p.x_img_pitch + (unsigned)csw;
     unsigned roff[R], coff[S];
     bool rok[R], cok[S];
@@ -607,7 +620,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
   const unsigned tapw = (unsigned)p.Ci * 2u;   // bytes between consecutive taps of a filter row
   {
     // ---- DMA of step k+1 runs under the MFMAs of step k; one barrier per step ----
-    issue(0, 0, 0u, 0u);
+    issue(0, 0, 0u, (unsigned)p.wt0 * tapw);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     load_frags(0, 0, 0);
@@ -619,9 +632,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
       for (int t = 0; t < NTAP; ++t) {
         const bool more = (t + 1 < NTAP) || (kc + 1 < p.kchunks);
         if (t + 1 < NTAP) {
-          issue(cur ^ 1, t + 1, kcb, kcb + (unsigned)(t + 1) * tapw);
+          issue(cur ^ 1, t + 1, kcb, kcb + (unsigned)(p.wt0 + ((t + 1) / S) * p.wtr + ((t + 1) % S) * p.wts) * tapw);
         } else if (kc + 1 < p.kchunks) {
-          issue(cur ^ 1, 0, kcb + BK * 2, kcb + BK * 2);
+          issue(cur ^ 1, 0, kcb + BK * 2, kcb + BK * 2 + (unsigned)p.wt0 * tapw);
         }
 #pragma unroll
         for (int kk = 0; kk + 1 < KK; ++kk) {
@@ -675,6 +688,11 @@ int launch2_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
     if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 3, 3>(a, st);
     return launch2_one<BM, BN, BK, WGM, WGN, false, false, 3, 3>(a, st);
   }
+  if (!stats) {   // parity classes of a stride-2 3x3 input gradient (asm_conv2d_dgrad)
+    if (a.R == 1 && a.S == 2) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 2>(a, st);
+    if (a.R == 2 && a.S == 1) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 2, 1>(a, st);
+    if (a.R == 2 && a.S == 2) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 2, 2>(a, st);
+  }
   if constexpr (BK == 32 && BM == 128 && BN <= 64) {   // the two stems (R = k, S = 1 over the 4-channel halo buffer)
     if (a.R == 7 && a.S == 1) {
       if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 7, 1>(a, st);
@@ -727,7 +745,7 @@ int launch_cfg(IGemmArgs& a, bool out_f32, bool stats, int mode, hipStream_t st)
   return launch_mode<BM, BN, BK, WGM, WGN, 0>(a, out_f32, stats, st);
 }
 
-int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
+int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_only = false) {
   // Measured on MI355X (tools/conv_bench.py, Assemble-ResNet-50 shapes, batch 256):
   //  * HBM-bound layers (1x1, and everything at 112x112): LDS-DMA staging + the smallest footprint wins
   //    (3-8 workgroups per CU hide the load round trip of the very short K loops);
@@ -750,8 +768,9 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
     else if (ftile == 2 && a.Ci % 64 == 0) rc = launch2_cfg<256, 128, 64, 4, 2>(a, out_f32, stats, st);
     else if (bigv) rc = launch2_cfg<256, 256, 64, 4, 2>(a, out_f32, stats, st);
     else rc = bk64 ? launch2_cfg<128, 128, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 128, 32, 2, 2>(a, out_f32, stats, st);
-    if (rc != 1) return rc;
+    if (rc != 1 || igemm2_only) return rc;
   }
+  if (igemm2_only) return 1;
   int mode = heavy ? 1 : 2;
   if (fmode == 1 || fmode == 2) mode = fmode;
   if (a.Co <= 32) return bk64 ? launch_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, mode, st)
@@ -811,6 +830,8 @@ extern "C" int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const voi
   a.Co = d->K; a.ldy = ldy;
   a.R = d->R; a.S = d->S;
   a.so = d->stride; a.sd = 1; a.tsign = 1; a.pad = d->pad;
+  a.pad_w = a.pad; a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
+  a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
   a.x_img_pitch = (int)img_pitch(d); a.x_row_pitch = row_pitch(d); a.x_pix_pitch = pix_pitch(d);
   a.w_row_pitch = d->R * d->S * d->C;
   return launch(a, d->out_f32 != 0, stats_partial != nullptr, (hipStream_t)stream);
@@ -834,9 +855,55 @@ extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const vo
   a.Wo = d->W; a.HoWo = d->H * d->W;
   a.Co = d->C; a.ldy = d->C;
   a.R = d->R; a.S = d->S;
-  // p = (h + pad - r) / stride  when divisible
-  a.so = 1; a.sd = d->stride; a.tsign = -1; a.pad = -d->pad;
   a.x_img_pitch = d->Ho * d->Wo * d->K; a.x_row_pitch = d->Wo * d->K; a.x_pix_pitch = d->K;
   a.w_row_pitch = d->R * d->S * d->K;
+  a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
+  a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
+  // Stride-2 3x3: three quarters of the (pixel, tap) pairs of the generic gather are parity misses (multiplied as
+  // zeros).  Split dx into its four (h % 2, w % 2) classes instead: within a class every pixel uses the same
+  // 1 / 2 / 2 / 4 taps, so each class is a dense stride-1 gather over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-filter
+  //   dx(2hh+ph, 2ww+pw) = sum_{i,j} dy(hh + dh0 - i, ww + dw0 - j) . w(r0 + 2i, s0 + 2j),
+  //   r0 = (ph + pad) & 1, dh0 = (ph + pad - r0) / 2   (same for columns)
+  // written through the strided-output epilogue: 9/4 instead of 9 tap passes.
+  static const int split_ok = getenv("ASM_DGRAD_PARITY") ? atoi(getenv("ASM_DGRAD_PARITY")) : 1;
+  const bool k3 = d->R == 3 && d->S == 3, k1 = d->R == 1 && d->S == 1 && d->pad == 0;
+  if (split_ok && d->stride == 2 && (k3 || k1) && env_int("ASM_IGEMM_MODE") == 0) {
+    // a 1x1 / 2 projection touches only the (even, even) class: the other three are zero (or just the addend)
+    bool launched = false;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int ph = cls >> 1, pw = cls & 1;
+      const int Hc = (d->H - ph + 1) / 2, Wc = (d->W - pw + 1) / 2;
+      const int r0 = (ph + d->pad) & 1, s0 = (pw + d->pad) & 1;
+      const int Rc = (d->R - r0 + 1) / 2, Sc = (d->S - s0 + 1) / 2;   // taps r0, r0 + 2, ... (< R)
+      if (Hc <= 0 || Wc <= 0 || Rc <= 0 || Sc <= 0) continue;
+      IGemmArgs c = a;
+      c.R = Rc; c.S = Sc;
+      c.M = d->N * Hc * Wc;
+      c.Wo = Wc; c.HoWo = Hc * Wc;
+      c.so = 1; c.sd = 1; c.tsign = -1;
+      c.pad = -((ph + d->pad - r0) / 2); c.pad_w = -((pw + d->pad - s0) / 2);
+      c.wt0 = r0 * d->S + s0; c.wtr = 2 * d->S; c.wts = 2;
+      c.y_strided = 1;
+      c.y_base = (ph * d->W + pw) * d->C;
+      c.y_img_pitch = d->H * d->W * d->C; c.y_row_pitch = 2 * d->W * d->C; c.y_pix_pitch = 2 * d->C;
+      if (!launched && k1) {   // fill the untouched classes before the one launch that overwrites its own pixels
+        const size_t bytes = (size_t)a.M * d->C * 2;
+        hipError_t e = (addend && addend != dx) ? hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream)
+                     : addend ? hipSuccess
+                              : hipMemsetAsync(dx, 0, bytes, (hipStream_t)stream);
+        if (e != hipSuccess) ASM_FAIL(ASM_EHIP, "conv dgrad: fill: %s", hipGetErrorString(e));
+      }
+      const int rc = launch(c, false, false, (hipStream_t)stream, /*igemm2_only=*/true);
+      if (rc == 1) {           // no igemm2 instantiation for this shape: nothing was launched for this class
+        if (launched) ASM_FAIL(ASM_ENOTSUP, "conv dgrad: parity classes launched inconsistently");
+        break;                 // (a stray fill above is overwritten by the generic kernel below)
+      }
+      if (rc != ASM_OK) return rc;
+      launched = true;
+    }
+    if (launched) return ASM_OK;
+  }
+  // generic form: p = (h + pad - r) / stride  when divisible
+  a.so = 1; a.sd = d->stride; a.tsign = -1; a.pad = -d->pad; a.pad_w = a.pad;
   return launch(a, false, false, (hipStream_t)stream);
 }
