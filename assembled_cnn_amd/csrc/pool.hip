@@ -156,9 +156,9 @@ __device__ __forceinline__ int valid_taps(int o, int stride, int pad, int k, int
 // Gather form (no atomics): dx(h, w) = sum over the windows that contain (h, w) of dy / window size.  stride is 1
 // or 2 (checked by the host wrapper), so the window test is a shift / mask instead of an integer division, and the
 // divisor is a per-launch constant unless the reference's "count only valid taps" SAME rule is on.
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* dx,
                                                           int N, int H, int W, int C, int k, int stride, int pad,
-                                                          int Ho, int Wo, int count_valid) {
+                                                          int Ho, int Wo, int count_valid, const bf16_t* addend) {
   const int vcols = C >> 3;
   const size_t nvec = (size_t)N * H * W * vcols;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -186,6 +186,12 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += g[e] * inv;
     }
+  }
+  if (addend) {   // same element is read and written by the same thread: aliasing dx is fine
+    float f[8];
+    unpack8(ldv(addend, i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
   }
   *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(acc);
 }
@@ -447,14 +453,14 @@ extern "C" int asm_avgpool_fwd(const void* x, void* y, int N, int H, int W, int 
 }
 
 extern "C" int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
-                               int Ho, int Wo, int count_valid, void* stream) {
+                               int Ho, int Wo, int count_valid, const void* addend, void* stream) {
   POOL_ARGS_OK("avgpool_bwd");
   ASM_REQUIRE(dy && dx && k >= 1 && k <= 7 && pad >= 0 && Ho > 0 && Wo > 0, "avgpool_bwd: bad arguments");
   ASM_REQUIRE(stride == 1 || stride == 2, "avgpool_bwd: stride %d not supported (the shortcut pools use 1 and 2)", stride);
   const size_t nvec = (size_t)N * H * W * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                     (bf16_t*)dx, N, H, W, C, k, stride, pad, Ho, Wo, count_valid);
+                     (bf16_t*)dx, N, H, W, C, k, stride, pad, Ho, Wo, count_valid, (const bf16_t*)addend);
   ASM_CHECK_LAUNCH("avgpool_bwd");
   return ASM_OK;
 }

@@ -70,7 +70,7 @@ SIGNATURES = {
     'asm_maxpool3x3s2_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'asm_maxpool3x3s2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'asm_avgpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'asm_avgpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'asm_avgpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'asm_upsample2x_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'asm_blurpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'asm_blurpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

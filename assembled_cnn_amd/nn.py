@@ -622,7 +622,11 @@ def avg_pool(ctx: Ctx, x: Var, k: int, stride: int, pad: int, count_valid: bool)
   y = Var(ops.avgpool_fwd(x.data, k, stride, pad, Ho, Wo, count_valid))
   if ctx.tape is not None:
     def bwd():
-      accum_grad(x, ops.avgpool_bwd(y.grad, x.shape, k, stride, pad, count_valid), True)
+      if x.needs_grad and x.grad is not None and x.grad_owned:
+        # gradient fan-in of the block input (main path arrived first): add inside the pool backward, in place
+        ops.avgpool_bwd(y.grad, x.shape, k, stride, pad, count_valid, addend=x.grad)
+      else:
+        accum_grad(x, ops.avgpool_bwd(y.grad, x.shape, k, stride, pad, count_valid), True)
       y.grad = None
     ctx.record(bwd)
   return y

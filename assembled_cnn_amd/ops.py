@@ -300,11 +300,12 @@ def avgpool_fwd(x, k, stride, pad, Ho, Wo, count_valid):
   return y
 
 
-def avgpool_bwd(dy, in_shape, k, stride, pad, count_valid):
+def avgpool_bwd(dy, in_shape, k, stride, pad, count_valid, addend=None):
+  """-> dx (+ addend when given; the sum is written into the addend's buffer when ``addend`` is passed)."""
   N, H, W, Cn = in_shape
-  dx = empty(in_shape, BF16, dy)
+  dx = addend if addend is not None else empty(in_shape, BF16, dy)
   check(L().asm_avgpool_bwd(_ptr(dy), _ptr(dx), N, H, W, Cn, k, stride, pad, dy.shape[1], dy.shape[2],
-                            1 if count_valid else 0, _stream()), 'avgpool_bwd')
+                            1 if count_valid else 0, _ptr(addend), _stream()), 'avgpool_bwd')
   return dx
 
 

@@ -170,8 +170,10 @@ int asm_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int N,
  * divisor forced to 1 for the UpSampling2D backward). */
 int asm_avgpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad,
                     int Ho, int Wo, int count_valid, void* stream);
+/* addend (optional, may alias dx): bf16 [N][H][W][C] added to the result -- the gradient fan-in add of the block
+ * input (main path + pooled shortcut) fused into the pool backward instead of a separate add pass */
 int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
-                    int Ho, int Wo, int count_valid, void* stream);
+                    int Ho, int Wo, int count_valid, const void* addend, void* stream);
 /* gradient of UpSampling2D((2,2)): dx[n,i,j,c] = sum of the 2x2 block of dy */
 int asm_upsample2x_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int C, void* stream);
 /* blocks.anti_aliased_downsample (nets/blocks.py:45-107): REFLECT pad (k-1)/2, binomial k x k, stride 2 */

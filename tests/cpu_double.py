@@ -354,12 +354,18 @@ class CpuDouble(object):
     T(y, (N, Ho, Wo, Cn), 'bf16').copy_(out.permute(0, 2, 3, 1))
     return 0
 
-  def asm_avgpool_bwd(self, dy, dx, N, H, W, Cn, k, stride, pad, Ho, Wo, cv, stream):
+  def asm_avgpool_bwd(self, dy, dx, N, H, W, Cn, k, stride, pad, Ho, Wo, cv, addend, stream):
+    if stride not in (1, 2):
+      self._err = b'avgpool_bwd: stride not supported'
+      return -1
     xt = torch.zeros(N, Cn, H, W, requires_grad=True)
     out = self._avgpool(xt, k, stride, pad, Ho, Wo, cv)
     g = T(dy, (N, Ho, Wo, Cn), 'bf16').float().permute(0, 3, 1, 2)
     (gx,) = torch.autograd.grad(out, xt, g)
-    T(dx, (N, H, W, Cn), 'bf16').copy_(gx.permute(0, 2, 3, 1))
+    gx = gx.permute(0, 2, 3, 1)
+    if addend:
+      gx = gx + T(addend, (N, H, W, Cn), 'bf16').float()
+    T(dx, (N, H, W, Cn), 'bf16').copy_(gx)
     return 0
 
   def asm_upsample2x_bwd(self, dy, dx, N, Hs, Ws, Cn, stream):

@@ -163,6 +163,12 @@ def test_avgpool(hip_lib, shape, k, stride, pad, cv):
   (gx,) = torch.autograd.grad(yr, xr, _nchw(dy))
   dx = ops.avgpool_bwd(dy.cuda(), shape, k, stride, pad, cv)
   _close(dx, _nhwc(gx), name='avgpool bwd')
+  # fused fan-in add, in place in the addend's buffer
+  add = _rand(shape, 3)
+  buf = add.cuda().clone()
+  out = ops.avgpool_bwd(dy.cuda(), shape, k, stride, pad, cv, addend=buf)
+  assert out.data_ptr() == buf.data_ptr()
+  _close(out, _nhwc(gx) + add.float(), name='avgpool bwd + addend')
 
 
 @pytest.mark.parametrize('k', [3, 5, 2])
