@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
 }
 
 // ---- finalize: partials -> per-channel statistics / coefficients --------------------------------
-// block = 16 channels x 16 partial-lanes
+// block = 16 channels x FL partial-lanes.  These kernels are pure latency (one per BN layer and direction, ~200 per
+// step): 64 lanes keep the dependent trip count at <= 4 for the <= 512 partial rows the reducers emit.
+constexpr int FL = 64;
 __device__ __forceinline__ void sum_partials(const float* partial, int blocks, int C, int ch, int ry,
                                              double& s0, double& s1) {
   s0 = 0.0;
@@ -138,11 +140,11 @@ __device__ __forceinline__ void sum_partials(const float* partial, int blocks, i
   if (ch < C) {
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
     int b = ry;
-    for (; b + 16 < blocks; b += 32) {   // two independent chains: loads overlap
+    for (; b + FL < blocks; b += 2 * FL) {   // two independent chains: loads overlap
       a0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
       b0 += (double)partial[((size_t)b * 2 + 1) * C + ch];
-      a1 += (double)partial[((size_t)(b + 16) * 2 + 0) * C + ch];
-      b1 += (double)partial[((size_t)(b + 16) * 2 + 1) * C + ch];
+      a1 += (double)partial[((size_t)(b + FL) * 2 + 0) * C + ch];
+      b1 += (double)partial[((size_t)(b + FL) * 2 + 1) * C + ch];
     }
     if (b < blocks) {
       a0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
@@ -179,12 +181,12 @@ __global__ __launch_bounds__(256) void partials_compact_kernel(const float* __re
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, int M, int C,
+__global__ __launch_bounds__(16 * FL) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, int M, int C,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float momentum,
                                                           float* moving_mean, float* moving_var, float* mean,
                                                           float* invstd, float* scale, float* shift) {
-  __shared__ double red[2][16][16];
+  __shared__ double red[2][FL][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cx;
   double s0, s1;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   __syncthreads();
   if (ry == 0 && ch < C) {
     double a = 0.0, b = 0.0;
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < FL; ++r) {
       a += red[0][r][cx];
       b += red[1][r][cx];
     }
@@ -215,13 +217,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int M,
+__global__ __launch_bounds__(16 * FL) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int M,
                                                               int C, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* dgamma,
                                                               float* dbeta, float* coefA, float* coefB,
                                                               float* coefC) {
-  __shared__ double red[2][16][16];
+  __shared__ double red[2][FL][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cx;
   double s0, s1;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   __syncthreads();
   if (ry == 0 && ch < C) {
     double db = 0.0, dg = 0.0;
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < FL; ++r) {
       db += red[0][r][cx];
       dg += red[1][r][cx];
     }
@@ -388,7 +390,7 @@ extern "C" int asm_bn_finalize(const float* stats_partial, int blocks, int M, in
   ASM_REQUIRE(stats_partial && gamma && beta && mean && invstd && scale && shift && blocks > 0 && M > 0 && C > 0,
               "bn_finalize: bad arguments");
   ASM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must both be given");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, stats_partial,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(16 * FL), 0, (hipStream_t)stream, stats_partial,
                      blocks, M, C, gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift);
   ASM_CHECK_LAUNCH("bn_finalize");
   return ASM_OK;
@@ -443,7 +445,7 @@ extern "C" int asm_bn_bwd_finalize(const float* partial, int blocks, int M, int 
                                    float* coefA, float* coefB, float* coefC, void* stream) {
   ASM_REQUIRE(partial && gamma && mean && invstd && dgamma && dbeta && coefA && coefB && coefC && blocks > 0,
               "bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, blocks,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(16 * FL), 0, (hipStream_t)stream, partial, blocks,
                      M, C, gamma, mean, invstd, dgamma, dbeta, coefA, coefB, coefC);
   ASM_CHECK_LAUNCH("bn_bwd_finalize");
   return ASM_OK;
