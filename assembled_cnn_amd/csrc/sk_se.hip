@@ -43,19 +43,42 @@ __global__ __launch_bounds__(256) void sk_select_fwd_kernel(const bf16_t* __rest
 }
 
 // datt[n][c] = a0*a1*(da0 - da1), datt[n][F+c] = -that ;  da_b = sum_hw f_b * dV
-__global__ __launch_bounds__(256) void sk_bwd_att_kernel(const bf16_t* __restrict__ f, const bf16_t* __restrict__ dv,
-                                                         const float* __restrict__ att, bf16_t* __restrict__ datt,
-                                                         int HW, int F, int vcb) {
-  __shared__ float red[256][9];
+// NT = 1024 with 2 rows in flight per trip for the large maps (one block per (image, 32 vector columns) walks all HW rows)
+template <int NT>
+__global__ __launch_bounds__(NT) void sk_bwd_att_kernel(const bf16_t* __restrict__ f, const bf16_t* __restrict__ dv,
+                                                        const float* __restrict__ att, bf16_t* __restrict__ datt,
+                                                        int HW, int F, int vcb) {
+  __shared__ float red[NT][9];
   const int vcols = F >> 3;
-  const int vcl = threadIdx.x % vcb, rl = threadIdx.x / vcb, nrl = 256 / vcb;
+  const int vcl = threadIdx.x % vcb, rl = threadIdx.x / vcb, nrl = NT / vcb;
   const int vc = blockIdx.x * vcb + vcl;
   const int n = blockIdx.y;
   float acc[8];  // sum_hw (f0 - f1) * dV
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   if (vc < vcols && rl < nrl) {
-    for (int r = rl; r < HW; r += nrl) {
+    constexpr int U = 2;
+    int r = rl;
+    for (; r + (U - 1) * nrl < HW; r += U * nrl) {
+      u32x4 v0[U], v1[U], vg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t m = (size_t)n * HW + r + u * nrl;
+        v0[u] = ldv(f, m * 2 * F + vc * 8);
+        v1[u] = ldv(f, m * 2 * F + F + vc * 8);
+        vg[u] = ldv(dv, m * F + vc * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f0[8], f1[8], g[8];
+        unpack8(v0[u], f0);
+        unpack8(v1[u], f1);
+        unpack8(vg[u], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (f0[e] - f1[e]) * g[e];
+      }
+    }
+    for (; r < HW; r += nrl) {
       const size_t m = (size_t)n * HW + r;
       float f0[8], f1[8], g[8];
       unpack8(ldv(f, m * 2 * F + vc * 8), f0);
@@ -205,8 +228,12 @@ extern "C" int asm_sk_select_bwd_att(const void* f, const void* dv, const float*
   SK_OK("sk_select_bwd_att");
   ASM_REQUIRE(f && dv && att && datt, "sk_select_bwd_att: null pointer");
   const int vcb = F / 8 < 32 ? F / 8 : 32;
-  hipLaunchKernelGGL(sk_bwd_att_kernel, dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)f, (const bf16_t*)dv, att, (bf16_t*)datt, HW, F, vcb);
+  if (HW >= 512)
+    hipLaunchKernelGGL(sk_bwd_att_kernel<1024>, dim3(cdiv(F / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
+                       (const bf16_t*)f, (const bf16_t*)dv, att, (bf16_t*)datt, HW, F, vcb);
+  else
+    hipLaunchKernelGGL(sk_bwd_att_kernel<256>, dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)f, (const bf16_t*)dv, att, (bf16_t*)datt, HW, F, vcb);
   ASM_CHECK_LAUNCH("sk_select_bwd_att");
   return ASM_OK;
 }

@@ -218,7 +218,7 @@ def bn_stats(x2d: torch.Tensor, M: int, Cn: int) -> torch.Tensor:
 def _compact(part: torch.Tensor, Cn: int) -> torch.Tensor:
   """Thousands of partial rows (conv epilogue at high resolution) -> <= 32 rows, fully parallel."""
   blocks = part.shape[0]
-  if blocks <= 512:
+  if blocks <= 1024:
     return part
   per = -(-blocks // 32)
   groups = -(-blocks // per)
