@@ -200,7 +200,7 @@ def test_gap_and_upsample(hip_lib):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('N,H,W,F_', [(4, 14, 14, 64), (3, 7, 7, 512), (2, 5, 5, 32)])
+@pytest.mark.parametrize('N,H,W,F_', [(4, 14, 14, 64), (3, 7, 7, 512), (2, 5, 5, 32), (2, 56, 56, 64), (2, 6, 6, 24)])
 def test_sk_select(hip_lib, N, H, W, F_):
   from assembled_cnn_amd import ops
   f = _rand((N, H, W, 2 * F_), 1).clamp(min=0)
