@@ -15,6 +15,7 @@
 // bit-reproducible).  With one split the tile goes straight to dW.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -35,10 +36,7 @@ struct WgradArgs {
   int HoWo, Wo;
 };
 
-constexpr int WT = 128;   // column-tile edge: (tap, channel) columns per block
 constexpr int WPX = 64;   // pixels per step
-constexpr int WROWB = WT * 2;
-constexpr int WTILE = WPX * WROWB;  // 16 KiB: the x tile of one stage
 
 __device__ __forceinline__ bf16x4 ds_read_tr(const unsigned char* p) {
   typedef __attribute__((ext_vector_type(4))) short s4;
@@ -50,30 +48,40 @@ __device__ __forceinline__ bf16x4 ds_read_tr(const unsigned char* p) {
 // transposing read touches must cover all 64 banks exactly once.
 template <int RB>
 __device__ __forceinline__ int tr_swz(int row) {
-  return RB == 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0);
+  return RB >= 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0);
 }
 
-// BNW = output-channel (dy) tile width: 128 / 64 / 32, so narrow layers (K = 32 / 64 at 112x112 and
-// 56x56, where the pixel count is largest) neither waste MFMAs on zero rows nor LDS on empty tiles.
-template <int BNW>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+// BNW = output-channel (dy) tile width: 256 / 128 / 64 / 32, so narrow layers (K = 32 / 64 at 112x112 and 56x56,
+// where the pixel count is largest) neither waste MFMAs on zero rows nor LDS on empty tiles.  BCW = (tap, channel)
+// column tile: 128, or 256 together with BNW = 256 and 8 waves (each 64 x 128): half the staging loads, index
+// decodes and 3/4 of the LDS fragment reads per MFMA, for the layers whose dW is at least 256 x 256.
+template <int BNW, int BCW>
+__global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs p) {
+  constexpr int NTHR = BCW == 256 ? 512 : 256;
+  constexpr int WROWB = BCW * 2;            // x tile row bytes
+  constexpr int WTILE = WPX * WROWB;
   constexpr int YROWB = BNW * 2;            // dy tile row bytes
   constexpr int YTILE = WPX * YROWB;
   constexpr int STAGE = YTILE + WTILE;
+  constexpr int CX = BCW / 8;               // 16-byte chunks per x row
+  constexpr int XRP = NTHR / CX;            // x rows staged per pass (16)
+  constexpr int XP = WPX / XRP;             // x passes (4)
   constexpr int CY = BNW / 8;               // 16-byte chunks per dy row
-  constexpr int YRP = 256 / CY;             // dy rows staged per pass
+  constexpr int YRP = NTHR / CY;            // dy rows staged per pass
   constexpr int YP = WPX / YRP;             // dy passes (4 / 2 / 1)
+  constexpr bool BIG = BCW == 256;
   constexpr int NT = BNW >= 64 ? 2 : 1;     // 32-row dy tiles per wave
-  constexpr int CT = BNW == 128 ? 2 : 1;    // 32-col x tiles per wave
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  constexpr int CT = BIG ? 4 : (BNW == 128 ? 2 : 1);    // 32-col x tiles per wave
+  static_assert(!BIG || BNW == 256, "the 8-wave form is 256 x 256");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wn = BNW == 128 ? (wave >> 1) : 0;
-  const int wc = BNW == 128 ? (wave & 1) : wave;
-  const int nbase = wn * 64;                       // wave's first dy channel within the tile
-  const int cbase = wc * (BNW == 128 ? 64 : 32);   // wave's first column within the tile
+  const int wn = (BIG || BNW == 128) ? (wave >> 1) : 0;
+  const int wc = (BIG || BNW == 128) ? (wave & 1) : wave;
+  const int nbase = wn * 64;                                        // wave's first dy channel within the tile
+  const int cbase = wc * (BIG ? 128 : (BNW == 128 ? 64 : 32));      // wave's first column within the tile
 
   // block -> (split, tile_n, tile_c): tiles of one split adjacent (they re-read the same pixels)
   // XCD-aware bijective remap (block b runs on XCD b % 8, each XCD has its own L2): give every XCD a
@@ -94,13 +102,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
 
-  const int chunk = tid & 15;  // x tile: 16-byte chunk (8 columns) within the 128-column row
-  const int prow = tid >> 4;   // x tile: pixel row 0..15 (+16 per pass)
+  const int chunk = tid % CX;  // x tile: 16-byte chunk (8 columns) within the row
+  const int prow = tid / CX;   // x tile: pixel row 0..15 (+16 per pass)
   const int ychunk = tid % CY;
   const int yrow = tid / CY;
 
   // this thread's fixed column group of the x tile: tap + channel
-  const int j0 = tile_c * WT + chunk * 8;
+  const int j0 = tile_c * BCW + chunk * 8;
   const bool col_ok = j0 < p.cols;
   int tap_r = 0, tap_s = 0, tap_c = 0;
   if (col_ok) {
@@ -117,8 +125,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const int steps = (m_end - m_begin + WPX - 1) / WPX;
 
   // two register tile sets: 2-deep global prefetch (see conv_igemm.hip)
-  u32x4 ya[YP], xa[4], yb[YP], xb[4];
-  auto load_tile = [&](int step, u32x4(&ry)[YP], u32x4(&rxv)[4]) {
+  u32x4 ya[YP], xa[XP], yb[YP], xb[XP];
+  auto load_tile = [&](int step, u32x4(&ry)[YP], u32x4(&rxv)[XP]) {
 #pragma unroll
     for (int j = 0; j < YP; ++j) {
       const int m = m_begin + step * WPX + yrow + YRP * j;
@@ -126,8 +134,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       ry[j] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (m < m_end && n_ok) ? offy : ASM_OOB, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m_begin + step * WPX + prow + 16 * j;
+    for (int j = 0; j < XP; ++j) {
+      const int m = m_begin + step * WPX + prow + XRP * j;
       const bool mok = m < m_end;
       const unsigned um = mok ? (unsigned)m : 0u;
       const unsigned img = fd_div(um, p.fd_howo);
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? offx : ASM_OOB, 0, 0);
     }
   };
-  auto store_tile = [&](int stage, const u32x4(&ry)[YP], const u32x4(&rxv)[4]) {
+  auto store_tile = [&](int stage, const u32x4(&ry)[YP], const u32x4(&rxv)[XP]) {
     unsigned char* ys = smem + stage * STAGE;
     unsigned char* xs = ys + YTILE;
 #pragma unroll
@@ -151,8 +159,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       *reinterpret_cast<u32x4*>(ys + row * YROWB + ((ychunk ^ tr_swz<YROWB>(row)) << 4)) = ry[j];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = prow + 16 * j;
+    for (int j = 0; j < XP; ++j) {
+      const int row = prow + XRP * j;
       *reinterpret_cast<u32x4*>(xs + row * WROWB + ((chunk ^ tr_swz<WROWB>(row)) << 4)) = rxv[j];
     }
   };
@@ -205,6 +213,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
   };
 
+  if constexpr (BIG) {
+    // one register tile set (two would not fit beside 128 accumulator registers): tile k+1 is in flight in
+    // registers while tile k is multiplied; a 256 x 256 step is 32 MFMAs per wave, twice the cover of a 128 x 128 one
+    load_tile(0, ya, xa);
+    store_tile(0, ya, xa);
+    __syncthreads();
+#pragma unroll 1
+    for (int step = 0; step < steps; ++step) {
+      const int cur = step & 1;
+      load_tile(step + 1, ya, xa);
+      compute(cur);
+      store_tile(cur ^ 1, ya, xa);
+      __syncthreads();
+    }
+  } else {
   // steps beyond the range load nothing (m >= m_end -> zeros), so the pair loop needs no tail branch
   load_tile(0, ya, xa);
   store_tile(0, ya, xa);
@@ -221,6 +244,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     store_tile(0, yb, xb);
     __syncthreads();
   }
+  }
 
   // D[i = n_local][j = col_local]: col = lane&31, n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   float* out = p.out + (size_t)split * p.Co * p.cols;
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   for (int a = 0; a < NT; ++a)
 #pragma unroll
     for (int b = 0; b < CT; ++b) {
-      const int col = tile_c * WT + cbase + b * 32 + l31;
+      const int col = tile_c * BCW + cbase + b * 32 + l31;
       if (col < p.cols) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct Plan {
-  int bnw, tiles_n, tiles_c, splits, m_per_split;
+  int bnw, bcw, tiles_n, tiles_c, splits, m_per_split;
 };
 
 Plan make_plan(const asm_conv_desc* d) {
@@ -278,8 +302,17 @@ Plan make_plan(const asm_conv_desc* d) {
   const int M = d->N * d->Ho * d->Wo;
   const int cols = d->R * d->S * d->C;
   pl.bnw = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);
+  pl.bcw = 128;
+  // 256 x 256 / 8 waves when dW tiles exactly (no padded MFMAs) and there is enough of it; ASM_WGRAD_BIG=0/1 forces
+  static const int big_env = getenv("ASM_WGRAD_BIG") ? atoi(getenv("ASM_WGRAD_BIG")) : -1;
+  // (measured: -13..-20 % on the layers with >= 40 GFLOP and a >= 512K-element dW, +5..+20 % on the small 7x7 ones)
+  bool big = d->K % 256 == 0 && cols % 256 == 0 && (long long)d->K * cols >= 512ll * 1024 &&
+             2.0 * (double)M * d->K * cols >= 40e9;
+  if (big_env == 0) big = false;
+  if (big_env == 1 && d->K >= 256 && cols >= 256) big = true;
+  if (big) pl.bnw = pl.bcw = 256;
   pl.tiles_n = cdiv(d->K, pl.bnw);
-  pl.tiles_c = cdiv(cols, WT);
+  pl.tiles_c = cdiv(cols, pl.bcw);
   const int tiles = pl.tiles_n * pl.tiles_c;
   const int msteps = cdiv(M, WPX);
   // Split count from a small cost model (microseconds): the MFMA/stream time scales with how evenly
@@ -290,7 +323,7 @@ Plan make_plan(const asm_conv_desc* d) {
   const double flops = 2.0 * (double)M * d->K * cols;
   const double io_bytes = 2.0 * ((double)M * d->C + (double)M * d->K);
   const double work_us = fmax(flops / 6.0e8, io_bytes / 4.0e6);      // ~600 TFLOP/s or ~4 TB/s
-  const int slots = 256 * (pl.bnw == 128 ? 2 : (pl.bnw == 64 ? 3 : 4));
+  const int slots = 256 * (pl.bnw == 256 ? 1 : (pl.bnw == 128 ? 2 : (pl.bnw == 64 ? 3 : 4)));
   const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;            // at least 4 steps per block
   int splits = 1;
   double best = 1e30;
@@ -353,10 +386,23 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   a.fd_howo = make_fastdiv((unsigned)a.HoWo);
   a.fd_wo = make_fastdiv((unsigned)a.Wo);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(pl.tiles_n * pl.tiles_c * pl.splits), block(256);
-  if (pl.bnw == 128) hipLaunchKernelGGL(wgrad_kernel<128>, grid, block, 0, st, a);
-  else if (pl.bnw == 64) hipLaunchKernelGGL(wgrad_kernel<64>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(wgrad_kernel<32>, grid, block, 0, st, a);
+  const dim3 grid(pl.tiles_n * pl.tiles_c * pl.splits);
+  if (pl.bcw == 256) {
+    constexpr int LDS = 2 * (WPX * 512 + WPX * 512);   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<256, 256>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<256, 256>), grid, dim3(512), LDS, st, a);
+  } else if (pl.bnw == 128) {
+    hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);
+  } else if (pl.bnw == 64) {
+    hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 2 * (WPX * 128 + WPX * 256), st, a);
+  } else {
+    hipLaunchKernelGGL((wgrad_kernel<32, 128>), grid, dim3(256), 2 * (WPX * 64 + WPX * 256), st, a);
+  }
   ASM_CHECK_LAUNCH("wgrad_kernel");
   if (pl.splits > 1) {
     const size_t n = (size_t)d->K * a.cols;
