@@ -83,19 +83,6 @@ class GradSync(object):
 
   def _launch(self, s: int, i: int):
     lo, hi = self.segments[s][i]
-    side = getattr(self.arena, 'side_stream', None)
-    if side is not None:
-      # a bucket mixes conv kernels (written on the weight-gradient stream) and BN parameters (compute stream):
-      # launch from the side stream after it has caught up with the compute stream, so the collective (which
-      # c10d orders after the CURRENT stream) follows both without stalling the backward chain.
-      import torch
-      cur = torch.cuda.current_stream()
-      if cur != side:
-        side.wait_stream(cur)
-      with torch.cuda.stream(side):
-        self._work.append(dist.all_reduce(self.arena.g32[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                          async_op=True))
-      return
     self._work.append(dist.all_reduce(self.arena.g32[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
   def finish(self):

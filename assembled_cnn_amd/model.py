@@ -112,8 +112,10 @@ class Model(object):
     self._walk(ctx, x, use_resnet_d, False)
     self._built_with_d = use_resnet_d
     self.arena.finalize(self.device, self.seed)
-    # opt-in: measured +-1 % on one MI355X (both streams' kernels are machine-filling grids), and it costs ~3 ms of
-    # host time per step in stream bookkeeping
+    # Weight gradients on a second HIP stream fill the tail rounds of the 1-workgroup-per-CU dgrad tiles: -1.7 % step
+    # time on one MI355X (same box).  Opt-in (ASM_WGRAD_STREAM=1): with two streams sharing the CUs the per-kernel
+    # HIP-event durations bench.py reports for the roofline stop being properties of the kernels.  Never used with a
+    # gradient all-reduce hook (the exchange has its own stream and its launch order follows the compute stream).
     if os.environ.get('ASM_WGRAD_STREAM', '0') == '1':
       self.arena.enable_side_stream()     # no-op on the CPU test double
 

@@ -394,7 +394,7 @@ class ConvKernel(object):
                addend: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """dW into the gradient arena; returns dx [+ addend] (or None)."""
     a = self.arena
-    side = a.side_stream
+    side = a.side_stream if a.on_grad is None else None
     if side is not None:
       side.wait_stream(torch.cuda.current_stream())     # x and dy were produced on the compute stream
       with torch.cuda.stream(side):
