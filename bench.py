@@ -33,7 +33,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MF
 
 WORKLOADS = {
     # BASELINE.json configs[1]
-    'r50': dict(desc='ResNet-50 v1.5 (resnet_version=1) bf16 train', hp=dict(resnet_version=1)),
+    'r50': dict(desc='ResNet-50 v1.5 (resnet_version=1) bf16 train', hp=dict(resnet_version=1), model='ResNet-50'),
     # BASELINE.json configs[2]  (the configuration the metric is quoted on)
     'assemble-r50': dict(desc='Assemble-ResNet-50 (BigLittle + SK + anti_alias sconv k=3 + resnet_d) bf16 train',
                          hp=dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
@@ -46,6 +46,11 @@ WORKLOADS = {
     'assemble-r50-nod': dict(desc='Assemble-ResNet-50 (BigLittle + SK + sconv k=3, no resnet_d) bf16 train',
                              hp=dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
                                      anti_alias_filter_size=3)),
+    # BASELINE.json configs[4], per-GPU shard: Assemble-ResNet-152 (alpha 1, beta 2) + knowledge distillation, batch 128
+    'assemble-r152-kd': dict(desc='Assemble-ResNet-152 (BigLittle alpha=1 beta=2 + SK + sconv k=3) + KD (T=1) bf16 train',
+                             hp=dict(resnet_size=152, resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
+                                     anti_alias_filter_size=3, bl_alpha=1, bl_beta=2, kd_temp=1.0), batch=128,
+                             model='Assemble-ResNet-152'),
 }
 
 
@@ -72,14 +77,19 @@ def _cpu_baseline_worker(workload, budget_s):
   threads = max(1, min(avail, 32))        # more threads than that only adds OpenMP spin on a shared host
   torch.set_num_threads(threads)
   B = 4
-  m = O.Model(50, num_classes=1001, zero_gamma=True, **hp)
+  size = hp.pop('resnet_size', 50)
+  kd = hp.pop('kd_temp', 0.0)
+  m = O.Model(size, num_classes=1001, zero_gamma=True, **hp)
   st = O.TrainState(m)
   g = torch.Generator().manual_seed(0)
   x = torch.randint(0, 256, (B * (2 if mix == 1 else 1), 224, 224, 3), generator=g).float()
   x = O.mean_image_subtraction(x)
   y = torch.randint(1, 1001, (x.shape[0],), generator=g)
   lam = torch.rand(x.shape[0] // 2, generator=g) if mix else None
-  kw = dict(lr=0.1, momentum=0.9, weight_decay=1e-4, label_smoothing=ls, mixup_type=mix, lam1=lam, use_resnet_d=d)
+  if kd > 0:
+    y = torch.cat([torch.nn.functional.one_hot(y, 1001).float(), torch.randn(x.shape[0], 1001, generator=g) * 3.0], 1)
+  kw = dict(lr=0.1, momentum=0.9, weight_decay=1e-4, label_smoothing=ls, mixup_type=mix, lam1=lam, use_resnet_d=d,
+            kd_temp=kd)
   O.train_step(st, x, y, **kw)           # warm-up (variable creation, thread pools)
   n, t0 = 0, time.time()
   while True:
@@ -147,8 +157,11 @@ def main():
   from assembled_cnn_amd.train import HParams, Trainer
   wl = WORKLOADS[args.workload]
   B = args.batch
-  hp = HParams(resnet_size=50, zero_gamma=True, weight_decay=1e-4, momentum=0.9, base_learning_rate=0.1 * B * world / 256,
-               learning_rate_decay_type='fixed', batch_size=B * world, dtype='bf16', **wl['hp'])
+  if 'batch' in wl and args.batch == 256:
+    B = wl['batch']               # the per-GPU shard BASELINE quotes for this configuration
+  hp = HParams(**dict(dict(resnet_size=50, zero_gamma=True, weight_decay=1e-4, momentum=0.9,
+                           base_learning_rate=0.1 * B * world / 256, learning_rate_decay_type='fixed',
+                           batch_size=B * world, dtype='bf16'), **wl['hp']))
   dev = torch.device('cuda', local_rank)
   tr = Trainer(hp, seed=0, device=dev, world_size=world)
   tr.model.build((224, 224), use_resnet_d=hp.use_resnet_d)
@@ -158,6 +171,10 @@ def main():
   nin = B * 2 if hp.mixup_type == 1 else B
   images = torch.randint(0, 256, (nin, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8)
   labels = torch.randint(1, 1001, (nin,), generator=g, device=dev, dtype=torch.int32)
+  if hp.kd_temp > 0:   # labels = concat(one-hot, teacher logits) (nets/run_loop_classification.py:90-96)
+    onehot = torch.nn.functional.one_hot(labels.long(), 1001).float()
+    teacher = torch.randn((nin, 1001), generator=g, device=dev) * 3.0
+    labels = torch.cat([onehot, teacher], 1).contiguous()
   lam1 = tr.sample_mixup_lambdas(nin // 2) if hp.mixup_type else None
 
   def step():
@@ -203,7 +220,7 @@ def main():
 
   if rank == 0:
     out = {
-        'metric': 'images/sec Assemble-ResNet-50 224^2 bf16 train',
+        'metric': 'images/sec %s 224^2 bf16 train' % wl.get('model', 'Assemble-ResNet-50'),
         'value': round(B * world * args.steps / el, 2),
         'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

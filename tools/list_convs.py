@@ -12,7 +12,7 @@ from assembled_cnn_amd.train import HParams  # noqa: E402
 
 
 def conv_shapes(workload='assemble-r50', batch=256):
-  hp = HParams(resnet_size=50, zero_gamma=True, **bench.WORKLOADS[workload]['hp'])
+  hp = HParams(**dict(dict(resnet_size=50, zero_gamma=True), **bench.WORKLOADS[workload]['hp']))
   m = hp.make_model(device='cpu')
   seen = OrderedDict()
   orig = nn.ConvKernel.desc
