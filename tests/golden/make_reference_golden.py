@@ -9,6 +9,7 @@ their modules are imported with `tensorflow` replaced by an inert stand-in, and 
   functions/data_config.py                          dataset constants used by the schedule / class count
   nets/hparams_config.py                            every flag's type and default (absl.flags replaced by a recorder)
   preprocessing/imagenet_preprocessing.py:46-54     CHANNEL_MEANS, _RESIZE_MIN
+  official/utils/flags/_performance.py:27-42        get_loss_scale
 """
 import json
 import os
@@ -94,6 +95,13 @@ def main():
     out['flag_defaults'] = rec.flags
   except Exception as e:   # pragma: no cover
     out['flag_defaults_import_error'] = repr(e)
+  try:   # official/utils/flags/_performance.py:27-42 (pinned by the reference's own flags_test.py:82-96)
+    from official.utils.flags import _performance as perf
+    ns = types.SimpleNamespace
+    out['loss_scale'] = [dict(dtype=dt, loss_scale=ls, result=perf.get_loss_scale(ns(dtype=dt, loss_scale=ls)))
+                         for dt in ('fp16', 'fp32') for ls in (None, 1, 64, 1024)]
+  except Exception as e:   # pragma: no cover
+    out['loss_scale_import_error'] = repr(e)
   try:
     from preprocessing import imagenet_preprocessing as ip
     out['preprocessing'] = dict(CHANNEL_MEANS=list(ip.CHANNEL_MEANS), RESIZE_MIN=ip._RESIZE_MIN)

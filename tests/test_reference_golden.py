@@ -71,3 +71,12 @@ def test_dataset_and_preprocessing_constants_match_reference():
     text = open(os.path.join(here, 'assembled_cnn_amd', 'csrc', src)).read()
     for m in means:
       assert ('%.2ff' % m) in text, (src, m)
+
+
+def test_loss_scale_rule_matches_reference():
+  """official/utils/flags/_performance.py:27-42 -- the rule the reference's own flags_test.py:82-96 pins."""
+  from assembled_cnn_amd.train import HParams
+  for row in GOLD['loss_scale']:
+    hp = HParams(dtype=row['dtype'], loss_scale=row['loss_scale'])
+    assert hp.get_loss_scale() == float(row['result']), row
+  assert HParams(dtype='bf16').get_loss_scale() == 1.0      # bf16 (this implementation's compute type) needs none
