@@ -274,9 +274,16 @@ class Trainer(object):
     ops.eval_accumulate(conf, top1, top5, self.eval_state)
     return pred
 
-  def eval_result(self) -> dict:
-    """{'accuracy', 'accuracy_top_5', 'ece'} from the running state (metric/ece_metric.py:271-279)."""
-    st = self.eval_state.double().cpu()
+  def eval_result(self, reduce: bool = True) -> dict:
+    """{'accuracy', 'accuracy_top_5', 'ece'} from the running state (metric/ece_metric.py:271-279).  With an
+    initialised process group the 33 running sums are all-reduced first (cross-replica aggregation, :281-298), so
+    every rank reports the metrics of the whole evaluation set."""
+    st = self.eval_state.clone()
+    if reduce:
+      import torch.distributed as dist
+      if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+    st = st.double().cpu()
     n = float(st[2])
     correct, conf, cnt = st[3:13], st[13:23], st[23:33]
     eps = 1e-7

@@ -72,6 +72,33 @@ def _worker(rank, world, port, out_dir):
   exp[:nd] -= 0.01 * (g[:nd] + 1e-4 * w0[:nd])
   exp[nd:] -= 0.01 * g[nd:]
   assert torch.allclose(tr.model.arena.w32, exp, rtol=1e-5, atol=1e-7)
+  # evaluation metrics: each rank scores its own shard, eval_result() all-reduces the 33 running sums
+  # (metric/ece_metric.py:281-298) and equals a single-process evaluation of the whole batch
+  from oracle import assembled_oracle as O
+  xe = img.float() - torch.tensor(O.CHANNEL_MEANS)
+  tr.eval_reset()
+  tr.eval_step(xe[rank * B:(rank + 1) * B], labels[rank * B:(rank + 1) * B])
+  local = tr.eval_result(reduce=False)
+  both = tr.eval_result()
+  assert local['count'] == B and both['count'] == B * world
+  single = Trainer(hp, seed=0, device='cpu')
+  single.model.build((S, S))
+  single.model.arena.w32.copy_(tr.model.arena.w32)
+  single.model.arena.state.copy_(tr.model.arena.state)
+  single.model.arena.refresh_shadows()
+  single.eval_reset()
+  single.eval_step(xe, labels)
+  want = single.eval_result(reduce=False)
+  for k in ('accuracy', 'accuracy_top_5', 'count'):
+    assert abs(both[k] - want[k]) < 1e-6, (k, both, want)
+  # confidences move by bf16 rounding when the CPU double convolves a batch of 4 instead of 2 x 2
+  assert abs(both['ece'] - want['ece']) < 1e-4, (both, want)
+  # the reduction itself is exact: reduced sums == sum of the per-rank sums
+  gathered_st = [torch.empty_like(tr.eval_state) for _ in range(world)]
+  dist.all_gather(gathered_st, tr.eval_state)
+  st_sum = gathered_st[0] + gathered_st[1]
+  n = float(st_sum[2])
+  assert both['accuracy'] == float(st_sum[0]) / n and both['accuracy_top_5'] == float(st_sum[1]) / n
   if rank == 0:
     open(os.path.join(out_dir, 'ok'), 'w').write('%d buckets' % len(launched))
   dist.barrier()
