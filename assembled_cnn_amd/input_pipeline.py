@@ -121,27 +121,59 @@ def _validate(win: dict, Hs: int, Ws: int, out_h: int, out_w: int):
     raise ValueError('window %r does not fit a %dx%d image / %dx%d output' % (win, Hs, Ws, out_h, out_w))
 
 
-def pack_batch(images: Sequence[np.ndarray], windows: Sequence[dict], out_h: int, out_w: int):
-  """Decoded images (uint8 [H, W, 3], any sizes) -> (packed uint8 buffer, descriptor table bytes), both pinned-able."""
-  if len(images) != len(windows):
+_DESC_DTYPE = np.dtype([('src_offset', '<i8'), ('Hs', '<i4'), ('Ws', '<i4'), ('crop_y', '<i4'), ('crop_x', '<i4'),
+                        ('crop_h', '<i4'), ('crop_w', '<i4'), ('resize_h', '<i4'), ('resize_w', '<i4'),
+                        ('out_y', '<i4'), ('out_x', '<i4'), ('flip', '<i4'), ('reserved', '<i4')])
+assert _DESC_DTYPE.itemsize == ctypes.sizeof(ImageDesc) == 56
+
+
+_STAGING = {}
+
+
+def _staging(nbytes: int, pin: bool) -> torch.Tensor:
+  """Grow-only host staging buffer (re-used across batches: a fresh 150 MB allocation costs more in page faults than
+  the copy itself).  The caller must have consumed the previous batch's H2D copy before packing the next one."""
+  ev = _STAGING.get('event')
+  if pin and ev is not None:
+    ev.synchronize()            # the previous batch's asynchronous H2D copy reads this buffer
+  cur = _STAGING.get(pin)
+  if cur is None or cur.numel() < nbytes:
+    cur = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=pin)
+    _STAGING[pin] = cur
+  return cur
+
+
+def pack_batch(images: Sequence[np.ndarray], windows: Sequence[dict], out_h: int, out_w: int, pin: bool = False):
+  """Decoded images (uint8 [H, W, 3], any sizes) -> (packed uint8 buffer, descriptor table bytes) as CPU tensors
+  (pinned when ``pin``).  One memcpy per image into the staging buffer and a vectorised descriptor table: ~10 GB/s
+  on one core, so the host side keeps up with the GPU (the per-image tensor ops of the first version did 670 img/s)."""
+  n = len(images)
+  if n != len(windows):
     raise ValueError('one window per image')
-  offs, total = [], 0
-  for im in images:
+  sizes = np.empty(n, dtype=np.int64)
+  for k, im in enumerate(images):
     if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
       raise ValueError('Input must be of size [height, width, 3] uint8')     # imagenet_preprocessing.py:143-144
-    offs.append(total)
-    total += (im.size + 15) // 16 * 16
-  buf = torch.empty(max(total, 16), dtype=torch.uint8)
-  descs = (ImageDesc * max(len(images), 1))()
-  for k, (im, win, off) in enumerate(zip(images, windows, offs)):
+    sizes[k] = im.size
+  padded = (sizes + 15) // 16 * 16
+  offs = np.concatenate([[0], np.cumsum(padded)[:-1]]) if n else np.zeros(0, np.int64)
+  total = int(padded.sum()) if n else 0
+  buf = _staging(max(total, 16), pin)
+  dst = buf.numpy()
+  table = torch.zeros(max(n, 1) * 56, dtype=torch.uint8, pin_memory=pin)
+  desc = table.numpy().view(_DESC_DTYPE)
+  for k, (im, win) in enumerate(zip(images, windows)):
     _validate(win, im.shape[0], im.shape[1], out_h, out_w)
-    buf[off:off + im.size] = torch.from_numpy(np.ascontiguousarray(im).reshape(-1))
-    d = descs[k]
-    d.src_offset, d.Hs, d.Ws = off, im.shape[0], im.shape[1]
+    o = int(offs[k])
+    dst[o:o + im.size] = im.reshape(-1)                                       # one memcpy (copies if not contiguous)
+  if n:
+    desc['src_offset'][:n] = offs
+    desc['Hs'][:n] = [im.shape[0] for im in images]
+    desc['Ws'][:n] = [im.shape[1] for im in images]
     for f in ('crop_y', 'crop_x', 'crop_h', 'crop_w', 'resize_h', 'resize_w', 'out_y', 'out_x', 'flip'):
-      setattr(d, f, int(win[f]))
-  table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)[:56 * len(images)].clone()
-  return buf, table
+      desc[f][:n] = [int(w[f]) for w in windows]
+  buf = buf[:max(total, 16)]
+  return buf, table[:56 * n]
 
 
 def preprocess_batch(images: Sequence[np.ndarray], is_training: bool, device, image_size: int = 224,
@@ -157,9 +189,11 @@ def preprocess_batch(images: Sequence[np.ndarray], is_training: bool, device, im
       windows = [train_window(im.shape[0], im.shape[1], side, side, rng, use_random_crop) for im in images]
     else:
       windows = [eval_window(im.shape[0], im.shape[1], side, side, crop_type) for im in images]
-  buf, table = pack_batch(images, windows, side, side)
   dev = torch.device(device)
+  buf, table = pack_batch(images, windows, side, side, pin=dev.type == 'cuda')
+  bd, td = buf.to(dev, non_blocking=True), table.to(dev, non_blocking=True)
   if dev.type == 'cuda':
-    buf, table = buf.pin_memory(), table.pin_memory()
-  return ops.resize_crop_flip(buf.to(dev, non_blocking=True), table.to(dev, non_blocking=True), len(images), side,
-                              side, subtract_mean)
+    ev = torch.cuda.Event()
+    ev.record()
+    _STAGING['event'] = ev
+  return ops.resize_crop_flip(bd, td, len(images), side, side, subtract_mean)
