@@ -388,6 +388,166 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
+// ---- small-tensor batch norm: statistics + finalize + apply in ONE launch (and reduce + finalize + apply backward) ----
+// The SK / SE squeeze layers normalise [N, 1, 1, d] tensors (256 x 32..256 elements): three to four ~5 us launches
+// of pure latency per direction in the general path.  Here one workgroup owns 64 channels x all M rows (M <= 4096):
+// 256 threads = 8 vector columns x 32 row lanes, two passes over data that stays in L1 / L2.
+constexpr int SMALL_BN_MAX_ROWS = 4096;
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int M,
+                                                           int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* moving_mean, float* moving_var, float* mean,
+                                                           float* invstd, uint8_t* __restrict__ mask) {
+  __shared__ float red[2][32][64];
+  __shared__ float coef[2][64];
+  const int vcols = C >> 3;
+  const int vcl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int vc = blockIdx.x * 8 + vcl;
+  const bool live = vc < vcols;
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+  if (live)
+    for (int r = rl; r < M; r += 32) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + (size_t)r * C + vc * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[e] += f[e];
+        ss[e] += f[e] * f[e];
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[0][rl][vcl * 8 + e] = s[e];
+    red[1][rl][vcl * 8 + e] = ss[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch < C) {
+      double a = 0.0, b = 0.0;
+      for (int r = 0; r < 32; ++r) {
+        a += (double)red[0][r][threadIdx.x];
+        b += (double)red[1][r][threadIdx.x];
+      }
+      const double mu = a / (double)M;
+      double var = b / (double)M - mu * mu;
+      if (var < 0.0) var = 0.0;
+      const float is = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = gamma[ch] * is;
+      mean[ch] = (float)mu;
+      invstd[ch] = is;
+      coef[0][threadIdx.x] = sc;
+      coef[1][threadIdx.x] = beta[ch] - (float)mu * sc;
+      if (moving_mean) {
+        const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+        moving_mean[ch] = moving_mean[ch] * momentum + (float)mu * (1.f - momentum);
+        moving_var[ch] = moving_var[ch] * momentum + (float)unbiased * (1.f - momentum);
+      }
+    }
+  }
+  __syncthreads();
+  if (live)
+    for (int r = rl; r < M; r += 32) {
+      const size_t i = (size_t)r * vcols + vc;
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), f);
+      unsigned mk = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        f[e] = f[e] * coef[0][vcl * 8 + e] + coef[1][vcl * 8 + e];
+        if (RELU) {
+          mk |= (f[e] > 0.f ? 1u : 0u) << e;
+          f[e] = fmaxf(f[e], 0.f);
+        }
+      }
+      if (RELU && mask) mask[i] = (uint8_t)mk;
+      *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+    }
+}
+
+template <int RELU>   // 0 none, 2 packed bitmask
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                           const uint8_t* __restrict__ mask, int M, int C,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* dgamma,
+                                                           float* dbeta, bf16_t* __restrict__ dx) {
+  __shared__ float red[2][32][64];
+  __shared__ float coef[3][64];
+  const int vcols = C >> 3;
+  const int vcl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int vc = blockIdx.x * 8 + vcl;
+  const bool live = vc < vcols;
+  float s[8], ss[8], mu[8], is[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s[e] = ss[e] = 0.f;
+    mu[e] = live ? mean[vc * 8 + e] : 0.f;
+    is[e] = live ? invstd[vc * 8 + e] : 0.f;
+  }
+  if (live)
+    for (int r = rl; r < M; r += 32) {
+      const size_t i = (size_t)r * vcols + vc;
+      float g[8], fx[8];
+      unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
+      unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), fx);
+      if (RELU == 2) {
+        const unsigned mk = mask[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[e] += g[e];
+        ss[e] += g[e] * ((fx[e] - mu[e]) * is[e]);
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[0][rl][vcl * 8 + e] = s[e];
+    red[1][rl][vcl * 8 + e] = ss[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch < C) {
+      double db = 0.0, dg = 0.0;
+      for (int r = 0; r < 32; ++r) {
+        db += (double)red[0][r][threadIdx.x];
+        dg += (double)red[1][r][threadIdx.x];
+      }
+      dbeta[ch] = (float)db;
+      dgamma[ch] = (float)dg;
+      const double g = gamma[ch], isd = invstd[ch], m = mean[ch];
+      const double A = g * isd;
+      const double B = -g * isd * isd * dg / (double)M;
+      coef[0][threadIdx.x] = (float)A;
+      coef[1][threadIdx.x] = (float)B;
+      coef[2][threadIdx.x] = (float)(-g * isd * db / (double)M - B * m);
+    }
+  }
+  __syncthreads();
+  if (live)
+    for (int r = rl; r < M; r += 32) {
+      const size_t i = (size_t)r * vcols + vc;
+      float g[8], fx[8], o[8];
+      unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
+      unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), fx);
+      if (RELU == 2) {
+        const unsigned mk = mask[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = coef[0][vcl * 8 + e] * g[e] + coef[1][vcl * 8 + e] * fx[e] + coef[2][vcl * 8 + e];
+      *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(o);
+    }
+}
+
 inline unsigned ew_grid(size_t nvec) {
   size_t b = cdivz(nvec, 256);
   return (unsigned)(b < 4096 ? (b ? b : 1) : 4096);
@@ -506,5 +666,40 @@ extern "C" int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout,
   else { if (dz_out) LAUNCH_BWD(0, true); else LAUNCH_BWD(0, false); }
 #undef LAUNCH_BWD
   ASM_CHECK_LAUNCH("bn_bwd_apply");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_small_max_rows(void) { return SMALL_BN_MAX_ROWS; }
+
+extern "C" int asm_bn_small_fwd(const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
+                                float momentum, float* moving_mean, float* moving_var, float* mean, float* invstd,
+                                int relu, uint8_t* relu_mask_out, void* stream) {
+  ASM_REQUIRE(x && y && gamma && beta && mean && invstd && M > 0 && M <= SMALL_BN_MAX_ROWS && C > 0 && C % 8 == 0,
+              "bn_small_fwd: bad arguments (M=%d C=%d)", M, C);
+  ASM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_small_fwd: moving stats must both be given");
+  const dim3 grid(cdiv(C, 64)), block(256);
+  if (relu)
+    hipLaunchKernelGGL(bn_small_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, M, C,
+                       gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, relu_mask_out);
+  else
+    hipLaunchKernelGGL(bn_small_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, M, C,
+                       gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, nullptr);
+  ASM_CHECK_LAUNCH("bn_small_fwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* relu_mask, int M, int C,
+                                const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                                float* dbeta, void* dx, void* stream) {
+  ASM_REQUIRE(dy && x && gamma && mean && invstd && dgamma && dbeta && dx && M > 0 && M <= SMALL_BN_MAX_ROWS && C > 0 &&
+                  C % 8 == 0, "bn_small_bwd: bad arguments (M=%d C=%d)", M, C);
+  const dim3 grid(cdiv(C, 64)), block(256);
+  if (relu_mask)
+    hipLaunchKernelGGL(bn_small_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+                       relu_mask, M, C, gamma, mean, invstd, dgamma, dbeta, (bf16_t*)dx);
+  else
+    hipLaunchKernelGGL(bn_small_bwd_kernel<0>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+                       nullptr, M, C, gamma, mean, invstd, dgamma, dbeta, (bf16_t*)dx);
+  ASM_CHECK_LAUNCH("bn_small_bwd");
   return ASM_OK;
 }

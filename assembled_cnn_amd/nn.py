@@ -450,7 +450,16 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
   Cn = conv.cout
   gamma, beta = a.w(bn.gamma), a.w(bn.beta)
   res_t = residual.data if residual is not None else None
-  if ctx.training:
+  taped = ctx.tape is not None
+  rm = res_mode if residual is not None else 0
+  # [N, 1, 1, d] squeeze layers (SK / SE fc): the whole BN is one launch per direction instead of 3-4 latency-bound ones
+  small = ctx.training and residual is None and d.Ho * d.Wo == 1 and not conv.stem and ops.bn_small_ok(M)
+  mask_t = None
+  if small:
+    y, _ = conv.fprop(d, x.data, False)
+    out_t, mask_t, mean, invstd = ops.bn_small_fwd(y, M, Cn, gamma, beta, BN_EPS, ctx.bn_momentum, a.st(bn.mm),
+                                                   a.st(bn.mv), relu, want_mask=taped)
+  elif ctx.training:
     y, part = conv.fprop(d, x.data, True)
     mean, invstd, scale, shift = ops.bn_finalize(part, M, Cn, gamma, beta, BN_EPS, ctx.bn_momentum,
                                                  a.st(bn.mm), a.st(bn.mv))
@@ -460,11 +469,9 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
     mean = invstd = None
   if tap_pre is not None:
     ctx.taps[tap_pre] = y
-  if tap_pre is not None:
-    ctx.taps[tap_pre] = y
-  taped = ctx.tape is not None
-  rm = res_mode if residual is not None else 0
-  if taped and relu:   # keep the 1-bit ReLU mask for the backward kernels (16x less traffic than re-reading out)
+  if small:
+    pass
+  elif taped and relu:   # keep the 1-bit ReLU mask for the backward kernels (16x less traffic than re-reading out)
     out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, rm, True, d.Ho, d.Wo, want_mask=True)
   else:
     out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, rm, relu, d.Ho, d.Wo), None
@@ -478,8 +485,12 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
       if dout is None:
         raise RuntimeError('conv_bn backward: no gradient reached this layer')
       want_dz = residual is not None and relu
-      dy, dz = ops.bn_bwd(dout, y, mask_t if relu else None, relu, M, Cn, gamma, mean, invstd, a.g(bn.gamma),
-                          a.g(bn.beta), want_dz)
+      if small:
+        dy, dz = ops.bn_small_bwd(dout, y, mask_t if relu else None, M, Cn, gamma, mean, invstd, a.g(bn.gamma),
+                                  a.g(bn.beta)), None
+      else:
+        dy, dz = ops.bn_bwd(dout, y, mask_t if relu else None, relu, M, Cn, gamma, mean, invstd, a.g(bn.gamma),
+                            a.g(bn.beta), want_dz)
       a.notify_grad(bn.gamma)
       if residual is not None:
         dres = dz if relu else dout

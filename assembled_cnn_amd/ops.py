@@ -273,6 +273,33 @@ def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz
   return dx, dz
 
 
+_SMALL_BN_ROWS = None
+
+
+def bn_small_ok(M: int) -> bool:
+  global _SMALL_BN_ROWS
+  if _SMALL_BN_ROWS is None:
+    _SMALL_BN_ROWS = int(L().asm_bn_small_max_rows())
+  return M <= _SMALL_BN_ROWS
+
+
+def bn_small_fwd(x, M, Cn, gamma, beta, eps, momentum, mm, mv, relu, want_mask):
+  """Whole training-mode BN of a small tensor in one launch -> (y, mask or None, mean, invstd)."""
+  y = torch.empty_like(x)
+  co = empty((2, Cn), F32, x)
+  mask = empty((M, Cn // 8), torch.uint8, x) if (want_mask and relu) else None
+  check(L().asm_bn_small_fwd(_ptr(x), _ptr(y), M, Cn, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(mm), _ptr(mv),
+                             _ptr(co[0]), _ptr(co[1]), 1 if relu else 0, _ptr(mask), _stream()), 'bn_small_fwd')
+  return y, mask, co[0], co[1]
+
+
+def bn_small_bwd(dy, x, mask, M, Cn, gamma, mean, invstd, dgamma, dbeta):
+  dx = torch.empty_like(x)
+  check(L().asm_bn_small_bwd(_ptr(dy), _ptr(x), _ptr(mask), M, Cn, _ptr(gamma), _ptr(mean), _ptr(invstd),
+                             _ptr(dgamma), _ptr(dbeta), _ptr(dx), _stream()), 'bn_small_bwd')
+  return dx
+
+
 # ---------------------------------------------------------------------------------------------------
 # pooling / resampling
 # ---------------------------------------------------------------------------------------------------

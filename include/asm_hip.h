@@ -158,6 +158,17 @@ int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout, int relu, 
                      const float* coefA, const float* coefB, const float* coefC, void* dx,
                      void* dz_out, void* stream);
 
+/* Small tensors (M <= asm_bn_small_max_rows(), e.g. the [N,1,1,d] squeeze layers of sk_conv2d / se_block,
+ * nets/blocks.py:139-146): the whole training-mode batch norm in one launch per direction.
+ * fwd: batch statistics of x (bf16-rounded, as above), moving-statistics update, mean / invstd out, y = bn(x) [relu],
+ *      optional packed ReLU mask [M][C/8].   bwd: dgamma, dbeta and dx from dy, x and the mask (NULL = no ReLU). */
+int asm_bn_small_max_rows(void);
+int asm_bn_small_fwd(const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
+                     float momentum, float* moving_mean, float* moving_var, float* mean, float* invstd, int relu,
+                     uint8_t* relu_mask_out, void* stream);
+int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* relu_mask, int M, int C, const float* gamma,
+                     const float* mean, const float* invstd, float* dgamma, float* dbeta, void* dx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pooling / resampling (NHWC bf16)
  * ---------------------------------------------------------------------------------------------- */

@@ -210,6 +210,56 @@ class CpuDouble(object):
       st[b, 1] = (blk * blk).sum(0)
     return 0
 
+  def asm_bn_small_max_rows(self):
+    return 4096
+
+  def asm_bn_small_fwd(self, x, y, M, Cn, gamma, beta, eps, momentum, mm, mv, mean, invstd, relu, mask, stream):
+    if M <= 0 or M > 4096 or Cn % 8:
+      self._err = b'bn_small_fwd: bad arguments'
+      return -1
+    v = T(x, (M, Cn), 'bf16').double()
+    mu = v.mean(0)
+    var = (v * v).mean(0) - mu * mu
+    var = var.clamp(min=0)
+    isd = (1.0 / torch.sqrt(var + eps)).float()
+    T(mean, (Cn,), 'f32').copy_(mu.float())
+    T(invstd, (Cn,), 'f32').copy_(isd)
+    g, b = T(gamma, (Cn,), 'f32'), T(beta, (Cn,), 'f32')
+    sc = g * isd
+    sh = b - mu.float() * sc
+    if mm:
+      m1, v1 = T(mm, (Cn,), 'f32'), T(mv, (Cn,), 'f32')
+      unb = (var * (M / max(M - 1, 1))).float()
+      m1.mul_(momentum).add_(mu.float() * (1 - momentum))
+      v1.mul_(momentum).add_(unb * (1 - momentum))
+    out = T(x, (M, Cn), 'bf16').float() * sc + sh
+    if relu:
+      if mask:
+        bits = (out > 0).view(M, Cn // 8, 8).to(torch.int32)
+        T(mask, (M, Cn // 8), 'u8').copy_((bits << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8))
+      out = out.clamp(min=0)
+    T(y, (M, Cn), 'bf16').copy_(out)
+    return 0
+
+  def asm_bn_small_bwd(self, dy, x, mask, M, Cn, gamma, mean, invstd, dgamma, dbeta, dx, stream):
+    g = T(dy, (M, Cn), 'bf16').float()
+    xv = T(x, (M, Cn), 'bf16').float()
+    if mask:
+      mk = T(mask, (M, Cn // 8), 'u8').to(torch.int32)
+      bits = ((mk[..., None] >> torch.arange(8, dtype=torch.int32)) & 1).view(M, Cn).bool()
+      g = torch.where(bits, g, torch.zeros_like(g))
+    mu, isd, gm = T(mean, (Cn,), 'f32'), T(invstd, (Cn,), 'f32'), T(gamma, (Cn,), 'f32')
+    xhat = (xv - mu) * isd
+    db = g.double().sum(0)
+    dg = (g * xhat).double().sum(0)
+    T(dbeta, (Cn,), 'f32').copy_(db.float())
+    T(dgamma, (Cn,), 'f32').copy_(dg.float())
+    A = (gm * isd).double()
+    B = -(gm * isd * isd).double() * dg / M
+    Cc = -(gm * isd).double() * db / M - B * mu.double()
+    T(dx, (M, Cn), 'bf16').copy_((A.float() * g + B.float() * xv + Cc.float()))
+    return 0
+
   def asm_bn_partials_compact(self, part, blocks, Cn, out, groups, stream):
     per = -(-blocks // groups)
     assert -(-blocks // per) == groups

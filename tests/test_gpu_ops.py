@@ -344,3 +344,40 @@ def test_elementwise(hip_lib):
   db = torch.empty(10, device='cuda')
   ops.bias_grad_bf16(dz.cuda(), 7, 10, 16, db)
   assert torch.allclose(db.cpu(), dz.float()[:, :10].sum(0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('M,Cn,relu', [(256, 32, True), (256, 256, True), (37, 72, False), (4096, 64, True)])
+def test_bn_small_fused(hip_lib, M, Cn, relu):
+  """one-launch BN of the [N,1,1,d] squeeze layers == the general three-kernel path == oracle batch_norm."""
+  from assembled_cnn_amd import ops
+  x = _rand((M, Cn), 1, scale=2.0)
+  gamma = (torch.rand(Cn, generator=torch.Generator().manual_seed(2)) + 0.5).cuda()
+  beta = (torch.randn(Cn, generator=torch.Generator().manual_seed(3)) * 0.1).cuda()
+  mm, mv = torch.zeros(Cn).cuda(), torch.ones(Cn).cuda()
+  y, mask, mean, invstd = ops.bn_small_fwd(x.cuda(), M, Cn, gamma, beta, 1e-5, 0.997, mm, mv, relu, True)
+  # general path on the same input
+  mm2, mv2 = torch.zeros(Cn).cuda(), torch.ones(Cn).cuda()
+  part = ops.bn_stats(x.cuda(), M, Cn)
+  mean2, invstd2, scale, shift = ops.bn_finalize(part, M, Cn, gamma, beta, 1e-5, 0.997, mm2, mv2)
+  if relu:
+    y2, mask2 = ops.bn_apply(x.cuda(), M, Cn, scale, shift, relu=True, want_mask=True)
+    assert torch.equal(mask, mask2)
+  else:
+    y2 = ops.bn_apply(x.cuda(), M, Cn, scale, shift, relu=False)
+    assert mask is None
+  assert torch.allclose(mean, mean2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, invstd2, rtol=1e-5)
+  assert torch.allclose(mm, mm2, rtol=1e-5, atol=1e-7) and torch.allclose(mv, mv2, rtol=1e-5)
+  _close(y, y2.float().cpu(), name='bn_small fwd vs general')
+  # fp32 reference
+  xf = x.float()
+  mu, var = xf.mean(0), xf.var(0, unbiased=False)
+  ref = (xf - mu) / torch.sqrt(var + 1e-5) * gamma.cpu() + beta.cpu()
+  _close(y, ref.clamp(min=0) if relu else ref, name='bn_small fwd vs fp32')
+  # backward
+  dy = _rand((M, Cn), 4)
+  dg, db = torch.empty(Cn).cuda(), torch.empty(Cn).cuda()
+  dx = ops.bn_small_bwd(dy.cuda(), x.cuda(), mask if relu else None, M, Cn, gamma, mean, invstd, dg, db)
+  dg2, db2 = torch.empty(Cn).cuda(), torch.empty(Cn).cuda()
+  dx2, _ = ops.bn_bwd(dy.cuda(), x.cuda(), mask if relu else None, relu, M, Cn, gamma, mean2, invstd2, dg2, db2, False)
+  _close(dx, dx2.float().cpu(), name='bn_small bwd vs general')
+  assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-3) and torch.allclose(db, db2, rtol=1e-4, atol=1e-3)
