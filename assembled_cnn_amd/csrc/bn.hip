@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
     }
-    *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+    __builtin_nontemporal_store(pack8(f), reinterpret_cast<u32x4*>(y + i * 8));
   }
 }
 
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = kA[e] * g[e] + kB[e] * fx[e] + kC[e];
-    *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(o);
+    __builtin_nontemporal_store(pack8(o), reinterpret_cast<u32x4*>(dx + i * 8));
   }
 }
 
