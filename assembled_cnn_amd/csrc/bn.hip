@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
           const int r = row + u * t.rpb;
           const bool ok = r < row_end;
           const size_t off = (size_t)(ok ? r : row) * C + vc * 8;
-          va[u] = *reinterpret_cast<const u32x4*>(a + off);
+          va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + off));
           if (MODE == 1) {
-            vb[u] = *reinterpret_cast<const u32x4*>(b + off);
+            vb[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(b + off));
             if (relu == 1) vy[u] = *reinterpret_cast<const u32x4*>(c + off);
             if (relu == 2) mk[u] = reinterpret_cast<const uint8_t*>(c)[(size_t)(ok ? r : row) * t.vcols + vc];
           }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
     const unsigned m = fd_div((unsigned)i, fd_vcols);
     const int vc = (int)((unsigned)i - m * (unsigned)vcols);
-    const u32x4 vx = *reinterpret_cast<const u32x4*>(x + i * 8);
+    const u32x4 vx = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + i * 8));
     float f[8];
     unpack8(vx, f);
     if (!fixed) {
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
     float g[8], fx[8];
-    unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
-    unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), fx);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dy + i * 8)), g);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + i * 8)), fx);
     if (RELU == 1) {
       float fy[8];
       unpack8(*reinterpret_cast<const u32x4*>(yout + i * 8), fy);
