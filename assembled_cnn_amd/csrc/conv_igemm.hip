@@ -43,6 +43,10 @@ struct IGemmArgs {
   int wt0, wtr, wts;               // filter tap of loop tap (i, j): wt0 + i * wtr + j * wts   (0, S, 1 normally)
   int y_strided;                   // 1: output row m = (img, ho, wo) goes to y_base + img*y_img + ho*y_row + wo*y_pix
   int y_base, y_img_pitch, y_row_pitch, y_pix_pitch;   // elements
+  // inference-mode batch norm folded into the epilogue (asm_conv2d_fprop_bn): y = [relu](acc * scale[n] + shift[n] + addend)
+  const float* bn_scale;
+  const float* bn_shift;
+  int bn_relu;
 };
 
 // 16 zero bytes: the source of every masked lane of an LDS-DMA load (global_load_lds has no bounds check)
@@ -159,13 +163,29 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
           yoff = (size_t)p.y_base + (size_t)img * p.y_img_pitch + (size_t)ho * p.y_row_pitch +
                  (size_t)wo * p.y_pix_pitch + n0;
         }
-        if (p.addend) {
-          const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) + yoff);
-          float fv[8], fa[8];
+        if (p.addend || p.bn_scale) {   // workgroup-uniform
+          float fv[8];
           unpack8(v, fv);
-          unpack8(av, fa);
+          if (p.bn_scale) {             // fused inference BN on the bf16-rounded conv tile (== the two-pass numerics)
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.bn_scale + n0), s1 = *reinterpret_cast<const f32x4*>(p.bn_scale + n0 + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.bn_shift + n0), h1 = *reinterpret_cast<const f32x4*>(p.bn_shift + n0 + 4);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) fv[e] += fa[e];
+            for (int e = 0; e < 4; ++e) {
+              fv[e] = fv[e] * s0[e] + h0[e];
+              fv[e + 4] = fv[e + 4] * s1[e] + h1[e];
+            }
+          }
+          if (p.addend) {
+            const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) + yoff);
+            float fa[8];
+            unpack8(av, fa);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fv[e] += fa[e];
+          }
+          if (p.bn_relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fv[e] = fmaxf(fv[e], 0.f);
+          }
           v = pack8(fv);
         }
         *reinterpret_cast<u32x4*>(y + yoff) = v;
@@ -811,8 +831,8 @@ extern "C" int asm_conv2d_stats_blocks(const asm_conv_desc* d) {
   return cdiv(d->N * d->Ho * d->Wo, STATS_BM);
 }
 
-extern "C" int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const void* w, void* y,
-                                float* stats_partial, void* stream) {
+static int fprop_impl(const asm_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
+                      const float* bn_scale, const float* bn_shift, const void* residual, int relu, void* stream) {
   if (int e = check_desc(d)) return e;
   ASM_REQUIRE(x && w && y, "conv fprop: null pointer");
   const int64_t xelems = (int64_t)d->N * img_pitch(d);
@@ -821,7 +841,7 @@ extern "C" int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const voi
   ASM_REQUIRE(ldy % (d->out_f32 ? 4 : 8) == 0 && ldy >= d->K, "conv fprop: bad ldy %d", ldy);
   ASM_REQUIRE(!(stats_partial && d->out_f32), "conv fprop: fused statistics need bf16 output");
   IGemmArgs a;
-  a.x = x; a.w = w; a.y = y; a.addend = nullptr; a.stats = stats_partial;
+  a.x = x; a.w = w; a.y = y; a.addend = residual; a.stats = stats_partial;
   a.x_bytes = (unsigned)(xelems * 2);
   a.w_bytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
   a.M = d->N * d->Ho * d->Wo;
@@ -832,9 +852,23 @@ extern "C" int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const voi
   a.so = d->stride; a.sd = 1; a.tsign = 1; a.pad = d->pad;
   a.pad_w = a.pad; a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
   a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
+  a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_relu = relu;
   a.x_img_pitch = (int)img_pitch(d); a.x_row_pitch = row_pitch(d); a.x_pix_pitch = pix_pitch(d);
   a.w_row_pitch = d->R * d->S * d->C;
   return launch(a, d->out_f32 != 0, stats_partial != nullptr, (hipStream_t)stream);
+}
+
+extern "C" int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const void* w, void* y,
+                                float* stats_partial, void* stream) {
+  return fprop_impl(d, x, w, y, stats_partial, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int asm_conv2d_fprop_bn(const asm_conv_desc* d, const void* x, const void* w, void* y, const float* scale,
+                                   const float* shift, const void* residual, int relu, void* stream) {
+  ASM_REQUIRE(d && scale && shift, "conv fprop_bn: null pointer");
+  ASM_REQUIRE(!d->out_f32 && d->K % 8 == 0, "conv fprop_bn: needs bf16 output and K %% 8 == 0 (K=%d)", d->K);
+  ASM_REQUIRE(d->ldy == 0 || d->ldy == d->K, "conv fprop_bn: padded output rows not supported");
+  return fprop_impl(d, x, w, y, nullptr, scale, shift, residual, relu ? 1 : 0, stream);
 }
 
 extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
@@ -859,6 +893,7 @@ extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const vo
   a.w_row_pitch = d->R * d->S * d->K;
   a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
   a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
+  a.bn_scale = a.bn_shift = nullptr; a.bn_relu = 0;
   // Stride-2 3x3: three quarters of the (pixel, tap) pairs of the generic gather are parity misses (multiplied as
   // zeros).  Split dx into its four (h % 2, w % 2) classes instead: within a class every pixel uses the same
   // 1 / 2 / 2 / 4 taps, so each class is a dense stride-1 gather over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-filter

@@ -380,6 +380,12 @@ class ConvKernel(object):
       x = self._stem_view(x)
     return ops.conv_fprop(d, x, self.weight(), want_stats)
 
+  def fprop_bn(self, d, x: torch.Tensor, scale, shift, residual, relu):
+    """inference: conv + folded BN [+ residual] [+ ReLU] in one launch"""
+    if self.stem:
+      x = self._stem_view(x)
+    return ops.conv_fprop_bn(d, x, self.weight(), scale, shift, residual, relu)
+
   def _wgrad(self, d, x: torch.Tensor, dy: torch.Tensor):
     a = self.arena
     if self.stem:
@@ -463,6 +469,10 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
     y, part = conv.fprop(d, x.data, True)
     mean, invstd, scale, shift = ops.bn_finalize(part, M, Cn, gamma, beta, BN_EPS, ctx.bn_momentum,
                                                  a.st(bn.mm), a.st(bn.mv))
+  elif tap_pre is None and not taped and rm in (0, 1) and Cn % 8 == 0:
+    # inference: moving-statistics BN, the shortcut add and the ReLU ride in the conv epilogue (no BN pass at all)
+    scale, shift = ops.bn_infer_coeffs(Cn, gamma, beta, a.st(bn.mm), a.st(bn.mv), BN_EPS)
+    return Var(conv.fprop_bn(d, x.data, scale, shift, res_t if rm == 1 else None, relu))
   else:
     y, _ = conv.fprop(d, x.data, False)
     scale, shift = ops.bn_infer_coeffs(Cn, gamma, beta, a.st(bn.mm), a.st(bn.mv), BN_EPS)

@@ -133,6 +133,17 @@ def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool =
   return y, stats
 
 
+def conv_fprop_bn(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, scale, shift, residual=None, relu=False):
+  """Inference: conv + folded batch norm [+ residual] [+ ReLU] in one launch -> y bf16 [N, Ho, Wo, K]."""
+  y = empty((d.N, d.Ho, d.Wo, d.K), BF16, x)
+  ev = _TIMER.start('fprop', d) if _TIMER is not None else None
+  check(L().asm_conv2d_fprop_bn(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(scale), _ptr(shift), _ptr(residual),
+                                1 if relu else 0, _stream()), 'conv2d_fprop_bn')
+  if ev is not None:
+    ev.record()
+  return y
+
+
 def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional[torch.Tensor] = None
                ) -> torch.Tensor:
   """dx = conv_transpose(dy, w) [+ addend]"""

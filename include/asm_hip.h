@@ -72,6 +72,15 @@ int asm_conv2d_fprop(const asm_conv_desc* d, const void* x, const void* w, void*
                      float* stats_partial, void* stream);
 int asm_conv2d_stats_blocks(const asm_conv_desc* d);
 
+/* Inference (training=False): y = [relu](conv(x, w) * scale[k] + shift[k] [+ residual]) with the moving-statistics
+ * coefficients of asm_bn_infer_coeffs folded into the conv epilogue -- tf.layers.batch_normalization(training=False)
+ * after conv2d_fixed_padding plus the bottleneck's shortcut add / ReLU (nets/model_helper.py:26-37,
+ * nets/resnet_model.py:92-95) without a separate pass.  residual: optional bf16 tensor of the output shape.
+ * bf16 output, K % 8 == 0.  Numerically the two-pass form: the conv tile is rounded to bf16 (it crosses LDS as bf16),
+ * normalised in fp32 and rounded again. */
+int asm_conv2d_fprop_bn(const asm_conv_desc* d, const void* x, const void* w, void* y, const float* scale,
+                        const float* shift, const void* residual, int relu, void* stream);
+
 /* dx = conv_transpose(dy, w).  wt is the filter in [C][R][S][K] layout (asm_filter_transpose).
  * Gradient of tf.layers.conv2d w.r.t. its input, which TF autodiff provides to
  * optimizer.compute_gradients (nets/optimizer_setting.py:30).  If addend != NULL (bf16, dx's shape) the kernel

@@ -115,6 +115,26 @@ class CpuDouble(object):
         st[b, 1] = (blk * blk).sum(0)
     return 0
 
+  def asm_conv2d_fprop_bn(self, d, x, w, y, scale, shift, residual, relu, stream):
+    d = _desc(d)
+    self._validate(d, 'fprop')
+    if d.out_f32 or d.K % 8 or not scale or not shift or (d.ldy and d.ldy != d.K):
+      self._err = b'conv fprop_bn: bad arguments'
+      return -1
+    wt = T(w, (d.K, d.R, d.S, d.C), 'bf16').float()
+    acc = torch.zeros(d.N, d.Ho, d.Wo, d.K)
+    for r in range(d.R):
+      for s in range(d.S):
+        acc += _gather(x, d, r, s) @ wt[:, r, s, :].t()
+    acc = acc.view(-1, d.K).to(torch.bfloat16).float()      # the kernel transposes the tile through LDS as bf16
+    out = acc * T(scale, (d.K,), 'f32') + T(shift, (d.K,), 'f32')
+    if residual:
+      out = out + T(residual, (d.N * d.Ho * d.Wo, d.K), 'bf16').float()
+    if relu:
+      out = out.clamp(min=0)
+    T(y, (d.N * d.Ho * d.Wo, d.K), 'bf16').copy_(out)
+    return 0
+
   def asm_conv2d_dgrad(self, d, dy, wt, addend, dx, stream):
     d = _desc(d)
     self._validate(d, 'dgrad')

@@ -278,3 +278,34 @@ def test_big_tile_variants(hip_lib, shape, tile, mode, monkeypatch):
   y1, _ = ops.conv_fprop(d, x.cuda(), w.cuda())
   # same K-order of accumulation in every tile config -> identical bits
   assert torch.equal(dx, dx1) and torch.equal(y, y1)
+
+
+@pytest.mark.parametrize('shape', [(2, 14, 14, 64, 128, 3, 1), (3, 7, 7, 256, 512, 1, 1), (2, 16, 16, 32, 64, 3, 2),
+                                   (2, 14, 14, 256, 512, 3, 1)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('res,relu', [(False, True), (True, True), (True, False)])
+def test_fprop_with_folded_inference_bn(hip_lib, shape, res, relu):
+  """asm_conv2d_fprop_bn == conv -> bn_apply(moving statistics) [-> + residual] [-> relu], up to the one rounding
+  it saves, and == the fp32 reference."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K, k, stride = shape
+  x = _rand((N, H, W, Cn), 31)
+  w = _rand((K, k, k, Cn), 32, scale=(1.0 / (k * k * Cn)) ** 0.5)
+  g = torch.Generator().manual_seed(33)
+  scale = (torch.rand(K, generator=g) + 0.5)
+  shift = torch.randn(K, generator=g) * 0.2
+  d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
+  ref = _ref_conv(x, w, stride)                                  # fp32 NHWC
+  r = _rand(tuple(ref.shape), 34) if res else None
+  want = ref * scale + shift + (r.float() if res else 0.0)
+  if relu:
+    want = want.clamp(min=0)
+  y = ops.conv_fprop_bn(d, x.cuda(), w.cuda(), scale.cuda(), shift.cuda(), r.cuda() if res else None, relu)
+  _check(y, want, name='fprop_bn vs fp32')
+  y0, _ = ops.conv_fprop(d, x.cuda(), w.cuda())
+  M = y0.numel() // K
+  two = ops.bn_apply(y0.view(M, K), M, K, scale.cuda(), shift.cuda(), r.cuda().view(M, K) if res else None,
+                     1 if res else 0, relu, d.Ho, d.Wo)
+  assert util.rel_l2(y.float().cpu().view(M, K), two.float().cpu()) <= 6e-3
+  with pytest.raises(ValueError):
+    ops.conv_fprop_bn(ops.make_conv_desc(N, H, W, Cn, K, k, k, stride, out_f32=True), x.cuda(), w.cuda(), scale.cuda(),
+                      shift.cuda())
