@@ -23,7 +23,7 @@ RowTiling make_tiling(int M, int C) {
   t.rpb = 256 / t.vcb;
   // <= 1024 partial rows = <= 1024 blocks = 4 workgroups (16 waves) per CU: with 512 the reducers ran at 4.4 TB/s,
   // with 1024 at 5.7 TB/s (occupancy-bound streaming).  The finalize kernels read 1024 rows without a compaction pass.
-  static const int cap = getenv("ASM_BN_ROWS") ? atoi(getenv("ASM_BN_ROWS")) : 1024;
+  const int cap = asm_env_int("ASM_BN_ROWS", 1024);
   int rows = cdiv(M, cap);
   rows = cdiv(rows, t.rpb) * t.rpb;
   if (rows < t.rpb * 4) rows = t.rpb * 4;

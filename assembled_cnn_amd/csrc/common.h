@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "../../include/asm_hip.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
@@ -91,6 +92,27 @@ __device__ __forceinline__ unsigned fd_div(unsigned n, const FastDiv& f) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// Tuning / test knobs are read on EVERY call (never cached in a static): a test process can flip a kernel choice
+// between two launches with setenv.  Cost: one getenv (~100 ns) per knob per launch.
+static inline int asm_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+// > 64 KiB of dynamic LDS needs an explicit per-function opt-in, and the attribute is per DEVICE: `done` is the
+// caller's static per-device flag table (idempotent; a racing second call just repeats the same setting).
+#define ASM_MAX_DEVICES 16
+template <class Kern>
+static inline hipError_t asm_ensure_dyn_lds(Kern kern, int lds_bytes, bool (&done)[ASM_MAX_DEVICES]) {
+  if (lds_bytes <= 64 * 1024) return hipSuccess;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const int slot = (dev >= 0 && dev < ASM_MAX_DEVICES) ? dev : -1;
+  if (slot >= 0 && done[slot]) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e == hipSuccess && slot >= 0) done[slot] = true;
+  return e;
+}
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 
 // buffer resource for raw (stride 0) access: out-of-range offsets load 0

@@ -679,12 +679,9 @@ int launch2_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
   constexpr int NTHR = 64 * WGM * WGN;
   auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (C::LDS > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_set = true;
-  }
+  static bool attr_done[ASM_MAX_DEVICES] = {};
+  if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
+    ASM_FAIL(ASM_EHIP, "igemm2_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(NTHR), C::LDS, st, a);
   ASM_CHECK_LAUNCH("igemm2_kernel");
   return ASM_OK;
@@ -730,12 +727,9 @@ template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, in
 int launch_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE>;
   auto kern = igemm_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in (idempotent; benign race)
-    if (C::LDS > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_set = true;
-  }
+  static bool attr_done[ASM_MAX_DEVICES] = {};
+  if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
+    ASM_FAIL(ASM_EHIP, "igemm_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(C::NT), C::LDS, st, a);
   ASM_CHECK_LAUNCH("igemm_kernel");
   return ASM_OK;
@@ -753,10 +747,7 @@ int launch_mode(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
 
 // staging: 1 = register-staged 2-deep prefetch, 2 = LDS-DMA (see Cfg); 0 = per-layer heuristic.
 // ASM_IGEMM_MODE / ASM_IGEMM_TILE (1 = 128-row tiles, 3 = 256x256) force a choice (tests, tuning).
-int env_int(const char* name) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : 0;
-}
+int env_int(const char* name) { return asm_env_int(name, 0); }
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool ALLOW_DEEP = true>
 int launch_cfg(IGemmArgs& a, bool out_f32, bool stats, int mode, hipStream_t st) {
@@ -776,7 +767,7 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
   const int fmode = env_int("ASM_IGEMM_MODE"), ftile = env_int("ASM_IGEMM_TILE");
   a.fd_howo = make_fastdiv((unsigned)a.HoWo);
   a.fd_wo = make_fastdiv((unsigned)a.Wo);
-  static const int v2 = getenv("ASM_IGEMM_V2") ? atoi(getenv("ASM_IGEMM_V2")) : 1;
+  const int v2 = asm_env_int("ASM_IGEMM_V2", 1);
   if (v2 && fmode == 0) {
     int rc;
     const long long b256v = (long long)cdiv(a.M, 256) * cdiv(a.Co, 256);
@@ -900,7 +891,7 @@ extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const vo
   //   dx(2hh+ph, 2ww+pw) = sum_{i,j} dy(hh + dh0 - i, ww + dw0 - j) . w(r0 + 2i, s0 + 2j),
   //   r0 = (ph + pad) & 1, dh0 = (ph + pad - r0) / 2   (same for columns)
   // written through the strided-output epilogue: 9/4 instead of 9 tap passes.
-  static const int split_ok = getenv("ASM_DGRAD_PARITY") ? atoi(getenv("ASM_DGRAD_PARITY")) : 1;
+  const int split_ok = asm_env_int("ASM_DGRAD_PARITY", 1);
   const bool k3 = d->R == 3 && d->S == 3, k1 = d->R == 1 && d->S == 1 && d->pad == 0;
   if (split_ok && d->stride == 2 && (k3 || k1) && env_int("ASM_IGEMM_MODE") == 0) {
     // a 1x1 / 2 projection touches only the (even, even) class: the other three are zero (or just the addend)

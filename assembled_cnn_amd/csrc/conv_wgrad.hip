@@ -14,6 +14,7 @@
 // [split][Co][cols]; asm_wgrad_reduce sums the slabs in a fixed order (no atomics ->
 // bit-reproducible).  With one split the tile goes straight to dW.
 #include "common.h"
+#include "../../include/asm_hip_debug.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -304,7 +305,7 @@ Plan make_plan(const asm_conv_desc* d) {
   pl.bnw = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);
   pl.bcw = 128;
   // 256 x 256 / 8 waves when dW tiles exactly (no padded MFMAs) and there is enough of it; ASM_WGRAD_BIG=0/1 forces
-  static const int big_env = getenv("ASM_WGRAD_BIG") ? atoi(getenv("ASM_WGRAD_BIG")) : -1;
+  const int big_env = asm_env_int("ASM_WGRAD_BIG", -1);
   // measured: -13..-20 % on the layers with >= 40 GFLOP, +5..+20 % on the small 7x7 / narrow ones; column padding
   // of up to 1/8 (3x3 with 128 input channels: 1152 -> 1280 columns) still nets -14 %
   const int cpad = cdiv(cols, 256) * 256;
@@ -340,6 +341,9 @@ Plan make_plan(const asm_conv_desc* d) {
       splits = sp;
     }
   }
+  // ASM_WGRAD_SPLITS=n forces the pixel split (tests: slab path on small shapes; tuning)
+  const int forced = asm_env_int("ASM_WGRAD_SPLITS", 0);
+  if (forced > 0) splits = forced < msteps ? forced : msteps;
   int steps_per = cdiv(msteps, splits);
   pl.m_per_split = steps_per * WPX;
   pl.splits = cdiv(M, pl.m_per_split);
@@ -353,6 +357,14 @@ extern "C" size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d) {
   Plan pl = make_plan(d);
   if (pl.splits <= 1) return 0;
   return (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float);
+}
+
+extern "C" int asm_conv2d_wgrad_plan(const asm_conv_desc* d, int32_t plan[6]) {
+  ASM_REQUIRE(d && plan, "conv wgrad plan: null pointer");
+  const Plan pl = make_plan(d);
+  plan[0] = pl.bnw; plan[1] = pl.bcw; plan[2] = pl.tiles_n; plan[3] = pl.tiles_c; plan[4] = pl.splits;
+  plan[5] = pl.m_per_split;
+  return ASM_OK;
 }
 
 extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const void* dy, float* dw,
@@ -391,12 +403,9 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   const dim3 grid(pl.tiles_n * pl.tiles_c * pl.splits);
   if (pl.bcw == 256) {
     constexpr int LDS = 2 * (WPX * 512 + WPX * 512);   // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<256, 256>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr_set = true;
-    }
+    static bool attr_done[ASM_MAX_DEVICES] = {};
+    if (hipError_t e = asm_ensure_dyn_lds(wgrad_kernel<256, 256>, LDS, attr_done); e != hipSuccess)
+      ASM_FAIL(ASM_EHIP, "wgrad_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
     hipLaunchKernelGGL((wgrad_kernel<256, 256>), grid, dim3(512), LDS, st, a);
   } else if (pl.bnw == 128) {
     hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);

@@ -1,5 +1,6 @@
 // Element-wise, loss, input-pipeline, optimiser, filter-layout and debug kernels.
 #include "common.h"
+#include "../../include/asm_hip_debug.h"
 
 // ---- error plumbing ------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";

@@ -42,6 +42,13 @@ class GradSync(object):
   def __init__(self, arena, bucket_bytes: int = 32 << 20, group=None, overlap: bool = True):
     if not dist.is_initialized():
       raise RuntimeError('GradSync needs an initialised torch.distributed process group')
+    if not arena.finalized or arena.total_elems <= 0:
+      # Trainer builds the model lazily on the first forward: a GradSync made before that would cut zero buckets and
+      # every later step would all-reduce nothing while the replicas drift apart silently.
+      raise RuntimeError('GradSync needs a built model: call model.build(...) (ParamArena.finalize) first')
+    if overlap and getattr(arena, 'side_stream', None) is not None:
+      raise RuntimeError('GradSync(overlap=True) cannot be combined with the weight-gradient side stream '
+                         '(ASM_WGRAD_STREAM=1): bucket launches are ordered against the compute stream only')
     self.arena = arena
     self.group = group
     self.world_size = dist.get_world_size(group)
@@ -57,12 +64,16 @@ class GradSync(object):
         b.append((start, end))
         end = start
       self.segments.append(b)
+    self._covered = sum(hi - lo for seg in self.segments for lo, hi in seg)
+    if self._covered != arena.total_elems:
+      raise RuntimeError('GradSync buckets cover %d of %d gradient elements' % (self._covered, arena.total_elems))
     self._reset()
     arena.on_grad = self.notify if overlap else None
 
   def _reset(self):
     self._next = [0 for _ in self.segments]     # next bucket (index) to launch per segment
     self._work = []
+    self._reduced = 0
     self._last = [1 << 62 for _ in self.segments]
 
   def _seg_of(self, offset: int) -> int:
@@ -83,6 +94,7 @@ class GradSync(object):
 
   def _launch(self, s: int, i: int):
     lo, hi = self.segments[s][i]
+    self._reduced += hi - lo
     self._work.append(dist.all_reduce(self.arena.g32[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
   def finish(self):
@@ -93,6 +105,8 @@ class GradSync(object):
         self._next[s] += 1
     for w in self._work:
       w.wait()
+    if self._reduced != self.arena.total_elems:
+      raise RuntimeError('gradient exchange covered %d of %d elements' % (self._reduced, self.arena.total_elems))
     self._reset()
 
   # Trainer hook: called between backward and the optimiser

@@ -51,10 +51,6 @@ SIGNATURES = {
     'asm_filter_transpose': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     'asm_filter_transpose_batched': (_I, [_P, _P, _P, _I, C.c_longlong, _P]),
     'asm_filter_transpose_tiled': (_I, [_P, _P, _P, _I, _I, _P]),
-    'asm_conv2d_fprop_naive': (_I, [_D, _P, _P, _P, _P]),
-    'asm_conv2d_dgrad_naive': (_I, [_D, _P, _P, _P, _P]),
-    'asm_conv2d_wgrad_naive': (_I, [_D, _P, _P, _P, _P]),
-    'asm_debug_tr_probe': (_I, [_P, _P]),
     'asm_stem_pack_filter': (_I, [_P, _P, _I, _I, _P]),
     'asm_stem_unpack_grad': (_I, [_P, _P, _I, _I, _P]),
     'asm_stem_pad_input': (_I, [_P, _I, _P, _I, _I, _I, _P]),
@@ -110,6 +106,16 @@ SIGNATURES = {
     'asm_resize_crop_flip': (_I, [_P, C.c_int64, _P, _I, _I, _I, _I, _P, _P]),
 }
 
+# test-only entry points (include/asm_hip_debug.h): bound so tests can call them with full-width pointers, never
+# called by the product package
+DEBUG_SIGNATURES = {
+    'asm_conv2d_fprop_naive': (_I, [_D, _P, _P, _P, _P]),
+    'asm_conv2d_dgrad_naive': (_I, [_D, _P, _P, _P, _P]),
+    'asm_conv2d_wgrad_naive': (_I, [_D, _P, _P, _P, _P]),
+    'asm_debug_tr_probe': (_I, [_P, _P]),
+    'asm_conv2d_wgrad_plan': (_I, [_D, C.POINTER(C.c_int32 * 6)]),
+}
+
 _lib = None
 
 
@@ -122,7 +128,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     raise AsmError('%s not found -- build it with `python -m assembled_cnn_amd.build` '
                    '(there is no CPU fallback)' % path)
   lib = C.CDLL(path)
-  for name, (res, args) in SIGNATURES.items():
+  for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
     fn = getattr(lib, name, None)
     if fn is None:
       raise AsmError('libasm_hip.so does not export %s' % name)

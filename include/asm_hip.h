@@ -109,15 +109,6 @@ int asm_filter_transpose_batched(const void* w_arena, void* wt_arena, const int3
 int asm_filter_transpose_tiled(const void* w_arena, void* wt_arena, const int32_t* table, int nlayers,
                                int total_tiles, void* stream);
 
-/* Debug / test-only direct convolutions (one thread per output element, fp32 accumulate).  They
- * exist so GPU tests can cross-check the MFMA kernels at sizes the CPU oracle cannot reach. */
-int asm_conv2d_fprop_naive(const asm_conv_desc* d, const void* x, const void* w, void* y, void* stream);
-int asm_conv2d_dgrad_naive(const asm_conv_desc* d, const void* dy, const void* w_krsc, void* dx, void* stream);
-int asm_conv2d_wgrad_naive(const asm_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
-
-/* Debug: each lane l of one wave reads ds_read_b64_tr_b16 at LDS element 4*l of lds[i] = i; out[l*4+j]. */
-int asm_debug_tr_probe(void* out256_i16, void* stream);
-
 /* Stem packing for 3-channel first convs (7x7/2 stem nets/resnet_model.py:359-367; 3x3/2 ResNet-D stem
  * :328-333,:344-347): master [K][k][k][3] float32 -> bf16 [K][k][L] rows with L = round_up(4k, 8)
  * (element s*4+c, zero padded), and the gradient unpack [K][k][L] float32 -> [K][k][k][3]. */

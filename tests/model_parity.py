@@ -64,16 +64,17 @@ def inputs(batch, size, seed=1):
   return img, x, labels
 
 
-def check_forward(name, device, batch, size, training, logits_tol, early_tol=4e-3):
+def check_forward(name, device, batch, size, training, logits_tol, early_tol=4e-3, stats=None):
   from oracle import assembled_oracle as O
   om, pm = make_pair(name, device, batch, size)
   d = uses_d(name)
   if not training:
     util.perturb_bn_state(om, 7)
     util.load_oracle_into_product(om, pm)
-  _, x, _ = inputs(batch, size)
-  lo = om(x, training, use_resnet_d=d).detach()
-  lp = pm(x.to(device), training, use_resnet_d=d).float().cpu()
+  _, x, labels = inputs(batch, size)
+  with torch.no_grad():      # forward only: no autograd graph (batch 256 x 224 x 224 would not fit otherwise)
+    lo = om(x, training, use_resnet_d=d).detach()
+  lp = pm(x.to(device), training, use_resnet_d=d, record_tape=False).float().cpu()
   taps_o = om.taps_nhwc()
   assert 'initial_conv' in pm.taps and 'final_dense' in pm.taps
   e0 = util.rel_l2(pm.taps['initial_conv'].float().cpu(), taps_o['initial_conv'].detach())
@@ -90,6 +91,13 @@ def check_forward(name, device, batch, size, training, logits_tol, early_tol=4e-
   margin = (top2[:, 0] - top2[:, 1]) / lo.std(dim=1)
   sure = margin > 0.3
   assert bool((lp.argmax(1)[sure] == lo.argmax(1)[sure]).all()), 'top-1 mismatch on a large-margin row'
+  if stats is not None:
+    stats['top1_agree'] = int((lp.argmax(1) == lo.argmax(1)).sum())
+    stats['rows'] = int(lp.shape[0])
+    oh = F.one_hot(labels.long(), lo.shape[1]).float()
+    stats['loss_oracle'] = float(O.softmax_cross_entropy(lo, oh, 0.0))
+    stats['loss_product'] = float(O.softmax_cross_entropy(lp, oh, 0.0))
+    stats['logits_rel_l2'] = e
   return e
 
 

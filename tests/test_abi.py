@@ -8,8 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-  hdr = open(os.path.join(ROOT, 'include', 'asm_hip.h')).read()
+def _declared(header='asm_hip.h'):
+  hdr = open(os.path.join(ROOT, 'include', header)).read()
   return sorted(set(re.findall(r'\b(asm_[a-z0-9_]+)\s*\(', hdr)))
 
 
@@ -23,6 +23,12 @@ def test_library_exports_every_declared_symbol():
   for n in names:
     assert hasattr(so, n), 'libasm_hip.so does not export %s' % n
   assert sorted(lib.SIGNATURES) == names, 'lib.py binding table and the header disagree'
+  # test-only entry points live in their own header and binding table; the public header declares none of them
+  dbg = _declared('asm_hip_debug.h')
+  assert sorted(lib.DEBUG_SIGNATURES) == dbg and not set(dbg) & set(names)
+  assert not [n for n in names if 'naive' in n or 'debug' in n]
+  for n in dbg:
+    assert hasattr(so, n), 'libasm_hip.so does not export %s' % n
   L = lib.load()
   assert L.asm_abi_version() == lib.ABI_VERSION
 

@@ -20,6 +20,26 @@ def test_forward_eval_mode_config1_style(hip_lib, name):
   mp.check_forward(name, 'cuda', 16, 96, False, 4e-2)
 
 
+def test_config1_literally_r50v1_eval_64_images_224(hip_lib):
+  """BASELINE config 1 (README.md:112-123, scripts/train_vanila_from_scratch.sh:15) as SURVEY 8d writes it: ResNet-50
+  resnet_version=1, eval mode with perturbed moving statistics, 64 seeded uint8 images at 224 x 224: every named tap,
+  the logits, and top-1 agreement >= 63/64."""
+  st = {}
+  mp.check_forward('r50v1', 'cuda', 64, 224, False, 4e-2, stats=st)
+  assert st['rows'] == 64 and st['top1_agree'] >= 63, st
+  assert abs(st['loss_product'] - st['loss_oracle']) <= 2e-2 * abs(st['loss_oracle']), st
+
+
+def test_config3_forward_at_batch_256_224_vs_oracle(hip_lib):
+  """BASELINE config 3 at its own size: Assemble-ResNet-50 (BL + SK + sconv3 + resnet_d), training mode (batch
+  statistics over all 256 images), batch 256 at 224 x 224 -- taps, logits and loss against the oracle's forward
+  (forward only on the CPU side: the autograd graph of a batch-256 step does not fit a host budget)."""
+  st = {}
+  mp.check_forward('a-r50-d', 'cuda', 256, 224, True, 6e-2, stats=st)
+  assert st['rows'] == 256
+  assert abs(st['loss_product'] - st['loss_oracle']) <= 2e-2 * abs(st['loss_oracle']), st
+
+
 @pytest.mark.parametrize('name', ['r50v1', 'a-r50-d', 'se-proj'])
 def test_backward_tape_vs_autograd(hip_lib, name):
   mp.check_backward(name, 'cuda', 16, 64)
