@@ -2,13 +2,19 @@
 
 TEST INFRASTRUCTURE ONLY -- never imported by the product package.
 
-**Parity status: UNPINNED by the reference.**  The reference ships no test,
-golden vector or fixture for any hot-path file and
-TensorFlow 1.14 cannot be installed here, so this restatement cannot be checked
-against outputs of the reference itself.  It is pinned instead by
-(a) hand-computed known-answer tests for every TF-semantics rule
-(``tests/test_oracle_semantics.py``) and (b) topology self-consistency pins
-(parameter / trainable-tensor counts, output shapes; ``tests/test_oracle_topology.py``).
+**Parity status: wiring PINNED to the reference's source, op arithmetic pinned by stated TF rules.**
+The reference ships no test, golden vector or fixture for any hot-path file and
+TensorFlow 1.14 cannot be installed here, so no OUTPUT OF TENSORFLOW pins this restatement.  What does pin it:
+(a) the reference's own ``nets/resnet_model.py``, ``nets/blocks.py``, ``nets/model_helper.py``,
+``functions/model_fns.py``, ``losses/cls_losses.py`` and ``utils/data_util.mixup`` are executed UNMODIFIED under a
+torch-backed ``tensorflow`` stand-in (``oracle/tf_shim``; generator ``tests/golden/make_reference_taps.py``, fixture
+``tests/golden/reference_taps.json``) and ``tests/test_reference_taps.py`` requires this oracle to reproduce every
+variable name / creation order / shape, every named tap and the logits of 8 configurations (all BASELINE ones) to
+1e-9 (inference) / 1e-6 (training mode at batch 2) in float64, plus DropBlock, the losses, mixup and the schedules;
+(b) the arithmetic INSIDE each tf op (SAME padding, fused-BN moving-variance Bessel correction, average-pool
+divisors, label smoothing ...) is restated twice, independently -- here and in the shim -- from the stated TF 1.14
+rules marked [TF-sem], with hand-computed known answers in ``tests/test_oracle_semantics.py``; TensorFlow itself
+never arbitrates; (c) topology pins (parameter / trainable-tensor counts, ``tests/test_oracle_topology.py``).
 
 Everything here is plain PyTorch-CPU *primitive* ops (conv2d / pad / mean ...)
 in fp32 (or fp64) with TF padding / pooling / BN semantics written out
