@@ -123,6 +123,7 @@ class VarStore(object):
 
   # ---- variable getters -----------------------------------------------------------
   def _get(self, table, name, init_fn, requires_grad):
+    self.last_name = name
     if name not in table:
       t = torch.as_tensor(np.asarray(init_fn(), dtype=np.float64)).to(self.dtype)
       if requires_grad:
@@ -177,6 +178,17 @@ class Ctx(object):
     self.vs = store
     self.emulate_bf16 = emulate_bf16
     self.taps: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    # optional per-layer record: kernel name -> conv input; gamma name -> (fused BN group output, residual or None)
+    self.rec_conv_in: Optional[Dict[str, torch.Tensor]] = None
+    self.rec_bn: Optional[Dict[str, Tuple[torch.Tensor, Optional[torch.Tensor]]]] = None
+
+  def note_conv(self, x: torch.Tensor):
+    if self.rec_conv_in is not None:
+      self.rec_conv_in[self.vs.last_name] = x.detach()
+
+  def note_bn(self, gamma_name: str, out: torch.Tensor, residual: Optional[torch.Tensor]):
+    if self.rec_bn is not None:
+      self.rec_bn[gamma_name] = (out.detach(), residual.detach() if residual is not None else None)
 
   def q(self, x: torch.Tensor) -> torch.Tensor:
     """Storage rounding of an activation."""
@@ -209,6 +221,7 @@ def _conv_raw(x: torch.Tensor, w_hwio: torch.Tensor, kernel_size: int, strides: 
 def conv2d_fixed_padding(ctx: Ctx, inputs, filters, kernel_size, strides, layer_name=None):
   cin = inputs.shape[1]
   w = ctx.vs.conv_kernel(kernel_size, cin, filters, layer_name)
+  ctx.note_conv(inputs)
   return ctx.q(_conv_raw(inputs, ctx.qw(w), kernel_size, strides))
 
 
@@ -221,6 +234,7 @@ def _bn_raw(ctx: Ctx, inputs, training, zero_gamma, momentum, epsilon, layer_nam
   """
   c = inputs.shape[1]
   gamma, beta, mm, mv, mm_name, mv_name = ctx.vs.bn_vars(c, zero_gamma, layer_name)
+  ctx.last_gamma_name = mm_name[:-len('moving_mean')] + 'gamma'
   red = [d for d in range(inputs.dim()) if d != 1]
   shape = [1, c] + [1] * (inputs.dim() - 2)
   if training:
@@ -249,7 +263,9 @@ def batch_norm(ctx: Ctx, inputs, training, zero_gamma=False, momentum=0.997, eps
     y = y + residual
   if relu:
     y = F.relu(y)
-  return ctx.q(y)
+  y = ctx.q(y)
+  ctx.note_bn(ctx.last_gamma_name, y, residual)
+  return y
 
 
 # --------------------------------------------------------------------------------------
@@ -329,6 +345,7 @@ def sk_conv2d(ctx: Ctx, inputs, filters, strides, training, r=2, L=32, bn_moment
   d = max(int(filters / r), L)                               # :136
   vs.push_scope('sk_block')
   w1 = vs.conv_kernel(1, filters, d, layer_name='sk_fc_1')
+  ctx.note_conv(fea_s)
   fea_z = ctx.q(_conv_raw(fea_s, ctx.qw(w1), 1, 1))
   fea_z = batch_norm(ctx, fea_z, training, momentum=bn_momentum, relu=True)
   w2 = vs.conv_kernel(1, d, filters * 2, layer_name='sk_fc_2')
@@ -551,11 +568,15 @@ class Model(object):
 
   # -------------------------------------------------------------------------------------
   def __call__(self, inputs_nhwc, training, reuse=False, use_resnet_d=False, keep_prob=1.0,
-               return_embedding=False, dropblock_uniforms=None):
-    """nets/resnet_model.py:305-599.  ``inputs_nhwc``: [N, H, W, 3]."""
+               return_embedding=False, dropblock_uniforms=None, record_layers=False):
+    """nets/resnet_model.py:305-599.  ``inputs_nhwc``: [N, H, W, 3].  ``record_layers`` keeps every conv input and
+    every fused BN-group output (NCHW) in ``self.layer_record`` for the teacher-forced per-layer product checks."""
     vs = self.vars
     vs.begin_call()
     ctx = Ctx(vs, self.emulate_bf16)
+    if record_layers:
+      ctx.rec_conv_in, ctx.rec_bn = OrderedDict(), OrderedDict()
+    self.layer_record = (ctx.rec_conv_in, ctx.rec_bn)
     bnm = self.bn_momentum
     x = ctx.q(inputs_nhwc.permute(0, 3, 1, 2))
     nf = self.num_filters
@@ -650,9 +671,11 @@ class Model(object):
                              'little{}'.format(i + 1), use_bl=True, **common)
         little_e = conv2d_fixed_padding(ctx, little, num_filters * 4, 1, 1)
         little_e = _bn_raw(ctx, little_e, training, False, bnm, 1e-5)  # :495-496 (unrounded)
+        merge_gamma = ctx.last_gamma_name
         vs.pop_scope()
         big_e = upsample2x_nearest(big)                                # :499
         x = ctx.q(F.relu(little_e + big_e))                            # :501, one storage rounding
+        ctx.note_bn(merge_gamma, x, big)                               # residual recorded at its own (half) resolution
         vs.push_scope('merge{}'.format(i + 1))
         x = block_layer(ctx, x, num_filters, True, _bottleneck_block_v1, 1, self.block_strides[i],
                         training, 'merge{}'.format(i + 1), use_bl=True, **common)
@@ -680,6 +703,7 @@ class Model(object):
 
     if self.embedding_size > 0:  # :574-586
       w = vs.conv_kernel(1, x.shape[1], self.embedding_size, layer_name='embedding_dense')
+      ctx.note_conv(x)
       e = ctx.q(_conv_raw(x, ctx.qw(w), 1, 1))
       e = batch_norm(ctx, e, training, momentum=bnm, layer_name='embedding_dense_batch_normalization')
       squeezed = e.flatten(1)

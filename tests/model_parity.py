@@ -223,3 +223,76 @@ def check_train_steps(name, device, batch, size, steps, hp_kwargs, mixup_type=0,
   some = [n for n in om.vars.state if n.endswith('moving_variance')][0]
   assert util.rel_l2(tr.model.arena.st(some).cpu(), om.vars.state[some]) <= 2e-2
   return lp_hist, lo_hist
+
+
+def check_teacher_forced(name, device, batch, size, training=True, out_tol=4e-3, in_tol=1e-2, squeeze_tol=2e-2):
+  """Per-layer parity over the WHOLE network without depth amplification.
+
+  The oracle (bf16-emulating) records the input of every convolution and the output (and residual operand) of every
+  fused conv -> BN [-> + residual] [-> ReLU] group.  The product then runs the same forward pass, but every such
+  group is FED THE ORACLE'S INPUT (teacher forcing), so each comparison sees one product layer on identical bf16
+  inputs -- the per-kernel tolerance (rel-L2 <= 4e-3) applies at layer 150 just as at layer 1:
+    * group output vs the oracle's                                      -> out_tol
+      (squeeze layers -- SK / SE fc on [N,1,1,d], batch statistics over N values only -- squeeze_tol);
+    * the tensor the product itself computed for that group's input (from the previous forced group through its own
+      pooling / blur / SK gap + select / SE / upsample-add kernels) vs the oracle's input, BEFORE it is replaced, and
+      the same for the residual operand                                 -> in_tol
+  Returns the list of (layer, kind, error) sorted by error."""
+  from assembled_cnn_amd import model as pmodel, nn as pnn, ops
+  om, pm = make_pair(name, device, batch, size)
+  d = uses_d(name)
+  if not training:
+    util.perturb_bn_state(om, 7)
+    util.load_oracle_into_product(om, pm)
+  _, x, _ = inputs(batch, size)
+  with torch.no_grad():
+    lo = om(x, training, use_resnet_d=d, record_layers=True).detach()
+  rec_in, rec_bn = om.layer_record
+  errs = []
+
+  def to_dev(t_nchw):
+    return t_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)
+
+  def cmp(got_nhwc, ref_nchw, layer, kind):
+    ref = ref_nchw.permute(0, 2, 3, 1)
+    e = util.rel_l2(got_nhwc.float().cpu().reshape(ref.shape), ref)
+    errs.append((layer, kind, e, tuple(ref.shape)))
+
+  orig = pnn.conv_bn
+
+  def forced(ctx, xv, conv, bn, stride, relu, residual=None, res_mode=0, tap_pre=None):
+    if ctx.dry:
+      return orig(ctx, xv, conv, bn, stride, relu, residual, res_mode, tap_pre)
+    ref_in = rec_in[conv.name]
+    if conv.stem:
+      cmp(xv.data[:, 3:-3, 3:-3, :3], ref_in, conv.name, 'input')
+    else:
+      cmp(xv.data, ref_in, conv.name, 'input')
+      xv = pnn.Var(to_dev(ref_in), needs_grad=False)
+    ref_out, ref_res = rec_bn[bn.gamma]
+    if residual is not None:
+      assert ref_res is not None, bn.gamma
+      cmp(residual.data, ref_res, bn.gamma, 'residual')
+      residual = pnn.Var(to_dev(ref_res), needs_grad=False)
+    out = orig(ctx, xv, conv, bn, stride, relu, residual, res_mode, tap_pre)
+    cmp(out.data, ref_out, bn.gamma, 'squeeze-output' if (ref_out.shape[2] * ref_out.shape[3] == 1) else 'output')
+    return out
+
+  pnn.conv_bn = forced
+  pmodel.conv_bn = forced
+  try:
+    lp = pm(x.to(device), training, use_resnet_d=d, record_tape=False).float().cpu()
+  finally:
+    pnn.conv_bn = orig
+    pmodel.conv_bn = orig
+  # the head: GAP + dense on the (product-computed) output of the last forced group
+  e_logits = util.rel_l2(lp, lo)
+  errs.append(('final_dense', 'logits', e_logits, tuple(lo.shape)))
+  n_groups = sum(1 for e in errs if e[1] in ('output', 'squeeze-output'))
+  assert n_groups == len(rec_bn), 'forced %d groups, the oracle recorded %d' % (n_groups, len(rec_bn))
+  lim = {'output': out_tol, 'squeeze-output': squeeze_tol, 'input': in_tol, 'residual': in_tol, 'logits': in_tol}
+  errs.sort(key=lambda t: -t[2] / lim[t[1]])
+  bad = [t for t in errs if not t[2] <= lim[t[1]]]
+  assert not bad, '%s: %d of %d teacher-forced comparisons out of tolerance; worst: %s' % (
+      name, len(bad), len(errs), ['%s %s %.3e %s' % t for t in bad[:8]])
+  return errs

@@ -20,6 +20,17 @@ def test_forward_eval_mode_config1_style(hip_lib, name):
   mp.check_forward(name, 'cuda', 16, 96, False, 4e-2)
 
 
+@pytest.mark.parametrize('name,batch,size,training', [('r50v1', 16, 64, True), ('a-r50-d', 16, 64, True),
+                                                      ('a-r50', 16, 96, False), ('se-proj', 16, 64, True),
+                                                      ('a-r152', 8, 128, True)])
+def test_teacher_forced_per_layer_parity(hip_lib, name, batch, size, training):
+  """Every conv -> BN [-> + residual] [-> ReLU] group of the whole network on the ORACLE'S input: rel-L2 <= 4e-3 at
+  every depth (2e-2 for the [N,1,1,d] squeeze layers whose batch statistics span N values only), and the product's
+  own non-parametric kernels in between (pools, blur, SK gap / select, SE, upsample-add) <= 1e-2."""
+  errs = mp.check_teacher_forced(name, 'cuda', batch, size, training)
+  assert len(errs) >= 100
+
+
 def test_config1_literally_r50v1_eval_64_images_224(hip_lib):
   """BASELINE config 1 (README.md:112-123, scripts/train_vanila_from_scratch.sh:15) as SURVEY 8d writes it: ResNet-50
   resnet_version=1, eval mode with perturbed moving statistics, 64 seeded uint8 images at 224 x 224: every named tap,

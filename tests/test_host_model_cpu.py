@@ -89,3 +89,11 @@ def test_lr_schedule_and_hparams_match_reference_defaults():
       assert abs(a(step) - b(step)) <= 1e-12, (kind, step)
   with pytest.raises(NotImplementedError):
     train.learning_rate_with_decay('nope', 1, 1, 1, 1, 1, 1, [], [], 1)
+
+
+def test_teacher_forced_per_layer_parity_on_the_double(cpu_double):
+  """The per-layer teacher-forcing harness itself (tests/model_parity.check_teacher_forced) through the host code:
+  every fused group of Assemble-ResNet-50 + D is matched by variable name and compared."""
+  from tests import model_parity as mp
+  errs = mp.check_teacher_forced('a-r50-d', 'cpu', 4, 64)
+  assert len(errs) >= 200 and max(e[2] for e in errs) <= 4e-3
