@@ -13,6 +13,7 @@ momentum / bf16 arenas) so the optimiser and the gradient all-reduce are single 
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -551,6 +552,12 @@ class SKUnit(object):
     ctx.pop_scope()
 
   def __call__(self, ctx: Ctx, x: Var, stride: int) -> Var:
+    # Training path: the BN + ReLU of the 3x3 convolution is applied on the fly by its three readers (pooled sum,
+    # select, their backward twins), so the 2F-channel normalised tensor, its ReLU mask and the gradient df are never
+    # written (csrc/sk_fused.hip).  ASM_SK_FUSED=0 keeps the materialising path (A/B runs, inference uses it too:
+    # there the conv epilogue already emits f).
+    if ctx.training and not ctx.dry and 2 * self.filters <= 2048 and os.environ.get('ASM_SK_FUSED', '1') != '0':
+      return self._call_fused(ctx, x, stride)
     F_ = self.filters
     f = conv_bn(ctx, x, self.conv, self.bn, stride, relu=True)
     N, H, W, _ = f.shape
@@ -578,6 +585,42 @@ class SKUnit(object):
         s.grad = None
         accum_grad(f, df, True)
         bwd_f()                            # -> x.grad
+        v.grad = None
+      ctx.record(bwd)
+    return v
+
+
+  def _call_fused(self, ctx: Ctx, x: Var, stride: int) -> Var:
+    F_ = self.filters
+    conv, bn, a = self.conv, self.bn, ctx.arena
+    N, H, W, _ = x.shape
+    d = conv.desc(N, H, W, stride)
+    M, C2 = N * d.Ho * d.Wo, 2 * F_
+    gamma, beta = a.w(bn.gamma), a.w(bn.beta)
+    y, part = conv.fprop(d, x.data, True)                               # conv + fused statistics :115-118
+    mean, invstd, scale, shift = ops.bn_finalize(part, M, C2, gamma, beta, BN_EPS, ctx.bn_momentum, a.st(bn.mm),
+                                                 a.st(bn.mv))
+    s = Var(ops.sk_gap_bn(y, scale, shift, F_))                         # mean_hw(f0 + f1)  :131-134
+    z = conv_bn(ctx, s, self.fc1, self.bn1, 1, relu=True)               # :137-143
+    att, fc2_bwd, _ = conv_plain(ctx, z, self.fc2, out_f32=True)         # :144-148 (fp32 logits)
+    v = Var(ops.sk_select_bn_fwd(y, scale, shift, att, F_))             # :149-152
+    if ctx.tape is not None:
+      bwd_z = ctx.tape.pop()        # re-sequenced below: select_bwd_att -> fc2 -> (bn1, fc1) -> BN backward -> conv
+      x_t = x.data
+
+      def bwd():
+        dv = v.grad
+        if dv is None:
+          raise RuntimeError('sk unit backward: no gradient reached this layer')
+        datt = ops.sk_select_bn_bwd_att(y, scale, shift, dv, att, F_)
+        fc2_bwd(datt)                      # -> z.grad
+        bwd_z()                            # -> s.grad
+        dy = ops.sk_bn_bwd(dv, att, s.grad, y, scale, shift, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), F_)
+        s.grad = None
+        a.notify_grad(bn.gamma)
+        dx = conv.backward(d, x_t, dy, x.needs_grad, addend=x.grad)     # fan-in add fused into the dgrad epilogue
+        if dx is not None:
+          x.grad, x.grad_owned = dx, True
         v.grad = None
       ctx.record(bwd)
     return v

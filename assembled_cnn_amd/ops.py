@@ -418,6 +418,50 @@ def sk_select_bwd_f(dv, att, ds, F_):
   return df
 
 
+# fused form: the 3x3 convolution's batch norm + ReLU applied on the fly (y = conv output [N,H,W,2F], never normalised in HBM)
+def sk_gap_bn(y, scale, shift, F_):
+  N, H, W, _ = y.shape
+  s = empty((N, 1, 1, F_), BF16, y)
+  check(L().asm_sk_gap_bn(_ptr(y), _ptr(scale), _ptr(shift), _ptr(s), N, H * W, F_, _stream()), 'sk_gap_bn')
+  return s
+
+
+def sk_select_bn_fwd(y, scale, shift, att, F_):
+  N, H, W, _ = y.shape
+  v = empty((N, H, W, F_), BF16, y)
+  check(L().asm_sk_select_bn_fwd(_ptr(y), _ptr(scale), _ptr(shift), _ptr(att), _ptr(v), N, H * W, F_, _stream()),
+        'sk_select_bn_fwd')
+  return v
+
+
+def sk_select_bn_bwd_att(y, scale, shift, dv, att, F_):
+  N, H, W, _ = y.shape
+  datt = empty((N, 1, 1, 2 * F_), BF16, y)
+  check(L().asm_sk_select_bn_bwd_att(_ptr(y), _ptr(scale), _ptr(shift), _ptr(dv), _ptr(att), _ptr(datt), N, H * W, F_,
+                                     _stream()), 'sk_select_bn_bwd_att')
+  return datt
+
+
+def sk_bn_bwd(dv, att, ds, y, scale, shift, gamma, mean, invstd, dgamma, dbeta, F_):
+  """BN backward of the SK unit's 2F-channel batch norm from dV (df is rebuilt in registers) -> dy [N,H,W,2F]."""
+  N, H, W, C2 = y.shape
+  HW, M = H * W, N * H * W
+  blocks = L().asm_sk_bn_bwd_blocks(N, HW, F_)
+  if blocks <= 0:
+    raise ValueError('sk_bn_bwd: bad shape')
+  part = empty((blocks, 2, C2), F32, y)
+  check(L().asm_sk_bn_bwd_reduce(_ptr(dv), _ptr(att), _ptr(ds), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
+                                 _ptr(invstd), N, HW, F_, _ptr(part), _stream()), 'sk_bn_bwd_reduce')
+  part = _compact(part, C2)
+  co = empty((3, C2), F32, y)
+  check(L().asm_bn_bwd_finalize(_ptr(part), part.shape[0], M, C2, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma),
+                                _ptr(dbeta), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _stream()), 'bn_bwd_finalize')
+  dy = torch.empty_like(y)
+  check(L().asm_sk_bn_bwd_apply(_ptr(dv), _ptr(att), _ptr(ds), _ptr(y), _ptr(scale), _ptr(shift), _ptr(co[0]),
+                                _ptr(co[1]), _ptr(co[2]), _ptr(dy), N, HW, F_, _stream()), 'sk_bn_bwd_apply')
+  return dy
+
+
 def se_scale_fwd(x, e):
   N, H, W, Cn = x.shape
   y = torch.empty_like(x)

@@ -206,6 +206,26 @@ int asm_sk_select_fwd(const void* f, const float* att, void* v, int N, int HW, i
 int asm_sk_select_bwd_att(const void* f, const void* dv, const float* att, void* datt, int N, int HW, int F, void* stream);
 /* df_b = a_b*dV + ds[n][c]/HW  -> bf16 [N,HW,2F]  (ds: bf16 [N,F], gradient of the pooled vector) */
 int asm_sk_select_bwd_f(const void* dv, const float* att, const void* ds, void* df, int N, int HW, int F, void* stream);
+/* The same unit with the batch norm + ReLU of its 3x3 convolution applied on the fly (training path): y is the
+ * convolution output [N, HW, 2F] bf16, scale / shift the per-channel coefficients of asm_bn_finalize, and
+ * f = bf16(relu(y * scale + shift)) is recomputed wherever blocks.sk_conv2d reads it (nets/blocks.py:126-152) instead
+ * of being written by asm_bn_apply and re-read; its ReLU mask and the gradient df = a_b dV + ds/HW are never
+ * materialised either.  gap: s = mean_hw(f0 + f1); select: V = a0 f0 + a1 f1; bwd_att: as asm_sk_select_bwd_att. */
+int asm_sk_gap_bn(const void* y, const float* scale, const float* shift, void* s, int N, int HW, int F, void* stream);
+int asm_sk_select_bn_fwd(const void* y, const float* scale, const float* shift, const float* att, void* v, int N,
+                         int HW, int F, void* stream);
+int asm_sk_select_bn_bwd_att(const void* y, const float* scale, const float* shift, const void* dv, const float* att,
+                             void* datt, int N, int HW, int F, void* stream);
+/* Backward of that 2F-channel batch norm fed with dV directly: dz = (a_b dV + ds/HW) * [y*scale+shift > 0].
+ * reduce writes asm_sk_bn_bwd_blocks(N, HW, F) partial rows [rows][2][2F] (sum dz, sum dz*xhat) for
+ * asm_bn_bwd_finalize; apply writes dy = A dz + B y + C (bf16 [N, HW, 2F]) -- the gradient of the 3x3 convolution. */
+int asm_sk_bn_bwd_blocks(int N, int HW, int F);
+int asm_sk_bn_bwd_reduce(const void* dv, const float* att, const void* ds, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, int N, int HW, int F,
+                         float* partial, void* stream);
+int asm_sk_bn_bwd_apply(const void* dv, const float* att, const void* ds, const void* y, const float* scale,
+                        const float* shift, const float* coefA, const float* coefB, const float* coefC, void* dy,
+                        int N, int HW, int F, void* stream);
 /* SE: y = x * sigmoid(e[n][c]);  e float32 [N, C] (pre-sigmoid) */
 int asm_se_scale_fwd(const void* x, const float* e, void* y, int N, int HW, int C, void* stream);
 /* de[n][c] = sigmoid'(e) * sum_hw x*dy (bf16 out) */

@@ -514,6 +514,60 @@ class CpuDouble(object):
     out[:, :, 1] = ((1 - a0) * g + u).to(torch.bfloat16)
     return 0
 
+  # ---- SK unit with the 3x3 conv's BN + ReLU applied on the fly ----
+  def _f_from_y(self, y, scale, shift, N, HW, F_):
+    yy = T(y, (N, HW, 2 * F_), 'bf16').float()
+    f = torch.relu(yy * T(scale, (2 * F_,), 'f32') + T(shift, (2 * F_,), 'f32'))
+    return f.to(torch.bfloat16).float().view(N, HW, 2, F_), yy
+
+  def asm_sk_gap_bn(self, y, scale, shift, s, N, HW, F_, stream):
+    f, _ = self._f_from_y(y, scale, shift, N, HW, F_)
+    T(s, (N, F_), 'bf16').copy_((f[:, :, 0] + f[:, :, 1]).mean(1))
+    return 0
+
+  def asm_sk_select_bn_fwd(self, y, scale, shift, att, v, N, HW, F_, stream):
+    f, _ = self._f_from_y(y, scale, shift, N, HW, F_)
+    a0 = self._a0(att, N, F_)[:, None, :]
+    T(v, (N, HW, F_), 'bf16').copy_(a0 * f[:, :, 0] + (1 - a0) * f[:, :, 1])
+    return 0
+
+  def asm_sk_select_bn_bwd_att(self, y, scale, shift, dv, att, datt, N, HW, F_, stream):
+    f, _ = self._f_from_y(y, scale, shift, N, HW, F_)
+    g = T(dv, (N, HW, F_), 'bf16').float()
+    a0 = self._a0(att, N, F_)
+    d0 = a0 * (1 - a0) * ((f[:, :, 0] - f[:, :, 1]) * g).sum(1)
+    out = T(datt, (N, 2, F_), 'bf16')
+    out[:, 0] = d0.to(torch.bfloat16)
+    out[:, 1] = (-d0).to(torch.bfloat16)
+    return 0
+
+  def asm_sk_bn_bwd_blocks(self, N, HW, F_):
+    return N
+
+  def _sk_dz(self, dv, att, ds, y, scale, shift, N, HW, F_):
+    f, yy = self._f_from_y(y, scale, shift, N, HW, F_)
+    g = T(dv, (N, HW, 1, F_), 'bf16').float()
+    a0 = self._a0(att, N, F_)[:, None, :]
+    ab = torch.stack([a0, 1 - a0], 2)                      # [N,1,2,F]
+    u = T(ds, (N, 1, 1, F_), 'bf16').float() / HW
+    pre = yy * T(scale, (2 * F_,), 'f32') + T(shift, (2 * F_,), 'f32')
+    df = (ab * g + u).reshape(N, HW, 2 * F_)
+    return torch.where(pre > 0, df, torch.zeros_like(df)), yy
+
+  def asm_sk_bn_bwd_reduce(self, dv, att, ds, y, scale, shift, mean, invstd, N, HW, F_, part, stream):
+    dz, yy = self._sk_dz(dv, att, ds, y, scale, shift, N, HW, F_)
+    xhat = (yy - T(mean, (2 * F_,), 'f32')) * T(invstd, (2 * F_,), 'f32')
+    out = T(part, (N, 2, 2 * F_), 'f32')
+    out[:, 0] = dz.sum(1)
+    out[:, 1] = (dz * xhat).sum(1)
+    return 0
+
+  def asm_sk_bn_bwd_apply(self, dv, att, ds, y, scale, shift, cA, cB, cC, dy, N, HW, F_, stream):
+    dz, yy = self._sk_dz(dv, att, ds, y, scale, shift, N, HW, F_)
+    C2 = 2 * F_
+    T(dy, (N, HW, C2), 'bf16').copy_(T(cA, (C2,), 'f32') * dz + T(cB, (C2,), 'f32') * yy + T(cC, (C2,), 'f32'))
+    return 0
+
   def asm_se_scale_fwd(self, x, e, y, N, HW, Cn, stream):
     s = torch.sigmoid(T(e, (N, 1, Cn), 'f32'))
     T(y, (N, HW, Cn), 'bf16').copy_(T(x, (N, HW, Cn), 'bf16').float() * s)

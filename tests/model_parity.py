@@ -278,18 +278,32 @@ def check_teacher_forced(name, device, batch, size, training=True, out_tol=4e-3,
     cmp(out.data, ref_out, bn.gamma, 'squeeze-output' if (ref_out.shape[2] * ref_out.shape[3] == 1) else 'output')
     return out
 
+  # the fused SK unit never materialises its normalised 3x3 output: force its input; its pooled vector is checked as
+  # the forced input of sk_fc_1 and its selected output V at the input of the block's last 1x1 convolution
+  fused_groups = []
+  orig_sk = pnn.SKUnit._call_fused
+
+  def forced_sk(self, ctx, xv, stride):
+    ref_in = rec_in[self.conv.name]
+    cmp(xv.data, ref_in, self.conv.name, 'input')
+    fused_groups.append(self.bn.gamma)
+    return orig_sk(self, ctx, pnn.Var(to_dev(ref_in), needs_grad=False), stride)
+
   pnn.conv_bn = forced
   pmodel.conv_bn = forced
+  pnn.SKUnit._call_fused = forced_sk
   try:
     lp = pm(x.to(device), training, use_resnet_d=d, record_tape=False).float().cpu()
   finally:
     pnn.conv_bn = orig
     pmodel.conv_bn = orig
+    pnn.SKUnit._call_fused = orig_sk
   # the head: GAP + dense on the (product-computed) output of the last forced group
   e_logits = util.rel_l2(lp, lo)
   errs.append(('final_dense', 'logits', e_logits, tuple(lo.shape)))
   n_groups = sum(1 for e in errs if e[1] in ('output', 'squeeze-output'))
-  assert n_groups == len(rec_bn), 'forced %d groups, the oracle recorded %d' % (n_groups, len(rec_bn))
+  assert n_groups + len(fused_groups) == len(rec_bn), 'forced %d + %d groups, the oracle recorded %d' % (
+      n_groups, len(fused_groups), len(rec_bn))
   lim = {'output': out_tol, 'squeeze-output': squeeze_tol, 'input': in_tol, 'residual': in_tol, 'logits': in_tol}
   errs.sort(key=lambda t: -t[2] / lim[t[1]])
   bad = [t for t in errs if not t[2] <= lim[t[1]]]

@@ -381,3 +381,54 @@ def test_bn_small_fused(hip_lib, M, Cn, relu):
   dx2, _ = ops.bn_bwd(dy.cuda(), x.cuda(), mask if relu else None, relu, M, Cn, gamma, mean2, invstd2, dg2, db2, False)
   _close(dx, dx2.float().cpu(), name='bn_small bwd vs general')
   assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-3) and torch.allclose(db, db2, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('N,H,W,F_', [(4, 14, 14, 64), (3, 28, 28, 32), (2, 7, 7, 1024), (5, 9, 9, 24), (2, 56, 56, 64)])
+def test_sk_unit_with_bn_applied_on_the_fly_equals_materialised_path(hip_lib, N, H, W, F_):
+  """csrc/sk_fused.hip against the kernels it replaces, on the same conv output y:
+  bn_apply -> sk_gap / sk_select / sk_select_bwd_att / sk_select_bwd_f -> bn_bwd  ==  the on-the-fly forms.
+  Forward pieces are bit-identical (f is rounded to bf16 at the same point); the BN backward differs only by the bf16
+  rounding of df that the fused form skips."""
+  from assembled_cnn_amd import ops
+  C2, M, HW = 2 * F_, N * H * W, H * W
+  g = torch.Generator().manual_seed(F_ + H)
+  y = (torch.randn((N, H, W, C2), generator=g) * 1.5 + 0.2).to(torch.bfloat16).cuda()
+  gamma = (torch.rand(C2, generator=g) + 0.5).cuda()
+  beta = (torch.randn(C2, generator=g) * 0.3).cuda()
+  att = (torch.randn((N, 1, 1, C2), generator=g) * 2).cuda()
+  dv = torch.randn((N, H, W, F_), generator=g).to(torch.bfloat16).cuda()
+  ds = torch.randn((N, 1, 1, F_), generator=g).to(torch.bfloat16).cuda()
+  part = ops.bn_stats(y.view(M, C2), M, C2)
+  mean, invstd, scale, shift = ops.bn_finalize(part, M, C2, gamma, beta, 1e-5, 0.997, None, None)
+  # materialising path
+  f, mask = ops.bn_apply(y.view(M, C2), M, C2, scale, shift, None, 0, True, H, W, want_mask=True)
+  f = f.view(N, H, W, C2)
+  s0 = ops.sk_gap(f, F_)
+  v0 = ops.sk_select_fwd(f, att, F_)
+  datt0 = ops.sk_select_bwd_att(f, dv, att, F_)
+  df = ops.sk_select_bwd_f(dv, att, ds, F_)
+  dg0, db0 = torch.empty(C2, device='cuda'), torch.empty(C2, device='cuda')
+  dy0, _ = ops.bn_bwd(df.view(M, C2), y.view(M, C2), mask, True, M, C2, gamma, mean, invstd, dg0, db0, False)
+  # on the fly
+  s1 = ops.sk_gap_bn(y, scale, shift, F_)
+  v1 = ops.sk_select_bn_fwd(y, scale, shift, att, F_)
+  datt1 = ops.sk_select_bn_bwd_att(y, scale, shift, dv, att, F_)
+  dg1, db1 = torch.empty(C2, device='cuda'), torch.empty(C2, device='cuda')
+  dy1 = ops.sk_bn_bwd(dv, att, ds, y, scale, shift, gamma, mean, invstd, dg1, db1, F_)
+  assert torch.equal(v0, v1), 'select'
+  assert util.rel_l2(s1.float(), s0.float()) <= 2e-3 and util.rel_l2(datt1.float(), datt0.float()) <= 4e-3
+  assert util.rel_l2(dg1, dg0) <= 4e-3 and util.rel_l2(db1, db0) <= 4e-3
+  assert util.rel_l2(dy1.float(), dy0.float()) <= 6e-3
+  # and against fp32 autograd of the definition (nets/blocks.py:126-152 + tf.layers.batch_normalization backward)
+  yy = y.float().cpu().requires_grad_(True)
+  mu = yy.mean((0, 1, 2))
+  var = ((yy - mu) ** 2).mean((0, 1, 2))
+  fr = torch.relu((yy - mu) * torch.rsqrt(var + 1e-5) * gamma.cpu() + beta.cpu())
+  f0, f1 = fr[..., :F_], fr[..., F_:]
+  a = torch.softmax(torch.stack([att.cpu()[..., :F_], att.cpu()[..., F_:]], 0), 0)
+  sr = (f0 + f1).mean((1, 2), keepdim=True)
+  vr = a[0] * f0 + a[1] * f1
+  (gy,) = torch.autograd.grad([vr, sr], [yy], [dv.float().cpu(), ds.float().cpu()])
+  assert util.rel_l2(v1.float().cpu(), vr.detach()) <= 4e-3
+  assert util.rel_l2(s1.float().cpu(), sr.detach()) <= 4e-3
+  assert util.rel_l2(dy1.float().cpu(), gy) <= 8e-3
