@@ -36,6 +36,34 @@ class ConvDesc(C.Structure):
               ('ldy', C.c_int32), ('out_f32', C.c_int32)]
 
 
+class ModelCfg(C.Structure):
+  """struct asm_model_cfg"""
+  _fields_ = [(n, C.c_int32) for n in (
+      'resnet_size', 'resnet_version', 'num_classes', 'use_se_block', 'use_sk_block', 'use_resnet_d',
+      'anti_alias_filter_size', 'anti_alias_type', 'bl_alpha', 'bl_beta', 'zero_gamma', 'no_downsample', 'pool_type',
+      'embedding_size', 'dtype', 'mixup_type')] + [(n, C.c_float) for n in (
+          'bn_momentum', 'bn_eps', 'loss_scale', 'label_smoothing', 'kd_temp', 'weight_decay', 'momentum')]
+
+
+class PlanEntry(C.Structure):
+  """struct asm_plan_entry"""
+  _fields_ = [(n, C.c_int32) for n in ('kind', 'N', 'H', 'W', 'C', 'K', 'R', 'S', 'stride', 'Ho', 'Wo', 'flags',
+                                       'trainable', 'reserved')] + [
+      ('param_offset', C.c_int64), ('param_elems', C.c_int64), ('name', C.c_char * 112)]
+
+
+class PlanSummary(C.Structure):
+  """struct asm_plan_summary"""
+  _fields_ = [('n_entries', C.c_int32), ('trainable_tensors', C.c_int32), ('trainable_elems', C.c_int64),
+              ('forward_macs_per_image', C.c_int64), ('wgrad_workspace_bytes', C.c_int64)]
+
+
+ASM_F32, ASM_BF16, ASM_F16 = 0, 1, 2
+ASM_AA_SCONV, ASM_AA_PROJ = 1, 2
+POOL_TYPES = {'gap': 0, 'gem': 1, 'flatten': 2}
+(PLAN_CONV, PLAN_BN, PLAN_DENSE, PLAN_MAXPOOL, PLAN_AVGPOOL, PLAN_BLURPOOL, PLAN_GAP, PLAN_GEM, PLAN_FLATTEN, PLAN_SK_GAP,
+ PLAN_SK_SELECT, PLAN_SE_SCALE, PLAN_ADD) = range(13)
+
 _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
 
@@ -110,6 +138,7 @@ SIGNATURES = {
     'asm_bn_small_fwd': (_I, [_P, _P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _P]),
     'asm_bn_small_bwd': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'asm_resize_crop_flip': (_I, [_P, C.c_int64, _P, _I, _I, _I, _I, _P, _P]),
+    'asm_model_plan': (_I, [C.POINTER(ModelCfg), _I, _I, _I, C.POINTER(PlanEntry), _I, C.POINTER(PlanSummary)]),
 }
 
 # test-only entry points (include/asm_hip_debug.h): bound so tests can call them with full-width pointers, never

@@ -84,12 +84,15 @@ def make_conv_desc(N, H, W, Cin, K, R, S, stride, pad=None, Ho=None, Wo=None, ld
 
 
 class ConvTimer(object):
-  """HIP-event timing of convolution launches on the launch stream (bench.py's roofline leg).
-  ``only`` restricts timing to one (kind, shape-key) class; otherwise every conv launch is timed."""
+  """HIP-event timing of kernel launches on the launch stream (bench.py's roofline leg).
+  ``only`` restricts convolution timing to one (kind, shape-key) class; otherwise every conv launch is timed.
+  With ``classes`` the batch-norm family is timed too, as one class with its algorithmic bytes per call."""
 
-  def __init__(self, only=None):
+  def __init__(self, only=None, classes=False):
     self.only = only
+    self.classes = classes
     self.events = {}
+    self.class_events = {}
 
   @staticmethod
   def key(kind, d):
@@ -105,9 +108,22 @@ class ConvTimer(object):
     self.events.setdefault(k, []).append((e0, e1))
     return e1
 
+  def start_class(self, cls, work):
+    """-> the end event (record it after the launches); ``work`` = algorithmic bytes (or FLOPs) of the call"""
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    self.class_events.setdefault(cls, []).append((e0, e1, float(work)))
+    return e1
+
   def summary(self):
     """key -> (launches, total ms); call after a device synchronize."""
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.events.items()}
+
+  def class_summary(self):
+    """class -> (calls, total ms, total work)"""
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v), sum(w for _, _, w in v))
+            for k, v in self.class_events.items()}
 
 
 _TIMER: Optional[ConvTimer] = None
@@ -116,6 +132,10 @@ _TIMER: Optional[ConvTimer] = None
 def set_conv_timer(t: Optional[ConvTimer]):
   global _TIMER
   _TIMER = t
+
+
+def _bn_ev(nbytes):
+  return _TIMER.start_class('bn', nbytes) if (_TIMER is not None and _TIMER.classes) else None
 
 
 def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool = False
@@ -240,11 +260,14 @@ def _compact(part: torch.Tensor, Cn: int) -> torch.Tensor:
 
 def bn_finalize(part, M, Cn, gamma, beta, eps, momentum, mm, mv):
   """-> mean, invstd, scale, shift (each [C] f32); updates moving stats in place when given."""
+  ev = _bn_ev(part.numel() * 4.0)
   part = _compact(part, Cn)
   co = empty((4, Cn), F32, part)
   check(L().asm_bn_finalize(_ptr(part), part.shape[0], M, Cn, _ptr(gamma), _ptr(beta), eps, momentum,
                             _ptr(mm), _ptr(mv), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _ptr(co[3]),
                             _stream()), 'bn_finalize')
+  if ev is not None:
+    ev.record()
   return co[0], co[1], co[2], co[3]
 
 
@@ -259,8 +282,11 @@ def bn_apply(x, M, Cn, scale, shift, residual=None, res_mode=0, relu=False, H=0,
   """-> y, or (y, packed ReLU mask [M, C/8] uint8) with want_mask."""
   y = torch.empty_like(x)
   mask = empty((M, Cn // 8), torch.uint8, x) if (want_mask and relu) else None
+  ev = _bn_ev(M * Cn * (4.0 + (2.0 if res_mode == 1 else 0.5 if res_mode == 2 else 0.0) + (0.125 if mask is not None else 0.0)))
   check(L().asm_bn_apply(_ptr(x), _ptr(y), M, Cn, _ptr(scale), _ptr(shift), _ptr(residual), res_mode,
                          1 if relu else 0, H, W, _ptr(mask), _stream()), 'bn_apply')
+  if ev is not None:
+    ev.record()
   return (y, mask) if want_mask else y
 
 
@@ -268,6 +294,7 @@ def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz
   """-> dx, dz (dz None unless want_dz).  dgamma/dbeta: f32 [C] views, overwritten.
   ``yout`` is the bf16 forward output or (uint8) the packed ReLU mask from bn_apply(want_mask=True)."""
   rk = 0 if not relu else (2 if yout.dtype == torch.uint8 else 1)
+  ev = _bn_ev(M * Cn * (2 * 4.0 + 2.0 + (2.0 if want_dz else 0.0) + 2 * (0.125 if rk == 2 else 2.0 if rk == 1 else 0.0)))
   blocks = L().asm_bn_stats_blocks(M, Cn)
   part = empty((blocks, 2, Cn), F32, dy)
   check(L().asm_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(yout if relu else None), rk, M, Cn,
@@ -281,6 +308,8 @@ def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz
   dz = torch.empty_like(x) if want_dz else None
   check(L().asm_bn_bwd_apply(_ptr(dy), _ptr(x), _ptr(yout if relu else None), rk, M, Cn,
                              _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _ptr(dx), _ptr(dz), _stream()), 'bn_bwd_apply')
+  if ev is not None:
+    ev.record()
   return dx, dz
 
 
@@ -449,6 +478,7 @@ def sk_bn_bwd(dv, att, ds, y, scale, shift, gamma, mean, invstd, dgamma, dbeta, 
   blocks = L().asm_sk_bn_bwd_blocks(N, HW, F_)
   if blocks <= 0:
     raise ValueError('sk_bn_bwd: bad shape')
+  ev = _bn_ev(M * (2 * (2.0 * C2 + 2.0 * F_) + 2.0 * C2))     # two passes over (y, dV), one write of dy
   part = empty((blocks, 2, C2), F32, y)
   check(L().asm_sk_bn_bwd_reduce(_ptr(dv), _ptr(att), _ptr(ds), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
                                  _ptr(invstd), N, HW, F_, _ptr(part), _stream()), 'sk_bn_bwd_reduce')
@@ -459,6 +489,8 @@ def sk_bn_bwd(dv, att, ds, y, scale, shift, gamma, mean, invstd, dgamma, dbeta, 
   dy = torch.empty_like(y)
   check(L().asm_sk_bn_bwd_apply(_ptr(dv), _ptr(att), _ptr(ds), _ptr(y), _ptr(scale), _ptr(shift), _ptr(co[0]),
                                 _ptr(co[1]), _ptr(co[2]), _ptr(dy), N, HW, F_, _stream()), 'sk_bn_bwd_apply')
+  if ev is not None:
+    ev.record()
   return dy
 
 

@@ -73,6 +73,23 @@ class HParams(object):
       return float(self.loss_scale)
     return 128.0 if self.dtype == 'fp16' else 1.0
 
+  def to_cfg(self):
+    """The flags as the C ABI's struct asm_model_cfg (include/asm_hip.h) -- what asm_model_plan consumes."""
+    from . import lib
+    aa = (lib.ASM_AA_SCONV if 'sconv' in self.anti_alias_type else 0) | (lib.ASM_AA_PROJ if 'proj' in self.anti_alias_type else 0)
+    if self.pool_type not in lib.POOL_TYPES:
+      raise NotImplementedError(self.pool_type)
+    dt = {'bf16': lib.ASM_BF16, 'fp16': lib.ASM_F16, 'fp32': lib.ASM_F32}[self.dtype]
+    return lib.ModelCfg(resnet_size=self.resnet_size, resnet_version=self.resnet_version, num_classes=self.num_classes,
+                        use_se_block=int(self.use_se_block), use_sk_block=int(self.use_sk_block),
+                        use_resnet_d=int(self.use_resnet_d), anti_alias_filter_size=self.anti_alias_filter_size,
+                        anti_alias_type=aa, bl_alpha=self.bl_alpha, bl_beta=self.bl_beta, zero_gamma=int(self.zero_gamma),
+                        no_downsample=int(self.no_downsample), pool_type=lib.POOL_TYPES[self.pool_type],
+                        embedding_size=self.embedding_size, dtype=dt, mixup_type=self.mixup_type,
+                        bn_momentum=self.bn_momentum, bn_eps=1e-5, loss_scale=self.get_loss_scale(),
+                        label_smoothing=self.label_smoothing, kd_temp=self.kd_temp, weight_decay=self.weight_decay,
+                        momentum=self.momentum)
+
   def make_model(self, seed=0, device='cuda') -> Model:
     if self.resnet_size < 50:  # functions/model_fns.py:202-206
       assert not (self.use_dropblock or self.use_se_block or self.use_sk_block or self.use_resnet_d)

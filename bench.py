@@ -14,8 +14,14 @@ Extra objects on the line:
                 launch in a warm-up step), timed with HIP events on the launch stream during the timed
                 region; achieved = algorithmic FLOPs of that launch / its mean duration, against the
                 gfx950 dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  step          the whole step against its per-layer bound sum_l max(flops_l / 2.5 PFLOP/s, bytes_l / 8 TB/s)
+                (every conv as fprop + dgrad + wgrad with un-fused algorithmic bytes, every batch norm
+                as 3 + 5 tensor passes), plus two class figures from HIP events of ONE instrumented step run after
+                the timed region: the 3x3-convolution class against the MFMA peak, the batch-norm family against
+                the HBM peak.
   cpu_baseline  the CPU oracle (a restatement of the reference's TF graph; TF 1.14 itself cannot run
-                here) timed on this host's cores on a bounded sample of the same workload.
+                here) timed on this host's cores, BASELINE.md section 2: value = training step of the same network
+                at batch 32 (median of 3), c1 = config-1 ResNet-50 64-image eval forward (median of 5).
 """
 from __future__ import annotations
 
@@ -30,6 +36,8 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PMC_FILE = 'round1_pmc_traffic.json'
+HBM_PEAK_GBS = 8000.0            # spec; MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -62,6 +70,53 @@ def conv_flops(key):
   return 2.0 * N * Ho * Wo * K * Cn * R * S
 
 
+def step_bound(workload, batch):
+  """Per-layer roofline bound of one training step: each convolution as fprop + dgrad + wgrad (no dgrad
+  for the stem) with flops = 2 N Ho Wo Co Ci k^2 and bytes = 2 (N H W Ci + N Ho Wo Co + k^2 Ci Co) each; each batch
+  norm as 3 (forward) + 5 (backward) bf16 passes over its tensor; pooling / SK / loss / optimiser passes are left out
+  (so the bound is a lower bound of the bound).  Shapes come from the product model's shape-only walk."""
+  from assembled_cnn_amd import nn
+  from assembled_cnn_amd.train import HParams
+  hp = HParams(**dict(dict(resnet_size=50, zero_gamma=True), **WORKLOADS[workload]['hp']))
+  m = hp.make_model(device='cpu')
+  convs, bns = [], []
+  orig_desc, orig_cb = nn.ConvKernel.desc, nn.conv_bn
+
+  def desc(self, N, H, W, stride, out_f32=False, ldy=0):
+    d = orig_desc(self, N, H, W, stride, out_f32, ldy)
+    convs.append((d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.Ho, d.Wo, bool(self.stem)))
+    return d
+
+  def cb(ctx, x, conv, bn, stride, relu, residual=None, res_mode=0, tap_pre=None):
+    out = orig_cb(ctx, x, conv, bn, stride, relu, residual, res_mode, tap_pre)
+    bns.append(out.shape[0] * out.shape[1] * out.shape[2] * out.shape[3])
+    return out
+  import assembled_cnn_amd.model as pmodel
+  nn.ConvKernel.desc, nn.conv_bn, pmodel.conv_bn = desc, cb, cb
+  try:
+    ctx = nn.Ctx(m.arena, True, True, 0.997, 'cpu', False, m._layers)
+    m._walk(ctx, nn.Var(None, (batch, 230, 230, 4), needs_grad=False), hp.use_resnet_d, False)
+  finally:
+    nn.ConvKernel.desc, nn.conv_bn, pmodel.conv_bn = orig_desc, orig_cb, orig_cb
+  peak_f, peak_b = MFMA_BF16_PEAK_TFLOPS * 1e12, HBM_PEAK_GBS * 1e9
+  t = fl = by = fl33 = 0.0
+  for (N, H, W, C, K, R, S, Ho, Wo, stem) in convs:
+    if stem:   # the halo-buffer view: R = k, S = 1, "C" = 4k rounded up; algorithmic C is 3, k x k
+      H, W, C, S = H - 6, W - 6, 3, R
+    f = 2.0 * N * Ho * Wo * K * C * R * S
+    b = 2.0 * (N * H * W * C + N * Ho * Wo * K + R * S * C * K)
+    passes = 2 if stem else 3
+    t += passes * max(f / peak_f, b / peak_b)
+    fl += passes * f
+    by += passes * b
+    if R == 3 and S == 3:
+      fl33 += passes * f
+  bn_bytes = sum(bns) * 2.0 * 8
+  t += bn_bytes / peak_b
+  by += bn_bytes
+  return {'bound_ms': t * 1e3, 'flops': fl, 'bytes': by, 'flops_3x3': fl33, 'bn_bytes': bn_bytes}
+
+
 def _cpu_baseline_worker(workload, budget_s):
   """Oracle train step (fp32) on a bounded sample of the same workload -> images/sec (runs in a child)."""
   import torch
@@ -74,14 +129,32 @@ def _cpu_baseline_worker(workload, budget_s):
     avail = len(os.sched_getaffinity(0))
   except AttributeError:
     avail = os.cpu_count() or 1
-  threads = max(1, min(avail, 32))        # more threads than that only adds OpenMP spin on a shared host
+  threads = avail                          # all usable cores, count stated
   torch.set_num_threads(threads)
-  B = 4
+  import statistics
+  B = 32
   size = hp.pop('resnet_size', 50)
   kd = hp.pop('kd_temp', 0.0)
+  g = torch.Generator().manual_seed(0)
+  # C1: BASELINE config 1 -- ResNet-50 resnet_version=1, 64 seeded 224 x 224 images, eval forward, median of 5
+  t_c1 = time.time()
+  m1 = O.Model(50, num_classes=1001)
+  x1 = O.mean_image_subtraction(torch.randint(0, 256, (64, 224, 224, 3), generator=g).float())
+  with torch.no_grad():
+    m1(x1[:2], False)
+    m1(x1, False)
+    c1 = []
+    for _ in range(5):
+      t0 = time.time()
+      m1(x1, False)
+      c1.append(time.time() - t0)
+      if time.time() - t_c1 > budget_s:
+        break
+  c1_ips = 64.0 / statistics.median(c1)
+  del m1, x1
+  # C2-style: one full training step (fwd + bwd + momentum update) of THIS workload's network at batch 32, fp32
   m = O.Model(size, num_classes=1001, zero_gamma=True, **hp)
   st = O.TrainState(m)
-  g = torch.Generator().manual_seed(0)
   x = torch.randint(0, 256, (B * (2 if mix == 1 else 1), 224, 224, 3), generator=g).float()
   x = O.mean_image_subtraction(x)
   y = torch.randint(1, 1001, (x.shape[0],), generator=g)
@@ -91,19 +164,21 @@ def _cpu_baseline_worker(workload, budget_s):
   kw = dict(lr=0.1, momentum=0.9, weight_decay=1e-4, label_smoothing=ls, mixup_type=mix, lam1=lam, use_resnet_d=d,
             kd_temp=kd)
   O.train_step(st, x, y, **kw)           # warm-up (variable creation, thread pools)
-  n, t0 = 0, time.time()
-  while True:
+  ts, t_all = [], time.time()
+  while len(ts) < 3:
+    t0 = time.time()
     O.train_step(st, x, y, **kw)
-    n += 1
-    el = time.time() - t0
-    if n >= 3 or el > budget_s:
+    ts.append(time.time() - t0)
+    if time.time() - t_all > budget_s:
       break
-  return {'value': round(B * n / el, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-          'sample': '%d training steps of batch %d at 224x224, fp32 PyTorch-CPU restatement of the TF graph '
-                    '(TF 1.14 unavailable); host reports %d cpus, %d usable' % (n, B, os.cpu_count() or 0, avail)}
+  return {'value': round(B / statistics.median(ts), 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+          'c1_eval_images_per_sec': round(c1_ips, 2),
+          'sample': 'median of %d training steps of batch %d at 224x224 of the same network (fp32 PyTorch-CPU restatement '
+                    'of the TF graph; TF 1.14 unavailable) + c1: ResNet-50 v1.5 64-image eval forward, median of %d; '
+                    'host reports %d cpus, %d usable, %d torch threads' % (len(ts), B, len(c1), os.cpu_count() or 0, avail, threads)}
 
 
-def cpu_baseline(workload, budget_s=20.0, hard_timeout_s=150.0):
+def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=200.0):
   """Run the CPU leg in a child process with a hard wall-clock bound so it can never stall the bench."""
   import subprocess
   cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', workload, str(budget_s)]
@@ -214,6 +289,15 @@ def main():
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
+  class_sum = None
+  if not args.no_roofline:   # ONE instrumented step after the timed region: HIP events around every conv and BN-family call
+    step()
+    ct = ops.ConvTimer(classes=True)
+    ops.set_conv_timer(ct)
+    step()
+    torch.cuda.synchronize()
+    ops.set_conv_timer(None)
+    class_sum = (ct.summary(), ct.class_summary())
   loss = float(tr.cross_entropy())
   if not (loss == loss) or loss > 50:
     raise SystemExit('training diverged (loss=%r): the number would be invalid' % loss)
@@ -237,14 +321,41 @@ def main():
       kname = 'conv %s N%d %dx%dx%d -> %d, %dx%d/%d' % dominant
       traffic = None
       try:  # PMC traffic of this kernel class from the committed rocprofv3 --pmc passes (profiles/)
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_FILE)))
         traffic = pmc.get(kname, {}).get('traffic_bytes')
       except (OSError, ValueError):
         pass
       out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_source': 'profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                                           'this command; not measured in this run)' % PMC_FILE,
                          'kernel': kname,
                          'launches_timed': n, 'avg_launch_ms': round(ms / n, 4), 'flops_per_launch': fl}
+    try:
+      sb = step_bound(args.workload, B)
+      ms_step = 1000.0 * el / args.steps
+      st_obj = {'bound_ms': round(sb['bound_ms'], 3), 'frac_of_bound': round(sb['bound_ms'] / ms_step, 4),
+                'algorithmic_tflop': round(sb['flops'] / 1e12, 3), 'algorithmic_gb': round(sb['bytes'] / 1e9, 2),
+                'achieved_tflops': round(sb['flops'] / (ms_step * 1e-3) / 1e12, 1),
+                'peaks': {'mfma_tflops': MFMA_BF16_PEAK_TFLOPS, 'hbm_gbs': HBM_PEAK_GBS}}
+      if class_sum is not None:
+        convs, classes = class_sum
+        f33 = sum(conv_flops(k) * v[0] for k, v in convs.items() if k[6] == 3 and k[7] == 3)
+        t33 = sum(v[1] for k, v in convs.items() if k[6] == 3 and k[7] == 3)
+        tall = sum(v[1] for v in convs.values())
+        st_obj['conv3x3_class'] = {'ms_per_step': round(t33, 3), 'tflops': round(f33 / (t33 * 1e-3) / 1e12, 1),
+                                   'frac_of_mfma_peak': round(f33 / (t33 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                   'launches': sum(v[0] for k, v in convs.items() if k[6] == 3 and k[7] == 3)}
+        st_obj['conv_all_ms_per_step'] = round(tall, 3)
+        if 'bn' in classes:
+          nb, tb, wb = classes['bn']
+          st_obj['bn_class'] = {'ms_per_step': round(tb, 3), 'algorithmic_gb': round(wb / 1e9, 2),
+                                'gbs': round(wb / (tb * 1e-3) / 1e9, 1),
+                                'frac_of_hbm_peak': round(wb / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'calls': nb}
+        st_obj['class_source'] = 'HIP events around every conv / batch-norm-family call of one instrumented step after the timed region'
+      out['step'] = st_obj
+    except Exception as e:   # reporting extras must never lose the measured number
+      out['step'] = {'error': repr(e)}
     if world == 1 and not args.no_cpu_baseline:
       try:
         out['cpu_baseline'] = cpu_baseline(args.workload)

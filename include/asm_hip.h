@@ -335,6 +335,77 @@ typedef struct asm_image_desc {
 int asm_resize_crop_flip(const uint8_t* src, int64_t src_bytes, const asm_image_desc* descs, int N,
                          int out_h, int out_w, int subtract_mean, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Flag surface and topology planner.  asm_model_cfg carries the flags of nets/hparams_config.py:30-292 (+
+ * official/utils/flags/_performance.py:29-42) that reach the hot path, with the reference's names; asm_model_plan walks
+ * functions/model_fns.Model + nets/resnet_model.Model.__call__ (:305-599) for that configuration and an input of
+ * N x H x W x 3 and returns the layers in creation order: every variable-owning layer with its TensorFlow scope name
+ * ("resnet_model/stage1/big1/conv2d_3": + "/kernel", or "/gamma" "/beta" "/moving_mean" "/moving_variance", or
+ * "/kernel" "/bias" for the dense layer), shapes, and its element offset in tf.trainable_variables() order, plus the
+ * parameter-free ops between them.  Host code only -- usable (and tested) without a GPU.
+ * Errors mirror the reference: bad resnet_version / unknown resnet_size -> ASM_EINVAL (ValueError), resnet_size < 50,
+ * unknown pool_type, dtype other than bf16 -> ASM_ENOTSUP (NotImplementedError; the reference's fp16 / fp32 graph
+ * dtypes are not computed by this library).
+ * ---------------------------------------------------------------------------------------------- */
+#define ASM_F32 0
+#define ASM_BF16 1
+#define ASM_F16 2
+#define ASM_AA_SCONV 1          /* 'sconv' in anti_alias_type */
+#define ASM_AA_PROJ 2           /* 'proj' in anti_alias_type  */
+#define ASM_POOL_GAP 0
+#define ASM_POOL_GEM 1
+#define ASM_POOL_FLATTEN 2
+typedef struct asm_model_cfg {
+  int32_t resnet_size, resnet_version, num_classes;
+  int32_t use_se_block, use_sk_block, use_resnet_d;
+  int32_t anti_alias_filter_size, anti_alias_type;   /* bitmask ASM_AA_* */
+  int32_t bl_alpha, bl_beta;
+  int32_t zero_gamma, no_downsample, pool_type, embedding_size;
+  int32_t dtype;                                     /* ASM_BF16 */
+  int32_t mixup_type;
+  float bn_momentum, bn_eps, loss_scale, label_smoothing, kd_temp, weight_decay, momentum;
+} asm_model_cfg;
+
+#define ASM_PLAN_CONV 0        /* conv2d_fixed_padding: 1 trainable tensor [R,S,C,K] (stored [K][R][S][C])   */
+#define ASM_PLAN_BN 1          /* batch_norm: gamma, beta (+ moving_mean, moving_variance), C channels        */
+#define ASM_PLAN_DENSE 2       /* tf.layers.dense: kernel [C,K] + bias [K]                                    */
+#define ASM_PLAN_MAXPOOL 3
+#define ASM_PLAN_AVGPOOL 4
+#define ASM_PLAN_BLURPOOL 5
+#define ASM_PLAN_GAP 6
+#define ASM_PLAN_GEM 7
+#define ASM_PLAN_FLATTEN 8
+#define ASM_PLAN_SK_GAP 9
+#define ASM_PLAN_SK_SELECT 10
+#define ASM_PLAN_SE_SCALE 11
+#define ASM_PLAN_ADD 12
+#define ASM_PLAN_RELU 1                  /* flags */
+#define ASM_PLAN_RESIDUAL 2              /* + shortcut / other branch before the ReLU                          */
+#define ASM_PLAN_UPSAMPLED_RESIDUAL 4    /* that operand is UpSampling2D((2,2)) of a half-resolution tensor    */
+#define ASM_PLAN_ZERO_GAMMA 8            /* gamma initialised to 0 (zero_gamma, nets/resnet_model.py:84)       */
+#define ASM_PLAN_COUNT_VALID 16          /* average pool divides by the in-range taps (stride-1 SAME)          */
+typedef struct asm_plan_entry {
+  int32_t kind;
+  int32_t N, H, W, C;          /* input activation                                                            */
+  int32_t K, R, S, stride;     /* output channels, window, stride                                             */
+  int32_t Ho, Wo;
+  int32_t flags;
+  int32_t trainable;           /* trainable tensors owned (conv 1, bn 2, dense 2, ops 0)                      */
+  int32_t reserved;
+  int64_t param_offset;        /* first element in tf.trainable_variables() order (-1 for parameter-free ops) */
+  int64_t param_elems;
+  char name[112];              /* variable scope of the layer; enclosing scope for parameter-free ops         */
+} asm_plan_entry;
+typedef struct asm_plan_summary {
+  int32_t n_entries, trainable_tensors;
+  int64_t trainable_elems;            /* e.g. 25 559 081 for ResNet-50, 1001 classes                          */
+  int64_t forward_macs_per_image;
+  int64_t wgrad_workspace_bytes;      /* largest asm_conv2d_wgrad_workspace_bytes over the layers at this N   */
+} asm_plan_summary;
+/* entries may be NULL to query summary->n_entries first. */
+int asm_model_plan(const asm_model_cfg* cfg, int N, int H, int W, asm_plan_entry* entries, int capacity,
+                   asm_plan_summary* summary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,32 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/profile_round.sh TAG [stats|traffic|sq ...]
+#   stats    rocprofv3 --kernel-trace --stats of bench.py (3 warm-up + 5 timed steps) -> gpurun_out/TAG_kernel_stats.md
+#   traffic  two --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain) -> gpurun_out/TAG_step_hbm_traffic.md
+#   sq       one --pmc pass of SQ occupancy / MFMA-busy counters -> gpurun_out/TAG_sq_counters.txt
+TAG=$1; shift
+WHAT="${*:-stats}"
+REPO=$(pwd)
+mkdir -p $REPO/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-roofline"
+for w in $WHAT; do
+  case $w in
+    stats)
+      rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_$TAG -o r -- $BENCH --steps 5 --warmup 3 > $REPO/gpurun_out/prof_$TAG.log 2>&1
+      DB=$(find $REPO/gpurun_out/prof_$TAG -name '*results.db' | head -1)
+      python $REPO/tools/rocpd_summary.py $DB $REPO/gpurun_out/${TAG}_kernel_stats.md "$TAG: bench.py --steps 5 --warmup 3 (8 steps profiled)"
+      ;;
+    traffic)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rocprofv3 --pmc $c -d $REPO/gpurun_out/pmc_${TAG}_$c -o p --output-format csv -- $BENCH --steps 2 --warmup 1 > $REPO/gpurun_out/pmc_${TAG}_$c.log 2>&1
+      done
+      python $REPO/tools/pmc_traffic_step.py $REPO/gpurun_out/pmc_${TAG}_FETCH_SIZE $REPO/gpurun_out/pmc_${TAG}_WRITE_SIZE 3 > $REPO/gpurun_out/${TAG}_step_hbm_traffic.md
+      ;;
+    sq)
+      rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
+        -d $REPO/gpurun_out/pmc_${TAG}_sq -o p --output-format csv -- $BENCH --steps 2 --warmup 1 > $REPO/gpurun_out/pmc_${TAG}_sq.log 2>&1
+      python $REPO/tools/pmc_summary.py $REPO/gpurun_out/pmc_${TAG}_sq > $REPO/gpurun_out/${TAG}_sq_counters.txt
+      ;;
+  esac
+done
+cd $REPO
