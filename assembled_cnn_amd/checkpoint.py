@@ -20,10 +20,20 @@ import torch
 from .model import Model
 
 
+def _is_dense_kernel(name: str) -> bool:
+  """tf.layers.dense kernels ([in, units]) are the ones whose LAYER is named dense / dense_N; 'embedding_dense' is a
+  tf.layers.conv2d (nets/resnet_model.py:576-580) and keeps the 4-D HWIO layout [1, 1, in, emb]."""
+  parts = name.split('/')
+  if len(parts) < 2 or parts[-1] not in ('kernel', 'kernel/Momentum') and parts[-2:] != ['kernel', 'Momentum']:
+    return False
+  layer = parts[-3] if parts[-1] == 'Momentum' else parts[-2]
+  return layer == 'dense' or (layer.startswith('dense_') and layer[6:].isdigit())
+
+
 def _to_tf_layout(name: str, t: torch.Tensor) -> np.ndarray:
   a = t.detach().float().cpu()
   if a.dim() == 4:
-    if name.endswith('dense/kernel'):
+    if _is_dense_kernel(name):
       return a.view(a.shape[0], a.shape[3]).t().contiguous().numpy()      # [units,1,1,in] -> [in, units]
     return a.permute(1, 2, 3, 0).contiguous().numpy()                       # KRSC -> HWIO
   return a.numpy().copy()
@@ -33,6 +43,8 @@ def _from_tf_layout(name: str, a: np.ndarray, like: torch.Tensor) -> torch.Tenso
   t = torch.as_tensor(np.asarray(a), dtype=torch.float32)
   if like.dim() == 4:
     if t.dim() == 2:                                                         # dense [in, units]
+      if not _is_dense_kernel(name):
+        raise ValueError('variable %s is a convolution kernel ([k, k, in, out] in the checkpoint), got a 2-D array' % name)
       t = t.t().contiguous().view(like.shape)
     else:
       t = t.permute(3, 0, 1, 2).contiguous()                                # HWIO -> KRSC
@@ -42,8 +54,13 @@ def _from_tf_layout(name: str, a: np.ndarray, like: torch.Tensor) -> torch.Tenso
   return t
 
 
-def export_variables(model: Model, global_step: Optional[int] = None) -> "OrderedDict[str, np.ndarray]":
-  """All trainable variables and BN moving statistics under their TF names, in TF layouts."""
+MOMENTUM_SLOT = '/Momentum'   # tf.train.MomentumOptimizer's slot variable name (nets/optimizer_setting.py:29)
+
+
+def export_variables(model: Model, global_step: Optional[int] = None, include_slots: bool = True
+                     ) -> "OrderedDict[str, np.ndarray]":
+  """All trainable variables, BN moving statistics and (``include_slots``) the momentum accumulators
+  ``<variable>/Momentum`` an Estimator checkpoint of the reference holds, under their TF names, in TF layouts."""
   a = model.arena
   if not a.finalized:
     raise RuntimeError('build the model first')
@@ -52,6 +69,9 @@ def export_variables(model: Model, global_step: Optional[int] = None) -> "Ordere
     out[name] = _to_tf_layout(name, a.w(name))
   for name in a.state_specs:
     out[name] = a.st(name).detach().cpu().numpy().copy()
+  if include_slots:
+    for name in a.specs:
+      out[name + MOMENTUM_SLOT] = _to_tf_layout(name, a.m(name))
   if global_step is not None:
     out['global_step'] = np.asarray(global_step, dtype=np.int64)
   return out
@@ -87,6 +107,10 @@ def import_variables(model: Model, variables: Dict[str, np.ndarray], warm_start:
         continue
       a.w(name).copy_(_from_tf_layout(name, variables[name], a.w(name)).to(a.w32.device))
       report['loaded'].append(name)
+      slot = name + MOMENTUM_SLOT      # optional: inference / warm-start checkpoints carry no optimiser slots
+      if not warm_start and slot in variables:
+        a.m(name).copy_(_from_tf_layout(name, variables[slot], a.m(name)).to(a.w32.device))
+        report['loaded'].append(slot)
     if not warm_start:   # a tf.train.Saver over trainables does not restore the moving statistics
       for name in a.state_specs:
         if name in variables:

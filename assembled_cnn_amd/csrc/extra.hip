@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(const float* __restrict_
   const int b = blockIdx.x;
   const float* z = logits + (size_t)b * ld;
   const int lab = labels[b];
-  const float zl = z[lab];
+  // a label outside [0, C) can never be hit (tf.nn.in_top_k yields False for an out-of-range target): no stray read
+  const bool lab_ok = (unsigned)lab < (unsigned)C;
+  const float zl = lab_ok ? z[lab] : INFINITY;
   float mx = -INFINITY;
   int arg = 0x7fffffff;
   float higher = 0.f;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(const float* __restrict_
     pred[b] = arg;
     conf[b] = 1.0f / se;                      // max of softmax
     top1[b] = arg == lab ? 1.f : 0.f;
-    top5[b] = higher < 5.f ? 1.f : 0.f;
+    top5[b] = (lab_ok && higher < 5.f) ? 1.f : 0.f;
   }
 }
 // state[0..2] = sum top1, sum top5, count ; state[3..12] correct per bin, [13..22] conf per bin, [23..32] count per bin

@@ -179,10 +179,11 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, like: torch.Tensor) -> Optional[torch.Tensor]:
-  """One grow-only scratch buffer per device (kernels on one stream run in order)."""
+  """One grow-only scratch buffer per (device, stream): launches on one stream run in order, launches on two
+  streams (the opt-in weight-gradient side stream) must not share the split-K slab."""
   if nbytes == 0:
     return None
-  key = str(like.device)
+  key = (str(like.device), _stream())
   buf = _ws_cache.get(key)
   if buf is None or buf.numel() < nbytes:
     buf = torch.empty((nbytes,), dtype=torch.uint8, device=like.device)

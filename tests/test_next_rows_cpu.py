@@ -144,10 +144,19 @@ def test_checkpoint_roundtrip_tf_layouts(cpu_double, tmp_path):
   variables.update({n: t.detach().numpy() for n, t in om.vars.state.items()})
   rep = ck.import_variables(a, variables)
   assert not rep['missing'] and len(rep['loaded']) == len(variables)
+  a.arena.m32.copy_(torch.arange(a.arena.m32.numel(), dtype=torch.float32) % 97 - 48)     # non-trivial momentum slots
   exp = ck.export_variables(a, global_step=7)
   for n, v in variables.items():
     assert exp[n].shape == v.shape and np.allclose(exp[n], v), n
+    if n in om.vars.trainable:      # '<var>/Momentum' slots of the Estimator checkpoint, same TF layout as the variable
+      assert exp[n + '/Momentum'].shape == v.shape
   assert int(exp['global_step']) == 7
+  c = Model(50, num_classes=1001, device='cpu', seed=4, **kw)
+  c.build((64, 64))
+  ck.import_variables(c, exp)
+  for n in a.arena.specs:      # (the arenas pad every variable to 8 elements; compare the variables, not the padding)
+    assert torch.equal(c.arena.m(n), a.arena.m(n)) and torch.equal(c.arena.w(n), a.arena.w(n)), 'resume restores ' + n
+  ck.import_variables(c, {k: v for k, v in exp.items() if not k.endswith('/Momentum')})     # slots are optional on import
   # npz round trip + warm start: everything but the classifier ('dense' outside se_block) is restored
   ck.save_npz(str(tmp_path / 'm.npz'), a)
   b = Model(50, num_classes=1001, device='cpu', seed=9, **kw)
@@ -160,6 +169,21 @@ def test_checkpoint_roundtrip_tf_layouts(cpu_double, tmp_path):
   assert torch.equal(b.arena.w(some_se), a.arena.w(some_se))
   first = list(a.arena.specs)[0]
   assert torch.equal(b.arena.w(first), a.arena.w(first)) and torch.equal(b.arena.wb(first), a.arena.wb(first))
+  # embedding head: 'embedding_dense/kernel' is a tf.layers.conv2d kernel -> [1, 1, in, emb], not a 2-D dense matrix
+  oe = O.Model(50, num_classes=1001, embedding_size=64)
+  oe(torch.zeros(1, 64, 64, 3), False)
+  e = Model(50, num_classes=1001, device='cpu', embedding_size=64)
+  e.build((64, 64))
+  ve = {n: t.detach().numpy() for n, t in oe.vars.trainable.items()}
+  ve.update({n: t.detach().numpy() for n, t in oe.vars.state.items()})
+  ck.import_variables(e, ve)
+  xe = ck.export_variables(e, include_slots=False)
+  assert xe['resnet_model/embedding_dense/kernel'].shape == (1, 1, 2048, 64) == ve['resnet_model/embedding_dense/kernel'].shape
+  assert xe['resnet_model/dense/kernel'].shape == (64, 1001)
+  for n, v in ve.items():
+    assert xe[n].shape == v.shape and np.allclose(xe[n], v), n
+  with pytest.raises(ValueError):
+    ck.import_variables(e, dict(ve, **{'resnet_model/embedding_dense/kernel': np.zeros((2048, 64), np.float32)}))
   # not at step 0 -> the hook does nothing
   assert ck.import_variables(b, {}, warm_start=True, global_step=5)['loaded'] == []
   with pytest.raises(KeyError):
