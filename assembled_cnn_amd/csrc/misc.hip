@@ -67,6 +67,9 @@ __global__ void bias_grad_kernel(const bf16_t* dz, int M, int C, int ld, float* 
 __global__ void cast_kernel(const float* x, bf16_t* y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = f2bf(x[i]);
 }
+__global__ void widen_kernel(const bf16_t* x, float* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = bf2f(x[i]);
+}
 
 // ---- softmax cross-entropy (+label smoothing, +KD), one block per row --------------------------------
 __device__ float block_reduce(float v, bool is_max, float* sh) {
@@ -554,6 +557,14 @@ extern "C" int asm_cast_f32_to_bf16(const float* x, void* y, size_t n, void* str
   if (n == 0) return ASM_OK;
   hipLaunchKernelGGL(cast_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
   ASM_CHECK_LAUNCH("cast");
+  return ASM_OK;
+}
+
+extern "C" int asm_cast_bf16_to_f32(const void* x, float* y, size_t n, void* stream) {
+  ASM_REQUIRE(x && y, "cast: null pointer");
+  if (n == 0) return ASM_OK;
+  hipLaunchKernelGGL(widen_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
+  ASM_CHECK_LAUNCH("cast_bf16_to_f32");
   return ASM_OK;
 }
 

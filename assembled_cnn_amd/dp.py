@@ -39,7 +39,7 @@ def per_device_batch_size(batch_size: int, num_gpus: int) -> int:
 class GradSync(object):
   """Bucketed, backward-overlapped all-reduce of a ParamArena's flat gradient buffer."""
 
-  def __init__(self, arena, bucket_bytes: int = 32 << 20, group=None, overlap: bool = True):
+  def __init__(self, arena, bucket_bytes: int = 32 << 20, group=None, overlap: bool = True, comm_dtype: str = 'fp32'):
     if not dist.is_initialized():
       raise RuntimeError('GradSync needs an initialised torch.distributed process group')
     if not arena.finalized or arena.total_elems <= 0:
@@ -49,11 +49,18 @@ class GradSync(object):
     if overlap and getattr(arena, 'side_stream', None) is not None:
       raise RuntimeError('GradSync(overlap=True) cannot be combined with the weight-gradient side stream '
                          '(ASM_WGRAD_STREAM=1): bucket launches are ordered against the compute stream only')
+    if comm_dtype not in ('fp32', 'bf16'):
+      raise ValueError("comm_dtype must be 'fp32' (the reference's all-reduce precision) or 'bf16'")
     self.arena = arena
     self.group = group
     self.world_size = dist.get_world_size(group)
     self.overlap = overlap
-    elems = max(1024, bucket_bytes // 4)
+    # 'bf16': each bucket is narrowed to bf16 just before it is handed to RCCL and widened back into the fp32 arena
+    # when the optimiser waits for it -- half the bytes on the xGMI ring (83.7 instead of 167.4 MB per step for
+    # Assemble-ResNet-50) at 8 significant bits per exchanged gradient; the fp32 default is what MirroredStrategy did.
+    self.comm_dtype = comm_dtype
+    self._stage = torch.empty_like(arena.g32, dtype=torch.bfloat16) if comm_dtype == 'bf16' else None
+    elems = max(1024, bucket_bytes // (2 if comm_dtype == 'bf16' else 4))
     # buckets inside each segment ([0, decay_elems) and [decay_elems, total)), highest offsets first
     self.segments: List[List[Tuple[int, int]]] = []
     for lo, hi in ((0, arena.decay_elems), (arena.decay_elems, arena.total_elems)):
@@ -95,7 +102,13 @@ class GradSync(object):
   def _launch(self, s: int, i: int):
     lo, hi = self.segments[s][i]
     self._reduced += hi - lo
-    self._work.append(dist.all_reduce(self.arena.g32[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+    if self._stage is not None:
+      from . import ops
+      ops.cast_f32_to_bf16(self.arena.g32[lo:hi], self._stage[lo:hi])
+      buf = self._stage[lo:hi]
+    else:
+      buf = self.arena.g32[lo:hi]
+    self._work.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi))
 
   def finish(self):
     """Launch whatever is left and make the compute stream wait for every bucket."""
@@ -103,8 +116,11 @@ class GradSync(object):
       while self._next[s] < len(buckets):
         self._launch(s, self._next[s])
         self._next[s] += 1
-    for w in self._work:
+    for w, lo, hi in self._work:
       w.wait()
+      if self._stage is not None:
+        from . import ops
+        ops.cast_bf16_to_f32(self._stage[lo:hi], self.arena.g32[lo:hi])
     if self._reduced != self.arena.total_elems:
       raise RuntimeError('gradient exchange covered %d of %d elements' % (self._reduced, self.arena.total_elems))
     self._reset()

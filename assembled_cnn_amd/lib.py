@@ -119,6 +119,7 @@ SIGNATURES = {
     'asm_bias_add_f32': (_I, [_P, _P, _I, _I, _I, _P]),
     'asm_bias_grad_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'asm_cast_f32_to_bf16': (_I, [_P, _P, _Z, _P]),
+    'asm_cast_bf16_to_f32': (_I, [_P, _P, _Z, _P]),
     'asm_softmax_ce': (_I, [_P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _P]),
     'asm_onehot': (_I, [_P, _P, _I, _I, _P]),
     'asm_softmax_rows': (_I, [_P, _P, _I, _I, _F, _P]),

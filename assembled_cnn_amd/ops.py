@@ -550,6 +550,10 @@ def cast_f32_to_bf16(x, y):
   check(L().asm_cast_f32_to_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), 'cast')
 
 
+def cast_bf16_to_f32(x, y):
+  check(L().asm_cast_bf16_to_f32(_ptr(x), _ptr(y), x.numel(), _stream()), 'cast_bf16_to_f32')
+
+
 def softmax_ce(logits, ld, targets, teacher, B, Cn, label_smoothing, kd_temp, loss_scale, ld_out, want_grad=True):
   loss_rows = empty((B,), F32, logits)
   dlogits = empty((B, 1, 1, ld_out), BF16, logits) if want_grad else None

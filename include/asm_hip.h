@@ -242,6 +242,7 @@ int asm_add_bf16(const void* a, const void* b, void* out, size_t n, void* stream
 int asm_bias_add_f32(float* y, const float* bias, int M, int C, int ldy, void* stream);
 int asm_bias_grad_bf16(const void* dz, int M, int C, int ld, float* dbias, void* stream);
 int asm_cast_f32_to_bf16(const float* x, void* y, size_t n, void* stream);
+int asm_cast_bf16_to_f32(const void* x, float* y, size_t n, void* stream);   /* bf16 gradient buckets back into the fp32 arena */
 
 /* ------------------------------------------------------------------------------------------------
  * Loss -- tf.losses.softmax_cross_entropy(label_smoothing) (losses/cls_losses.py:31-33) + the KD term

@@ -612,6 +612,11 @@ class CpuDouble(object):
       T(y, (n,), 'bf16').copy_(T(x, (n,), 'f32'))
     return 0
 
+  def asm_cast_bf16_to_f32(self, x, y, n, stream):
+    if n:
+      T(y, (n,), 'f32').copy_(T(x, (n,), 'bf16'))
+    return 0
+
   # ---- loss ----------------------------------------------------------------------------------------
   def asm_softmax_ce(self, logits, ld, targets, teacher, B, Cn, eps, T_, loss_scale, loss_rows, dlogits, ld_out,
                      stream):

@@ -118,3 +118,61 @@ def test_per_device_batch_size():
   assert per_device_batch_size(32, 1) == 32 and per_device_batch_size(32, 0) == 32
   with pytest.raises(ValueError):
     per_device_batch_size(147, 5)
+
+
+def _worker_mixup(rank, world, port, out_dir, comm_dtype):
+  """SURVEY 8e invariant at world size 4 with mixup type 1: every rank receives its own 2B-image slice, forms the
+  mixup pairs INSIDE that slice (functions/input_fns.py:98-104), normalises with its own batch statistics, and the
+  exchanged gradient is the sum of the four per-shard gradients."""
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  torch.set_num_threads(2)
+  import numpy as np
+  from assembled_cnn_amd import dp, ops
+  from assembled_cnn_amd.train import HParams, Trainer
+  from tests.cpu_double import CpuDouble
+  from tests import model_parity as mpar
+  ops.set_library(CpuDouble(), is_double=True)
+  dp.init_process_group_from_env('gloo')
+  B, S = 2, 32
+  hp = HParams(resnet_version=1, zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01,
+               weight_decay=1e-4, label_smoothing=0.1, mixup_type=1, batch_size=B * world)
+  img, _, labels = mpar.inputs(2 * B * world, S)            # type 1 feeds 2x the batch
+  lams = torch.from_numpy(np.random.default_rng(4).beta(0.2, 0.2, size=B * world).astype(np.float32))
+  ref = Trainer(hp, seed=0, device='cpu')
+  ref.model.build((S, S))
+  shard_grads = []
+  for r in range(world):
+    sl = slice(r * 2 * B, (r + 1) * 2 * B)
+    x, onehot, _ = ref.prepare_inputs(img[sl], labels[sl], lams[r * B:(r + 1) * B])
+    assert x.shape[0] == B
+    ref.model(x, True, prepadded=True)
+    rows, dz = ops.softmax_ce(ref.model.logits_padded, ref.model.ldc, onehot, None, B, 1001, 0.1, 0.0, 1.0, ref.model.ldc)
+    ref.model.backward(dz)
+    shard_grads.append(ref.model.arena.g32.clone())
+  w0 = ref.model.arena.w32.clone()
+  tr = Trainer(hp, seed=0, device='cpu', world_size=world)
+  tr.model.build((S, S))
+  tr.grad_sync = dp.GradSync(tr.model.arena, bucket_bytes=16 << 20, comm_dtype=comm_dtype)
+  sl = slice(rank * 2 * B, (rank + 1) * 2 * B)
+  tr.train_step(img[sl], labels[sl], lams[rank * B:(rank + 1) * B])
+  g_sum = sum(shard_grads)
+  if comm_dtype == 'fp32':    # four addends: the ring's summation order is not Python's, so equal up to fp32 rounding
+    assert float((tr.model.arena.g32 - g_sum).norm() / g_sum.norm()) <= 1e-6
+  else:   # every rank's contribution was rounded to bf16 once, the ring sums in bf16
+    err = (tr.model.arena.g32 - g_sum).norm() / g_sum.norm()
+    assert 0 < float(err) <= 2e-2, float(err)
+  gathered = [torch.empty_like(tr.model.arena.w32) for _ in range(world)]
+  dist.all_gather(gathered, tr.model.arena.w32)
+  assert all(torch.equal(gathered[0], g) for g in gathered[1:]), 'replicas diverged'
+  assert not torch.equal(gathered[0], w0)
+  if rank == 0:
+    open(os.path.join(out_dir, 'ok_' + comm_dtype), 'w').write('ok')
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('comm_dtype', ['fp32', 'bf16'])
+def test_dp_world4_mixup_slices_gloo(tmp_path, comm_dtype):
+  port = _free_port()
+  mp.spawn(_worker_mixup, args=(4, port, str(tmp_path), comm_dtype), nprocs=4, join=True)
+  assert (tmp_path / ('ok_' + comm_dtype)).exists()
