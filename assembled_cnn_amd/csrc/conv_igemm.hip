@@ -25,6 +25,7 @@ struct IGemmArgs {
   const void* w;
   void* y;
   const void* addend;  // optional bf16 [M][ldy] added to the result (gradient accumulation, dgrad)
+  const uint8_t* addend_mask;  // optional packed ReLU mask of the addend ([M][ldy/8] bytes): addend lanes with a 0 bit count as 0
   float* stats;
   unsigned x_bytes, w_bytes;
   int M;           // number of output rows
@@ -179,6 +180,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
             const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) + yoff);
             float fa[8];
             unpack8(av, fa);
+            if (p.addend_mask) {          // workgroup-uniform: the addend is a not-yet-masked gradient (dz = dy * [y > 0])
+              const unsigned mk = p.addend_mask[yoff >> 3];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) fa[e] = ((mk >> e) & 1u) ? fa[e] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) fv[e] += fa[e];
           }
@@ -832,7 +838,7 @@ static int fprop_impl(const asm_conv_desc* d, const void* x, const void* w, void
   ASM_REQUIRE(ldy % (d->out_f32 ? 4 : 8) == 0 && ldy >= d->K, "conv fprop: bad ldy %d", ldy);
   ASM_REQUIRE(!(stats_partial && d->out_f32), "conv fprop: fused statistics need bf16 output");
   IGemmArgs a;
-  a.x = x; a.w = w; a.y = y; a.addend = residual; a.stats = stats_partial;
+  a.x = x; a.w = w; a.y = y; a.addend = residual; a.addend_mask = nullptr; a.stats = stats_partial;
   a.x_bytes = (unsigned)(xelems * 2);
   a.w_bytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
   a.M = d->N * d->Ho * d->Wo;
@@ -862,8 +868,23 @@ extern "C" int asm_conv2d_fprop_bn(const asm_conv_desc* d, const void* x, const 
   return fprop_impl(d, x, w, y, nullptr, scale, shift, residual, relu ? 1 : 0, stream);
 }
 
+static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                      const uint8_t* addend_mask, void* dx, void* stream);
+
 extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
                                 void* dx, void* stream) {
+  return dgrad_impl(d, dy, wt, addend, nullptr, dx, stream);
+}
+
+extern "C" int asm_conv2d_dgrad_masked(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                                       const uint8_t* addend_mask, void* dx, void* stream) {
+  ASM_REQUIRE(addend && addend_mask, "conv dgrad_masked: needs the addend and its mask");
+  ASM_REQUIRE(d && d->C % 8 == 0, "conv dgrad_masked: C must be a multiple of 8");
+  return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream);
+}
+
+static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                      const uint8_t* addend_mask, void* dx, void* stream) {
   if (int e = check_desc(d)) return e;
   ASM_REQUIRE(dy && wt && dx, "conv dgrad: null pointer");
   ASM_REQUIRE(d->K % 8 == 0, "conv dgrad: K=%d must be a multiple of 8 (pad dy)", d->K);
@@ -872,7 +893,7 @@ extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const vo
   const int64_t dyelems = (int64_t)d->N * d->Ho * d->Wo * d->K;
   ASM_REQUIRE(dyelems * 2 < (int64_t)ASM_OOB, "conv dgrad: dy larger than 2 GiB");
   IGemmArgs a;
-  a.x = dy; a.w = wt; a.y = dx; a.addend = addend; a.stats = nullptr;
+  a.x = dy; a.w = wt; a.y = dx; a.addend = addend; a.addend_mask = addend_mask; a.stats = nullptr;
   a.x_bytes = (unsigned)(dyelems * 2);
   a.w_bytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
   a.M = d->N * d->H * d->W;
@@ -912,6 +933,8 @@ extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const vo
       c.y_strided = 1;
       c.y_base = (ph * d->W + pw) * d->C;
       c.y_img_pitch = d->H * d->W * d->C; c.y_row_pitch = 2 * d->W * d->C; c.y_pix_pitch = 2 * d->C;
+      if (!launched && k1 && addend_mask)
+        ASM_FAIL(ASM_ENOTSUP, "conv dgrad_masked: a masked addend is not supported for the 1x1 stride-2 input gradient");
       if (!launched && k1) {   // fill the untouched classes before the one launch that overwrites its own pixels
         const size_t bytes = (size_t)a.M * d->C * 2;
         hipError_t e = (addend && addend != dx) ? hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream)

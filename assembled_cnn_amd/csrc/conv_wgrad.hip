@@ -56,7 +56,10 @@ __device__ __forceinline__ int tr_swz(int row) {
 // where the pixel count is largest) neither waste MFMAs on zero rows nor LDS on empty tiles.  BCW = (tap, channel)
 // column tile: 128, or 256 together with BNW = 256 and 8 waves (each 64 x 128): half the staging loads, index
 // decodes and 3/4 of the LDS fragment reads per MFMA, for the layers whose dW is at least 256 x 256.
-template <int BNW, int BCW>
+// LIN: 1x1, stride 1, no padding over a densely packed x: output pixel m IS input pixel m and column j IS channel j, so
+// the staging loads need no (image, row, column) decode at all (two multiply-shift divisions, ~25 VALU per row and step in
+// the general form; most weight-gradient launches of a bottleneck network are such 1x1 layers).
+template <int BNW, int BCW, bool LIN = false>
 __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs p) {
   constexpr int NTHR = BCW == 256 ? 512 : 256;
   constexpr int WROWB = BCW * 2;            // x tile row bytes
@@ -138,6 +141,11 @@ __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs
     for (int j = 0; j < XP; ++j) {
       const int m = m_begin + step * WPX + prow + XRP * j;
       const bool mok = m < m_end;
+      if constexpr (LIN) {
+        const unsigned offl = ((unsigned)m * (unsigned)p.Ci + (unsigned)j0) * 2u;
+        rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (mok && col_ok) ? offl : ASM_OOB, 0, 0);
+        continue;
+      }
       const unsigned um = mok ? (unsigned)m : 0u;
       const unsigned img = fd_div(um, p.fd_howo);
       const unsigned rem = um - img * (unsigned)p.HoWo;
@@ -401,12 +409,26 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   a.fd_wo = make_fastdiv((unsigned)a.Wo);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(pl.tiles_n * pl.tiles_c * pl.splits);
-  if (pl.bcw == 256) {
+  const bool lin = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->Ho == d->H && d->Wo == d->W &&
+                   a.x_pix_pitch == d->C && a.x_row_pitch == d->W * d->C && a.x_img_pitch == d->H * d->W * d->C &&
+                   asm_env_int("ASM_WGRAD_LINEAR", 1) != 0;
+  if (lin && pl.bcw != 256) {
+    if (pl.bnw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128, true>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);
+    else if (pl.bnw == 64) hipLaunchKernelGGL((wgrad_kernel<64, 128, true>), grid, dim3(256), 2 * (WPX * 128 + WPX * 256), st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<32, 128, true>), grid, dim3(256), 2 * (WPX * 64 + WPX * 256), st, a);
+  } else if (pl.bcw == 256) {
     constexpr int LDS = 2 * (WPX * 512 + WPX * 512);   // 128 KiB
     static bool attr_done[ASM_MAX_DEVICES] = {};
     if (hipError_t e = asm_ensure_dyn_lds(wgrad_kernel<256, 256>, LDS, attr_done); e != hipSuccess)
       ASM_FAIL(ASM_EHIP, "wgrad_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((wgrad_kernel<256, 256>), grid, dim3(512), LDS, st, a);
+    if (lin) {
+      static bool attr_done_l[ASM_MAX_DEVICES] = {};
+      if (hipError_t e = asm_ensure_dyn_lds(wgrad_kernel<256, 256, true>, LDS, attr_done_l); e != hipSuccess)
+        ASM_FAIL(ASM_EHIP, "wgrad_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
+      hipLaunchKernelGGL((wgrad_kernel<256, 256, true>), grid, dim3(512), LDS, st, a);
+    } else {
+      hipLaunchKernelGGL((wgrad_kernel<256, 256>), grid, dim3(512), LDS, st, a);
+    }
   } else if (pl.bnw == 128) {
     hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);
   } else if (pl.bnw == 64) {

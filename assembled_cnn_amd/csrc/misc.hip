@@ -40,6 +40,16 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* dy, const b
     *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(g);
   }
 }
+__global__ __launch_bounds__(256) void mask_apply_kernel(const bf16_t* dy, const uint8_t* mask, bf16_t* dx, size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    float g[8];
+    unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
+    const unsigned mk = mask[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
+    *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(g);
+  }
+}
 __global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, const bf16_t* b, bf16_t* o, size_t nvec) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     float f[8], g[8];
@@ -528,6 +538,14 @@ extern "C" int asm_relu_bwd(const void* dy, const void* y, void* dx, size_t n, v
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (const bf16_t*)y, (bf16_t*)dx, n / 8);
   ASM_CHECK_LAUNCH("relu_bwd");
+  return ASM_OK;
+}
+extern "C" int asm_mask_apply(const void* dy, const uint8_t* mask, void* dx, size_t n, void* stream) {
+  ASM_REQUIRE(dy && mask && dx, "mask_apply: null pointer");
+  VEC8_OK("mask_apply");
+  hipLaunchKernelGGL(mask_apply_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, mask,
+                     (bf16_t*)dx, n / 8);
+  ASM_CHECK_LAUNCH("mask_apply");
   return ASM_OK;
 }
 extern "C" int asm_add_bf16(const void* a, const void* b, void* out, size_t n, void* stream) {

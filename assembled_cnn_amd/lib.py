@@ -74,6 +74,7 @@ SIGNATURES = {
     'asm_conv2d_fprop': (_I, [_D, _P, _P, _P, _P, _P]),
     'asm_conv2d_stats_blocks': (_I, [_D]),
     'asm_conv2d_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
+    'asm_conv2d_dgrad_masked': (_I, [_D, _P, _P, _P, _P, _P, _P]),
     'asm_conv2d_wgrad_workspace_bytes': (_Z, [_D]),
     'asm_conv2d_wgrad': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
     'asm_filter_transpose': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     'asm_relu_fwd': (_I, [_P, _P, _Z, _P]),
     'asm_relu_bwd': (_I, [_P, _P, _P, _Z, _P]),
     'asm_add_bf16': (_I, [_P, _P, _P, _Z, _P]),
+    'asm_mask_apply': (_I, [_P, _P, _P, _Z, _P]),
     'asm_bias_add_f32': (_I, [_P, _P, _I, _I, _I, _P]),
     'asm_bias_grad_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'asm_cast_f32_to_bf16': (_I, [_P, _P, _Z, _P]),

@@ -23,6 +23,8 @@ import torch
 from . import ops
 
 BN_EPS = 1e-5  # nets/model_helper.py:26
+# ASM_LAZY_DZ=0: materialise the masked shortcut gradient dz in the BN backward apply (the pre-round-2 path; A/B runs)
+LAZY_DZ = os.environ.get('ASM_LAZY_DZ', '1') != '0'
 
 
 def _round_up(n: int, m: int) -> int:
@@ -220,21 +222,50 @@ def const_init(shape, value):
 # activations + tape
 # ---------------------------------------------------------------------------------------------------
 class Var(object):
-  """An activation: NHWC bf16 tensor (``data`` is None during the shape-only build walk)."""
-  __slots__ = ('data', 'shape', 'grad', 'grad_owned', 'needs_grad')
+  """An activation: NHWC bf16 tensor (``data`` is None during the shape-only build walk).
+
+  The gradient may be held LAZILY MASKED: (``_grad``, ``grad_mask``) stands for _grad * [mask bit set] -- the masked
+  gradient dz = dy * [y > 0] that the ReLU behind a residual add sends down the shortcut branch.  The two consumers
+  that dominate (the input gradient of the next 1x1 convolution, which adds it in its epilogue, and the batch-norm
+  backward of a projection shortcut) read (dy, mask) directly, so dz is never written; anything else just reads
+  ``.grad``, which materialises it."""
+  __slots__ = ('data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad')
 
   def __init__(self, data, shape=None, needs_grad=True):
     self.data = data
     self.shape = tuple(data.shape) if data is not None else tuple(shape)
-    self.grad = None
+    self._grad = None
+    self.grad_mask = None
     self.grad_owned = False
     self.needs_grad = needs_grad
 
+  @property
+  def grad(self):
+    if self.grad_mask is not None:
+      self._grad = ops.mask_apply(self._grad, self.grad_mask)
+      self.grad_mask = None
+      self.grad_owned = True
+    return self._grad
 
-def accum_grad(v: Var, g: torch.Tensor, owned: bool):
-  """v.grad += g.  ``owned`` says whether g may later be updated in place by us."""
+  @grad.setter
+  def grad(self, g):
+    self._grad = g
+    self.grad_mask = None
+
+  def take_masked_grad(self):
+    """-> (gradient tensor, packed mask or None) without materialising the product"""
+    return self._grad, self.grad_mask
+
+
+def accum_grad(v: Var, g: torch.Tensor, owned: bool, mask: Optional[torch.Tensor] = None):
+  """v.grad += g [* mask].  ``owned`` says whether g may later be updated in place by us."""
   if not v.needs_grad:
     return
+  if mask is not None:
+    if v._grad is None:
+      v._grad, v.grad_mask, v.grad_owned = g, mask, False
+      return
+    g, owned = ops.mask_apply(g, mask), True
   if v.grad is None:
     v.grad = g
     v.grad_owned = owned
@@ -398,8 +429,9 @@ class ConvKernel(object):
     a.notify_grad(self.name)
 
   def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool,
-               addend: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """dW into the gradient arena; returns dx [+ addend] (or None)."""
+               addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None
+               ) -> Optional[torch.Tensor]:
+    """dW into the gradient arena; returns dx [+ addend [where addend_mask]] (or None)."""
     a = self.arena
     side = a.side_stream if a.on_grad is None else None
     if side is not None:
@@ -414,10 +446,12 @@ class ConvKernel(object):
       return None
     if not need_dx:
       return None
+    if addend_mask is not None and (d.stride != 1 or d.C % 8):
+      addend, addend_mask = ops.mask_apply(addend, addend_mask), None     # the strided forms take a plain addend
     if self.kpad != self.cout:  # dy carries kpad channels (zero padded)
       dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, self.kpad, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo)
-      return ops.conv_dgrad(dd, dy, a.wt_view(self._wts), addend)
-    return ops.conv_dgrad(d, dy, a.wt_view(self._wts), addend)
+      return ops.conv_dgrad(dd, dy, a.wt_view(self._wts), addend, addend_mask)
+    return ops.conv_dgrad(d, dy, a.wt_view(self._wts), addend, addend_mask)
 
 
 class BatchNorm(object):
@@ -492,24 +526,35 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
     x_t = x.data
 
     def bwd():
-      dout = out.grad
+      # the incoming gradient may be lazily masked by the ReLU of the block this layer's output was the shortcut of:
+      # a BN without its own ReLU takes that mask as if it were its own (dz = dout * mask is exactly what it needs)
+      dout, in_mask = out.take_masked_grad()
       if dout is None:
         raise RuntimeError('conv_bn backward: no gradient reached this layer')
-      want_dz = residual is not None and relu
+      bmask, brelu = (mask_t if relu else None), relu
+      if in_mask is not None:
+        if relu or small or residual is not None:
+          dout, in_mask = out.grad, None                 # (never on this path's networks) materialise
+        else:
+          bmask, brelu = in_mask, True
+      lazy = LAZY_DZ and residual is not None and relu and res_mode == 1 and mask_t is not None and residual.needs_grad
+      want_dz = residual is not None and relu and not lazy
       if small:
-        dy, dz = ops.bn_small_bwd(dout, y, mask_t if relu else None, M, Cn, gamma, mean, invstd, a.g(bn.gamma),
-                                  a.g(bn.beta)), None
+        dy, dz = ops.bn_small_bwd(dout, y, bmask, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta)), None
       else:
-        dy, dz = ops.bn_bwd(dout, y, mask_t if relu else None, relu, M, Cn, gamma, mean, invstd, a.g(bn.gamma),
-                            a.g(bn.beta), want_dz)
+        dy, dz = ops.bn_bwd(dout, y, bmask, brelu, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), want_dz)
       a.notify_grad(bn.gamma)
       if residual is not None:
-        dres = dz if relu else dout
-        if res_mode == 2:
-          accum_grad(residual, ops.upsample2x_bwd(dres), True)
+        if lazy:           # dz = dout * mask is NOT written: the shortcut branch receives (dout, mask)
+          accum_grad(residual, dout, False, mask=mask_t)
         else:
-          accum_grad(residual, dres, relu)
-      dx = conv.backward(d, x_t, dy, x.needs_grad, addend=x.grad)   # fan-in add fused into the dgrad epilogue
+          dres = dz if relu else dout
+          if res_mode == 2:
+            accum_grad(residual, ops.upsample2x_bwd(dres), True)
+          else:
+            accum_grad(residual, dres, relu)
+      xg, xmask = x.take_masked_grad()
+      dx = conv.backward(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask)   # fan-in add fused into the dgrad epilogue
       if dx is not None:
         x.grad, x.grad_owned = dx, True
       out.grad = None

@@ -164,12 +164,16 @@ def conv_fprop_bn(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, scale, shift, r
   return y
 
 
-def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional[torch.Tensor] = None
-               ) -> torch.Tensor:
-  """dx = conv_transpose(dy, w) [+ addend]"""
+def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional[torch.Tensor] = None,
+               addend_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+  """dx = conv_transpose(dy, w) [+ addend [where addend_mask]]"""
   dx = empty((d.N, d.H, d.W, d.C), BF16, dy)
   ev = _TIMER.start('dgrad', d) if _TIMER is not None else None
-  check(L().asm_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(addend), _ptr(dx), _stream()), 'conv2d_dgrad')
+  if addend_mask is not None:
+    check(L().asm_conv2d_dgrad_masked(C.byref(d), _ptr(dy), _ptr(wt), _ptr(addend), _ptr(addend_mask), _ptr(dx),
+                                      _stream()), 'conv2d_dgrad_masked')
+  else:
+    check(L().asm_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(addend), _ptr(dx), _stream()), 'conv2d_dgrad')
   if ev is not None:
     ev.record()
   return dx
@@ -528,6 +532,12 @@ def relu_fwd(x):
 def relu_bwd(dy, y):
   dx = torch.empty_like(dy)
   check(L().asm_relu_bwd(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()), 'relu_bwd')
+  return dx
+
+
+def mask_apply(dy, mask):
+  dx = torch.empty_like(dy)
+  check(L().asm_mask_apply(_ptr(dy), _ptr(mask), _ptr(dx), dy.numel(), _stream()), 'mask_apply')
   return dx
 
 

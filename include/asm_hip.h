@@ -89,6 +89,13 @@ int asm_conv2d_fprop_bn(const asm_conv_desc* d, const void* x, const void* w, vo
 int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend, void* dx,
                      void* stream);
 
+/* The same with an addend that is a NOT-YET-MASKED gradient: addend_mask is the packed ReLU mask written by asm_bn_apply
+ * ([N*H*W][C/8] bytes) and addend lanes whose bit is 0 count as 0 -- the masked gradient dz = dy * [y > 0] that
+ * tf.nn.relu's backward would have materialised for the shortcut branch (nets/resnet_model.py:92-95) is consumed
+ * straight from (dy, mask).  Not for the 1x1 stride-2 form (ASM_ENOTSUP). */
+int asm_conv2d_dgrad_masked(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                            const uint8_t* addend_mask, void* dx, void* stream);
+
 /* dw[k][r][s][c] (float32) = sum_{n,ho,wo} dy(n,ho,wo,k) * x(n, ho*stride+r-pad, wo*stride+s-pad, c).
  * Split-K over output pixels; `workspace` holds the per-split slabs. */
 size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d);
@@ -239,6 +246,8 @@ int asm_se_scale_bwd_x(const void* dy, const float* e, const void* dsq, void* dx
 int asm_relu_fwd(const void* x, void* y, size_t n, void* stream);
 int asm_relu_bwd(const void* dy, const void* y, void* dx, size_t n, void* stream);
 int asm_add_bf16(const void* a, const void* b, void* out, size_t n, void* stream);   /* out = a + b */
+/* dx = dy where the packed ReLU mask (asm_bn_apply) has a 1 bit, else 0; n elements, n / 8 mask bytes */
+int asm_mask_apply(const void* dy, const uint8_t* mask, void* dx, size_t n, void* stream);
 int asm_bias_add_f32(float* y, const float* bias, int M, int C, int ldy, void* stream);
 int asm_bias_grad_bf16(const void* dz, int M, int C, int ld, float* dbias, void* stream);
 int asm_cast_f32_to_bf16(const float* x, void* y, size_t n, void* stream);

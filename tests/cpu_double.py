@@ -135,7 +135,7 @@ class CpuDouble(object):
     T(y, (d.N * d.Ho * d.Wo, d.K), 'bf16').copy_(out)
     return 0
 
-  def asm_conv2d_dgrad(self, d, dy, wt, addend, dx, stream):
+  def asm_conv2d_dgrad(self, d, dy, wt, addend, dx, stream, addend_mask=0):
     d = _desc(d)
     self._validate(d, 'dgrad')
     g = T(dy, (d.N, d.Ho, d.Wo, d.K), 'bf16').float()
@@ -149,8 +149,24 @@ class CpuDouble(object):
     (gx,) = torch.autograd.grad(yy, x, g.permute(0, 3, 1, 2))
     gx = gx.permute(0, 2, 3, 1).to(torch.bfloat16).float()
     if addend:
-      gx = gx + T(addend, (d.N, d.H, d.W, d.C), 'bf16').float()
+      ad = T(addend, (d.N, d.H, d.W, d.C), 'bf16').float()
+      if addend_mask:
+        ad = ad * self._unpack_mask(addend_mask, d.N * d.H * d.W, d.C).view(ad.shape)
+      gx = gx + ad
     T(dx, (d.N, d.H, d.W, d.C), 'bf16').copy_(gx)
+    return 0
+
+  def asm_conv2d_dgrad_masked(self, d, dy, wt, addend, addend_mask, dx, stream):
+    return self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream, addend_mask)
+
+  @staticmethod
+  def _unpack_mask(mask, M, Cn):
+    mk = T(mask, (M, Cn // 8), 'u8').to(torch.int32)
+    bits = (mk[:, :, None] >> torch.arange(8, dtype=torch.int32)) & 1
+    return bits.reshape(M, Cn).float()
+
+  def asm_mask_apply(self, dy, mask, dx, n, stream):
+    T(dx, (n,), 'bf16').copy_(T(dy, (n,), 'bf16').float() * self._unpack_mask(mask, n // 8, 8).view(n))
     return 0
 
   def asm_conv2d_wgrad_workspace_bytes(self, d):

@@ -309,3 +309,26 @@ def test_fprop_with_folded_inference_bn(hip_lib, shape, res, relu):
   with pytest.raises(ValueError):
     ops.conv_fprop_bn(ops.make_conv_desc(N, H, W, Cn, K, k, k, stride, out_f32=True), x.cuda(), w.cuda(), scale.cuda(),
                       shift.cuda())
+
+
+@pytest.mark.parametrize('shape', [(4, 14, 14, 128, 512, 1, 1), (2, 28, 28, 64, 256, 1, 1), (2, 14, 14, 64, 64, 3, 1),
+                                   (32, 14, 14, 256, 1024, 1, 1)], ids=lambda s: 'x'.join(map(str, s)))
+def test_dgrad_with_masked_addend(hip_lib, shape):
+  """asm_conv2d_dgrad_masked(addend, mask) == asm_conv2d_dgrad(addend * mask) bit for bit, and asm_mask_apply is that
+  product: the lazily masked shortcut gradient is the same gradient."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K, k, stride = shape
+  g = torch.Generator(device='cuda').manual_seed(17)
+  d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
+  dy = torch.randn((N, d.Ho, d.Wo, K), generator=g, device='cuda').to(BF)
+  w = (torch.randn((K, k, k, Cn), generator=g, device='cuda') * (k * k * Cn) ** -0.5).to(BF)
+  wt = torch.empty((Cn, k, k, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w, wt, K, k, k, Cn)
+  addend = torch.randn((N, H, W, Cn), generator=g, device='cuda').to(BF)
+  mask = torch.randint(0, 256, (N * H * W, Cn // 8), generator=g, device='cuda', dtype=torch.uint8)
+  masked = ops.mask_apply(addend, mask)
+  bits = ((mask.to(torch.int32)[:, :, None] >> torch.arange(8, device='cuda', dtype=torch.int32)) & 1).reshape(N, H, W, Cn)
+  assert torch.equal(masked.float(), addend.float() * bits.float())
+  a = ops.conv_dgrad(d, dy, wt, addend, mask)
+  b = ops.conv_dgrad(d, dy, wt, masked)
+  assert torch.equal(a, b)
