@@ -96,9 +96,12 @@ struct Cfg {
 
 // Epilogue shared by both kernels.  acc[a][b][reg]: n_local = wn*WTN + a*32 + (reg&3) + 8*(reg>>2) + 4*lhi ;
 // m_local = wm*WTM + b*32 + l31.
+// patch_base >= 0: the tile's 128 rows are an 8 x 16 pixel patch of one image (conv_halo_kernel): row r is pixel
+// patch_base + (r >> 4) * W + (r & 15) of the [N*H*W] output.
 template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[TN][TM], unsigned char* smem,
-                                               int tile_m, int tile_n, int tid, int wm, int wn, int l31, int lhi) {
+                                               int tile_m, int tile_n, int tid, int wm, int wn, int l31, int lhi,
+                                               int patch_base = -1) {
   // ---------------- epilogue ----------------
   // acc[a][b][reg]: n_local = wn*WTN + a*32 + (reg&3) + 8*(reg>>2) + 4*lhi ; m_local = wm*WTM + b*32 + l31
   if constexpr (OUT_F32) {
@@ -156,7 +159,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
       if (m < p.M && n0 < co8) {
         size_t yoff = (size_t)m * p.ldy + n0;
-        if (p.y_strided) {   // workgroup-uniform: rows of a parity class scatter into the full-resolution tensor
+        if (patch_base >= 0) {
+          yoff = (size_t)(patch_base + (row >> 4) * p.Wi + (row & 15)) * p.ldy + n0;
+        } else if (p.y_strided) {   // workgroup-uniform: rows of a parity class scatter into the full-resolution tensor
           const unsigned img = fd_div((unsigned)m, p.fd_howo);
           const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
           const unsigned ho = fd_div(rem, p.fd_wo);
@@ -680,6 +685,178 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
   igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// conv_halo_kernel: stride-1 3x3 convolution (and its input gradient) for the NARROW high-resolution layers
+// (Ci in {32, 64}, 112 x 112 maps: the BigLittle module-0 / ResNet-D stem convolutions).
+// The gather-GEMM stages one activation tile PER TAP, so the 9 taps of a 3x3 read (almost) the same pixels 9 times
+// through L2 -> LDS: these layers need ~0.6 GB of HBM traffic but ~5 GB of L2 -> LDS traffic and ran at 2.0-3.0 TB/s
+// of HBM-equivalent rate (L2-bound, 14-20 % of the MFMA peak).  Here a workgroup owns an 8 x 16 pixel patch of one
+// image: the 10 x 18 halo of the patch is staged in LDS ONCE (rows padded by 16 bytes: conflict-free ds_read_b128 at
+// any tap offset), the whole 9-tap filter slice for the workgroup's output channels is LDS-DMA'd once, and the tap loop
+// runs entirely out of LDS with compile-time tap offsets and NO barriers.  Epilogue (bf16 pack, coalesced stores, fused
+// BN statistics / gradient fan-in addend) is the shared one.
+// Requires H % 8 == 0, W % 16 == 0, stride 1, pad 1 (so tiles == M / 128 and the statistics partials keep their layout).
+template <int KO, int CI, int WGM, int WGN, bool STATS>
+__global__ __launch_bounds__(256) void conv_halo_kernel(IGemmArgs p) {
+  using C = Cfg<128, KO, CI, WGM, WGN, false, STATS, 2>;
+  constexpr int TM = C::TM, TN = C::TN, WTM = C::WTM, WTN = C::WTN;
+  constexpr int HW_ = 18, HH_ = 10;                 // halo width / height in pixels
+  constexpr int RB = CI * 2 + 16;                   // padded halo row (bytes)
+  constexpr int HALO = HH_ * HW_ * RB;
+  constexpr int CPR = CI / 8;                       // 16-byte chunks per pixel / per filter row
+  constexpr int WROWB = CI * 2;                     // filter tile row bytes (XOR-swizzled, as in igemm2)
+  constexpr int WTAP = KO * WROWB;                  // one tap's filter tile
+  constexpr int KK = CI / 16;
+  static_assert(HALO % 16 == 0, "filter tiles stay 16-byte aligned behind the halo");
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xs = smem;
+  unsigned char* ws = smem + HALO;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // tile -> (image, patch row, patch column); XCD-aware bijective remap (block b runs on XCD b % 8): every XCD gets a
+  // contiguous run of patches, so the halo rows neighbouring patches share are re-read from that XCD's L2
+  int logical;
+  {
+    const int nb = p.n_blocks, q = nb >> 3, r = nb & 7;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = logical / p.n_tiles_n, tile_n = logical - tile_m * p.n_tiles_n;
+  const int tiles_x = p.Wi >> 4, tpi = tiles_x * (p.Hi >> 3);
+  const int img = tile_m / tpi, trem = tile_m - img * tpi;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int y0 = ty * 8, x0 = tx * 16;
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- filter: all 9 taps of this workgroup's KO rows by LDS-DMA (lane-linear destination, swizzle on the source) ----
+  {
+    const int chunk = tid % CPR, r0 = tid / CPR;
+    constexpr int RPP = 256 / CPR;
+    const int csw = (chunk ^ swz<CI>(r0)) << 3;
+    const int wrow0 = wave * (64 / CPR);
+#pragma unroll
+    for (int j = 0; j < (KO + RPP - 1) / RPP; ++j) {
+      const int row = r0 + j * RPP;
+      const int n = tile_n * KO + row;
+      const unsigned vw = (row < KO && n < p.Co) ? ((unsigned)n * (unsigned)p.w_row_pitch + (unsigned)csw) * 2u : ASM_OOB;
+      if (j * RPP + wrow0 < KO) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(ws + t * WTAP + (j * RPP + wrow0) * WROWB), 16, (int)vw,
+                                                   (int)((unsigned)t * (unsigned)p.Ci * 2u), 0, 0);
+      }
+    }
+  }
+  // ---- halo: 10 x 18 pixels x CI channels, register-staged (zero outside the image) ----
+  {
+    constexpr int NV = HH_ * HW_ * CPR;
+    const unsigned img_off = (unsigned)img * (unsigned)p.x_img_pitch;
+#pragma unroll
+    for (int i0 = 0; i0 < NV; i0 += 256) {
+      const int i = i0 + tid;
+      if (i < NV) {
+        const int hp = i / CPR, ck = i - hp * CPR;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = ((unsigned)gy < (unsigned)p.Hi) && ((unsigned)gx < (unsigned)p.Wi) && (ck * 8 < p.Ci);
+        const unsigned off = (img_off + (unsigned)gy * (unsigned)p.x_row_pitch + (unsigned)gx * (unsigned)p.x_pix_pitch +
+                              (unsigned)ck * 8u) * 2u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : ASM_OOB, 0, 0);
+        *reinterpret_cast<u32x4*>(xs + hp * RB + ck * 16) = v;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // per-lane fragment bases: activation pixel (py, px) of row m_local -> halo index py * 18 + px (top-left of its window)
+  unsigned fxo[TM], fwo[TN];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int row = wm * WTM + b * 32 + l31;
+    fxo[b] = (unsigned)(((row >> 4) * HW_ + (row & 15)) * RB + lhi * 16);
+  }
+  // (+32 filter rows keep the swizzle term -- rows 32 apart share (row >> 1) & 7 / (row >> 2) & 3 -- but the XOR with the
+  //  k-chunk does not distribute over kk, so the swizzled chunk is formed per (a, kk) below)
+#pragma unroll
+  for (int a = 0; a < TN; ++a) fwo[a] = (unsigned)((wn * WTN + a * 32 + l31) * WROWB);
+  const int wsw = swz<CI>(wn * WTN + l31);
+
+  // tap loop: fprop (tsign > 0) reads halo (py + r, px + s) with filter tap (r, s); the input gradient (tsign < 0) reads
+  // halo (py + 2 - r, px + 2 - s) with the same filter tap (dx(h, w) = sum dy(h + 1 - r, w + 1 - s) . w(r, s))
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int r = t / 3, q = t - r * 3;
+    const int hoff = (p.tsign > 0 ? (r * HW_ + q) : ((2 - r) * HW_ + (2 - q))) * RB;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      bf16x8 fw[TN], fx[TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+        fw[a] = *reinterpret_cast<const bf16x8*>(ws + t * WTAP + fwo[a] + (((kk * 2 + lhi) ^ wsw) << 4));
+#pragma unroll
+      for (int b = 0; b < TM; ++b) fx[b] = *reinterpret_cast<const bf16x8*>(xs + fxo[b] + hoff + kk * 32);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a], fx[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // every wave is done reading the halo / filter: the epilogue reuses the LDS for the output tile
+  const int patch_base = (img * p.Hi + y0) * p.Wi + x0;
+  igemm_epilogue<C, 128, KO, WTM, WTN, TM, TN, false, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi, patch_base);
+}
+
+template <int KO, int CI, int WGM, int WGN>
+int launch_halo(IGemmArgs& a, bool stats, hipStream_t st) {
+  using C = Cfg<128, KO, CI, WGM, WGN, false, true, 2>;
+  constexpr int LDS = cmax(cmax(10 * 18 * (CI * 2 + 16) + 9 * KO * CI * 2, C::EPI), C::RED);
+  a.n_tiles_n = cdiv(a.Co, KO);
+  a.n_blocks = (a.M / 128) * a.n_tiles_n;
+  static bool attr_done[2][ASM_MAX_DEVICES] = {};
+  if (stats) {
+    auto kern = conv_halo_kernel<KO, CI, WGM, WGN, true>;
+    if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done[1]); e != hipSuccess)
+      ASM_FAIL(ASM_EHIP, "conv_halo_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), LDS, st, a);
+  } else {
+    auto kern = conv_halo_kernel<KO, CI, WGM, WGN, false>;
+    if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done[0]); e != hipSuccess)
+      ASM_FAIL(ASM_EHIP, "conv_halo_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), LDS, st, a);
+  }
+  ASM_CHECK_LAUNCH("conv_halo_kernel");
+  return ASM_OK;
+}
+
+// returns 1 when the layer is not one the halo kernel covers
+int try_halo(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
+  if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.bn_scale) return 1;
+  if (a.Hi % 8 || a.Wi % 16 || a.M != (a.HoWo / a.Wo) * a.Wo * (a.M / a.HoWo) || a.HoWo != a.Hi * a.Wi) return 1;
+  if (a.x_pix_pitch != a.Ci || a.x_row_pitch != a.Wi * a.Ci || a.x_img_pitch != a.Hi * a.Wi * a.Ci) return 1;
+  if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return 1;
+  if (a.wt0 != 0 || a.wtr != 3 || a.wts != 1) return 1;
+  if (a.Ci == 64 && a.Co == 32) return launch_halo<32, 64, 4, 1>(a, stats, st);
+  if (a.Ci == 32 && a.Co == 32) return launch_halo<32, 32, 4, 1>(a, stats, st);
+  if (a.Ci == 32 && a.Co == 64) return launch_halo<64, 32, 2, 2>(a, stats, st);
+  if (a.Ci == 64 && a.Co == 64) return launch_halo<64, 64, 2, 2>(a, stats, st);
+  return 1;
+}
+
 template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2>
 int launch2_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
@@ -774,14 +951,23 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
   a.fd_howo = make_fastdiv((unsigned)a.HoWo);
   a.fd_wo = make_fastdiv((unsigned)a.Wo);
   const int v2 = asm_env_int("ASM_IGEMM_V2", 1);
+  if (v2 && fmode == 0 && ftile == 0 && asm_env_int("ASM_CONV_HALO", 1)) {
+    const int rc = try_halo(a, out_f32, stats, st);
+    if (rc != 1) return rc;
+  }
   if (v2 && fmode == 0) {
     int rc;
     const long long b256v = (long long)cdiv(a.M, 256) * cdiv(a.Co, 256);
     bool bigv = heavy && a.Co >= 256 && b256v >= 192;
     if (ftile == 1) bigv = false;
     if (ftile == 3 && a.Ci % 64 == 0) bigv = true;
+    // Small-M, deep-K layers (7x7 maps at batch 256: 98 row tiles): with 128 x 128 tiles a 256-channel output makes only
+    // 196 workgroups for the 512 resident slots; 128 x 64 tiles double the workgroup count (ASM_IGEMM_SMALLM=1, A/B knob).
+    const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Co, 128);
+    const bool narrow = asm_env_int("ASM_IGEMM_SMALLM", 0) && !bigv && ftile == 0 && a.Co > 64 && a.Co % 64 == 0 &&
+                        t128 < 320 && (long long)a.R * a.S * a.Ci >= 1024;
     if (a.Co <= 32) rc = bk64 ? launch2_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, st) : launch2_cfg<128, 32, 32, 4, 1>(a, out_f32, stats, st);
-    else if (a.Co <= 64) rc = bk64 ? launch2_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, st);
+    else if (a.Co <= 64 || narrow) rc = bk64 ? launch2_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, st);
     else if (ftile == 2 && a.Ci % 64 == 0) rc = launch2_cfg<256, 128, 64, 4, 2>(a, out_f32, stats, st);
     else if (bigv) rc = launch2_cfg<256, 256, 64, 4, 2>(a, out_f32, stats, st);
     else rc = bk64 ? launch2_cfg<128, 128, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 128, 32, 2, 2>(a, out_f32, stats, st);

@@ -302,33 +302,61 @@ __global__ __launch_bounds__(256) void sk_bn_bwd_reduce_kernel(const bf16_t* __r
 }
 
 // pass 2: dy = A * dz + B * y + C   (coefficients from asm_bn_bwd_finalize)
+// Same (chunk, image) x (vector column, row lane) decomposition as the reducer: a thread keeps its 8 channels, so the
+// gates, ds / HW and the five per-channel coefficient vectors are loaded ONCE and the loop streams y, dV -> dy (the
+// one-vector-per-thread form re-derived 56 scalars for every 32 bytes moved and ran at 3.3 TB/s).
 __global__ __launch_bounds__(256) void sk_bn_bwd_apply_kernel(const bf16_t* __restrict__ dv, const float* __restrict__ att,
                                                               const bf16_t* __restrict__ ds, const bf16_t* __restrict__ y,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ cA,
                                                               const float* __restrict__ cB, const float* __restrict__ cC,
-                                                              bf16_t* __restrict__ dy, int N, SkBnGeom g) {
-  const size_t nvec = (size_t)N * g.HW * g.vcols;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nvec) return;
-  const unsigned iu = (unsigned)i;
-  const unsigned mu_ = iu / (unsigned)g.vcols;
-  const int vc = (int)(iu - mu_ * (unsigned)g.vcols);
-  const int n = (int)(mu_ / (unsigned)g.HW);
+                                                              bf16_t* __restrict__ dy, SkBnGeom g) {
+  const int tid = threadIdx.x;
+  const int vc = tid % g.vcols;
+  const int rr = tid / g.vcols;
+  if (rr >= g.rpb) return;
+  const int n = blockIdx.y;
+  const int C2 = 2 * g.F;
   const int fv = g.F >> 3;
   const int cv = vc >= fv ? vc - fv : vc;
   Coef8 k;
   load_coef(scale, shift, vc * 8, k);
-  float ab[8], u[8], fy[8], fg[8], o[8];
-  sk_thread_setup(g, n, vc, att, ds, ab, u);
-  unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + i * 8)), fy);
-  unpack8(ldv(dv, (size_t)mu_ * g.F + cv * 8), fg);
+  float ab[8], u[8], kA[8], kB[8], kC[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float dz = (fy[e] * k.sc[e] + k.sh[e] > 0.f) ? (ab[e] * fg[e] + u[e]) : 0.f;
-    o[e] = cA[vc * 8 + e] * dz + cB[vc * 8 + e] * fy[e] + cC[vc * 8 + e];
+    kA[e] = cA[vc * 8 + e];
+    kB[e] = cB[vc * 8 + e];
+    kC[e] = cC[vc * 8 + e];
   }
-  __builtin_nontemporal_store(pack8(o), reinterpret_cast<u32x4*>(dy + i * 8));
+  sk_thread_setup(g, n, vc, att, ds, ab, u);
+  const int r_begin = blockIdx.x * g.rows_per_chunk;
+  const int r_end = min(g.HW, r_begin + g.rows_per_chunk);
+  constexpr int U = 2;
+  for (int r = r_begin + rr; r < r_end; r += U * g.rpb) {
+    u32x4 vy[U], vg[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int rq = r + q * g.rpb;
+      const size_t m = (size_t)n * g.HW + (rq < r_end ? rq : r);
+      vy[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + m * C2 + vc * 8));
+      vg[q] = ldv(dv, m * g.F + cv * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int rq = r + q * g.rpb;
+      if (rq >= r_end) break;
+      float fy[8], fg[8], o[8];
+      unpack8(vy[q], fy);
+      unpack8(vg[q], fg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dz = (fy[e] * k.sc[e] + k.sh[e] > 0.f) ? (ab[e] * fg[e] + u[e]) : 0.f;
+        o[e] = kA[e] * dz + kB[e] * fy[e] + kC[e];
+      }
+      const size_t m = (size_t)n * g.HW + rq;
+      __builtin_nontemporal_store(pack8(o), reinterpret_cast<u32x4*>(dy + m * C2 + vc * 8));
+    }
+  }
 }
 
 SkBnGeom make_geom(int N, int HW, int F) {
@@ -418,10 +446,9 @@ extern "C" int asm_sk_bn_bwd_apply(const void* dv, const float* att, const void*
   SKF_OK("sk_bn_bwd_apply");
   ASM_REQUIRE(dv && att && ds && y && scale && shift && coefA && coefB && coefC && dy, "sk_bn_bwd_apply: null pointer");
   const SkBnGeom g = make_geom(N, HW, F);
-  const size_t nvec = (size_t)N * HW * g.vcols;
-  hipLaunchKernelGGL(sk_bn_bwd_apply_kernel, dim3((unsigned)cdivz(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(sk_bn_bwd_apply_kernel, dim3(g.chunks, N), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dv, att, (const bf16_t*)ds, (const bf16_t*)y, scale, shift, coefA, coefB, coefC,
-                     (bf16_t*)dy, N, g);
+                     (bf16_t*)dy, g);
   ASM_CHECK_LAUNCH("sk_bn_bwd_apply");
   return ASM_OK;
 }

@@ -46,9 +46,11 @@ class GradSync(object):
       # Trainer builds the model lazily on the first forward: a GradSync made before that would cut zero buckets and
       # every later step would all-reduce nothing while the replicas drift apart silently.
       raise RuntimeError('GradSync needs a built model: call model.build(...) (ParamArena.finalize) first')
-    if overlap and getattr(arena, 'side_stream', None) is not None:
-      raise RuntimeError('GradSync(overlap=True) cannot be combined with the weight-gradient side stream '
-                         '(ASM_WGRAD_STREAM=1): bucket launches are ordered against the compute stream only')
+    if getattr(arena, 'side_stream', None) is not None:
+      # bucket launches are ordered against the compute stream only, so with an exchange attached the weight
+      # gradients go back onto the compute stream (nn.ConvKernel.backward checks arena.on_grad / side_stream)
+      arena.join_side_stream()
+      arena.side_stream = None
     if comm_dtype not in ('fp32', 'bf16'):
       raise ValueError("comm_dtype must be 'fp32' (the reference's all-reduce precision) or 'bf16'")
     self.arena = arena

@@ -112,11 +112,12 @@ class Model(object):
     self._walk(ctx, x, use_resnet_d, False)
     self._built_with_d = use_resnet_d
     self.arena.finalize(self.device, self.seed)
-    # Weight gradients on a second HIP stream fill the tail rounds of the 1-workgroup-per-CU dgrad tiles: -1.7 % step
-    # time on one MI355X (same box).  Opt-in (ASM_WGRAD_STREAM=1): with two streams sharing the CUs the per-kernel
-    # HIP-event durations bench.py reports for the roofline stop being properties of the kernels.  Never used with a
-    # gradient all-reduce hook (the exchange has its own stream and its launch order follows the compute stream).
-    if os.environ.get('ASM_WGRAD_STREAM', '0') == '1':
+    # Weight gradients are leaves of the backward graph, so they run on a second HIP stream beside the
+    # dgrad -> BN-backward chain and fill the tail rounds of the 1-workgroup-per-CU convolution tiles: -0.4 .. -0.8 % step
+    # time in same-box A/B runs (round 1: 8330 vs 8190 img/s; round 2: 29.59 / 29.71 vs 29.83 / 29.84 ms).
+    # ASM_WGRAD_STREAM=0 keeps everything on the compute stream.  Single-GPU only: dp.GradSync (whose bucket launches are
+    # ordered against the compute stream) switches it off when it attaches.
+    if os.environ.get('ASM_WGRAD_STREAM', '1') != '0':
       self.arena.enable_side_stream()     # no-op on the CPU test double
 
   def __call__(self, inputs, training, reuse=False, use_resnet_d=False, keep_prob=1.0, return_embedding=False,

@@ -55,6 +55,10 @@ SHAPES = [
     (2, 9, 9, 72, 40, 3, 1),        # channel tail (72 % 32 = 8), K not multiple of 64
     (256, 1, 1, 64, 32, 1, 1),      # SK fc1 shape
     (4, 15, 15, 64, 64, 3, 2),      # odd spatial, strided
+    (2, 16, 32, 64, 32, 3, 1),      # conv_halo_kernel: 8 x 16 patches with a resident halo, Ci 64 -> 32
+    (3, 8, 16, 32, 64, 3, 1),       # conv_halo_kernel: one patch per image, Ci 32 -> 64
+    (1, 24, 48, 32, 32, 3, 1),      # conv_halo_kernel: 3 x 3 patches, Ci 32 -> 32
+    (2, 16, 16, 64, 64, 3, 1),      # conv_halo_kernel: Ci 64 -> 64
 ]
 
 
