@@ -43,7 +43,7 @@ def _check(out, ref, rel=4e-3, name=''):
 
 SHAPES = [
     # N, H,  W,  C,   K,   k, stride
-    (2, 16, 16, 64, 64, 3, 1),      # BN=64, BK=64
+    (2, 16, 16, 64, 64, 3, 1),      # BN=64, BK=64 (igemm variants); conv_halo_kernel Ci 64 -> 64 in the default mode
     (2, 16, 16, 64, 128, 3, 1),     # BN=128 (SK conv shape, small)
     (3, 7, 7, 256, 512, 3, 1),      # M=147 (ragged M tile), 4 N-tiles
     (2, 14, 14, 128, 128, 3, 2),    # strided 3x3
@@ -58,7 +58,6 @@ SHAPES = [
     (2, 16, 32, 64, 32, 3, 1),      # conv_halo_kernel: 8 x 16 patches with a resident halo, Ci 64 -> 32
     (3, 8, 16, 32, 64, 3, 1),       # conv_halo_kernel: one patch per image, Ci 32 -> 64
     (1, 24, 48, 32, 32, 3, 1),      # conv_halo_kernel: 3 x 3 patches, Ci 32 -> 32
-    (2, 16, 16, 64, 64, 3, 1),      # conv_halo_kernel: Ci 64 -> 64
 ]
 
 
