@@ -696,45 +696,61 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
 // runs entirely out of LDS with compile-time tap offsets and NO barriers.  Epilogue (bf16 pack, coalesced stores, fused
 // BN statistics / gradient fan-in addend) is the shared one.
 // Requires H % 8 == 0, W % 16 == 0, stride 1, pad 1 (so tiles == M / 128 and the statistics partials keep their layout).
+template <int KO, int CI>
+struct HaloCfg {
+  static constexpr int RB = CI * 2 + 16;                    // padded halo row (bytes)
+  static constexpr int HALO = 10 * 18 * RB;
+  static constexpr int FILT = 9 * KO * CI * 2;              // the whole 3x3 filter slice of the workgroup's KO rows
+  static constexpr int EPI = 128 * (KO * 2 + 16);           // Cfg::EPI
+  static constexpr int RED = (256 / (KO / 8)) * KO * 2 * 4; // Cfg::RED
+  static constexpr int WORK = cmax(cmax(HALO, EPI), RED);   // halo, then output tile / statistics scratch
+  static constexpr int LDS = FILT + WORK;
+  static constexpr int PER_CU = (160 * 1024) / LDS < 4 ? (160 * 1024) / LDS : 4;
+};
+
+// PERSISTENT and weight-stationary: a workgroup loads its filter slice ONCE and then walks a contiguous run of patches
+// (vertical / horizontal neighbours back to back: shared halo rows come from this XCD's L2).  The halo of patch i+1 is
+// prefetched into registers while patch i is multiplied and stored, so a workgroup hides its own HBM latency.
 template <int KO, int CI, int WGM, int WGN, bool STATS>
 __global__ __launch_bounds__(256) void conv_halo_kernel(IGemmArgs p) {
   using C = Cfg<128, KO, CI, WGM, WGN, false, STATS, 2>;
+  using H = HaloCfg<KO, CI>;
   constexpr int TM = C::TM, TN = C::TN, WTM = C::WTM, WTN = C::WTN;
-  constexpr int HW_ = 18, HH_ = 10;                 // halo width / height in pixels
-  constexpr int RB = CI * 2 + 16;                   // padded halo row (bytes)
-  constexpr int HALO = HH_ * HW_ * RB;
+  constexpr int HW_ = 18;                           // halo width in pixels (height 10)
+  constexpr int RB = H::RB;
   constexpr int CPR = CI / 8;                       // 16-byte chunks per pixel / per filter row
   constexpr int WROWB = CI * 2;                     // filter tile row bytes (XOR-swizzled, as in igemm2)
   constexpr int WTAP = KO * WROWB;                  // one tap's filter tile
   constexpr int KK = CI / 16;
-  static_assert(HALO % 16 == 0, "filter tiles stay 16-byte aligned behind the halo");
+  constexpr int NV = 10 * HW_ * CPR;                // 16-byte vectors of one halo
+  constexpr int HP = (NV + 255) / 256;              // halo vectors per thread
+  static_assert(H::EPI == C::EPI && H::RED >= C::RED, "epilogue scratch size");
   typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* xs = smem;
-  unsigned char* ws = smem + HALO;
+  unsigned char* ws = smem;                         // filter (resident)
+  unsigned char* xs = smem + H::FILT;               // halo of the current patch; reused by the epilogue
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  // tile -> (image, patch row, patch column); XCD-aware bijective remap (block b runs on XCD b % 8): every XCD gets a
-  // contiguous run of patches, so the halo rows neighbouring patches share are re-read from that XCD's L2
-  int logical;
+  // this workgroup's run of (row-tile) patches; block b runs on XCD b % 8, so give XCD x the x-th eighth of the patches
+  const int n_m = p.M >> 7;
+  int t_begin, t_end;
   {
-    const int nb = p.n_blocks, q = nb >> 3, r = nb & 7;
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
     const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective remap
+    const int per = n_m / nb, extra = n_m - per * nb;
+    t_begin = logical * per + (logical < extra ? logical : extra);
+    t_end = t_begin + per + (logical < extra ? 1 : 0);
   }
-  const int tile_m = logical / p.n_tiles_n, tile_n = logical - tile_m * p.n_tiles_n;
   const int tiles_x = p.Wi >> 4, tpi = tiles_x * (p.Hi >> 3);
-  const int img = tile_m / tpi, trem = tile_m - img * tpi;
-  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-  const int y0 = ty * 8, x0 = tx * 16;
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
 
-  // ---- filter: all 9 taps of this workgroup's KO rows by LDS-DMA (lane-linear destination, swizzle on the source) ----
+  // ---- filter: all 9 taps of the KO rows by LDS-DMA (lane-linear destination, swizzle on the source), once ----
   {
     const int chunk = tid % CPR, r0 = tid / CPR;
     constexpr int RPP = 256 / CPR;
@@ -743,8 +759,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(IGemmArgs p) {
 #pragma unroll
     for (int j = 0; j < (KO + RPP - 1) / RPP; ++j) {
       const int row = r0 + j * RPP;
-      const int n = tile_n * KO + row;
-      const unsigned vw = (row < KO && n < p.Co) ? ((unsigned)n * (unsigned)p.w_row_pitch + (unsigned)csw) * 2u : ASM_OOB;
+      const unsigned vw = (row < KO && row < p.Co) ? ((unsigned)row * (unsigned)p.w_row_pitch + (unsigned)csw) * 2u : ASM_OOB;
       if (j * RPP + wrow0 < KO) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -753,35 +768,33 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(IGemmArgs p) {
       }
     }
   }
-  // ---- halo: 10 x 18 pixels x CI channels, register-staged (zero outside the image) ----
-  {
-    constexpr int NV = HH_ * HW_ * CPR;
+
+  // halo vector i of a thread: pixel hp = i / CPR of the 10 x 18 halo, chunk ck
+  auto load_halo = [&](int tile, u32x4 (&hv)[HP]) {
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 16;
     const unsigned img_off = (unsigned)img * (unsigned)p.x_img_pitch;
 #pragma unroll
-    for (int i0 = 0; i0 < NV; i0 += 256) {
-      const int i = i0 + tid;
-      if (i < NV) {
-        const int hp = i / CPR, ck = i - hp * CPR;
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = ((unsigned)gy < (unsigned)p.Hi) && ((unsigned)gx < (unsigned)p.Wi) && (ck * 8 < p.Ci);
-        const unsigned off = (img_off + (unsigned)gy * (unsigned)p.x_row_pitch + (unsigned)gx * (unsigned)p.x_pix_pitch +
-                              (unsigned)ck * 8u) * 2u;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : ASM_OOB, 0, 0);
-        *reinterpret_cast<u32x4*>(xs + hp * RB + ck * 16) = v;
-      }
+    for (int k = 0; k < HP; ++k) {
+      const int i = k * 256 + tid;
+      const int hp = i / CPR, ck = i - hp * CPR;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool ok = (i < NV) && ((unsigned)gy < (unsigned)p.Hi) && ((unsigned)gx < (unsigned)p.Wi);
+      const unsigned off = (img_off + (unsigned)gy * (unsigned)p.x_row_pitch + (unsigned)gx * (unsigned)p.x_pix_pitch +
+                            (unsigned)ck * 8u) * 2u;
+      hv[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : ASM_OOB, 0, 0);
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  f32x16 acc[TN][TM];
+  };
+  auto store_halo = [&](const u32x4 (&hv)[HP]) {
 #pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    for (int k = 0; k < HP; ++k) {
+      const int i = k * 256 + tid;
+      const int hp = i / CPR, ck = i - hp * CPR;
+      if (i < NV) *reinterpret_cast<u32x4*>(xs + hp * RB + ck * 16) = hv[k];
+    }
+  };
 
   // per-lane fragment bases: activation pixel (py, px) of row m_local -> halo index py * 18 + px (top-left of its window)
   unsigned fxo[TM], fwo[TN];
@@ -790,54 +803,73 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(IGemmArgs p) {
     const int row = wm * WTM + b * 32 + l31;
     fxo[b] = (unsigned)(((row >> 4) * HW_ + (row & 15)) * RB + lhi * 16);
   }
-  // (+32 filter rows keep the swizzle term -- rows 32 apart share (row >> 1) & 7 / (row >> 2) & 3 -- but the XOR with the
-  //  k-chunk does not distribute over kk, so the swizzled chunk is formed per (a, kk) below)
 #pragma unroll
   for (int a = 0; a < TN; ++a) fwo[a] = (unsigned)((wn * WTN + a * 32 + l31) * WROWB);
-  const int wsw = swz<CI>(wn * WTN + l31);
+  const int wsw = swz<CI>(wn * WTN + l31);   // rows 32 apart share the swizzle term
 
-  // tap loop: fprop (tsign > 0) reads halo (py + r, px + s) with filter tap (r, s); the input gradient (tsign < 0) reads
-  // halo (py + 2 - r, px + 2 - s) with the same filter tap (dx(h, w) = sum dy(h + 1 - r, w + 1 - s) . w(r, s))
+  u32x4 hv[HP];
+  if (t_begin < t_end) load_halo(t_begin, hv);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the filter DMA (and the first halo) have landed
+
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                 // the previous patch's epilogue is done with the scratch region (1st trip: filter visible)
+    store_halo(hv);
+    __syncthreads();
+    if (tile + 1 < t_end) load_halo(tile + 1, hv);   // in flight under the MFMAs and the stores of this patch
+
+    f32x16 acc[TN][TM];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int r = t / 3, q = t - r * 3;
-    const int hoff = (p.tsign > 0 ? (r * HW_ + q) : ((2 - r) * HW_ + (2 - q))) * RB;
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      bf16x8 fw[TN], fx[TM];
+      for (int b = 0; b < TM; ++b)
 #pragma unroll
-      for (int a = 0; a < TN; ++a)
-        fw[a] = *reinterpret_cast<const bf16x8*>(ws + t * WTAP + fwo[a] + (((kk * 2 + lhi) ^ wsw) << 4));
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // tap loop: fprop (tsign > 0) reads halo (py + r, px + s) with filter tap (r, s); the input gradient (tsign < 0)
+    // reads halo (py + 2 - r, px + 2 - s) with the same filter tap (dx(h, w) = sum dy(h + 1 - r, w + 1 - s) . w(r, s))
 #pragma unroll
-      for (int b = 0; b < TM; ++b) fx[b] = *reinterpret_cast<const bf16x8*>(xs + fxo[b] + hoff + kk * 32);
+    for (int t = 0; t < 9; ++t) {
+      const int r = t / 3, q = t - r * 3;
+      const int hoff = (p.tsign > 0 ? (r * HW_ + q) : ((2 - r) * HW_ + (2 - q))) * RB;
 #pragma unroll
-      for (int a = 0; a < TN; ++a)
+      for (int kk = 0; kk < KK; ++kk) {
+        bf16x8 fw[TN], fx[TM];
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a], fx[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < TN; ++a)
+          fw[a] = *reinterpret_cast<const bf16x8*>(ws + t * WTAP + fwo[a] + (((kk * 2 + lhi) ^ wsw) << 4));
+#pragma unroll
+        for (int b = 0; b < TM; ++b) fx[b] = *reinterpret_cast<const bf16x8*>(xs + fxo[b] + hoff + kk * 32);
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a], fx[b], acc[a][b], 0, 0, 0);
+      }
     }
+    __syncthreads();   // every wave is done reading the halo: the epilogue reuses the region for the output tile
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int patch_base = (img * p.Hi + ty * 8) * p.Wi + tx * 16;
+    igemm_epilogue<C, 128, KO, WTM, WTN, TM, TN, false, STATS>(p, acc, xs, tile, 0, tid, wm, wn, l31, lhi, patch_base);
   }
-  __syncthreads();   // every wave is done reading the halo / filter: the epilogue reuses the LDS for the output tile
-  const int patch_base = (img * p.Hi + y0) * p.Wi + x0;
-  igemm_epilogue<C, 128, KO, WTM, WTN, TM, TN, false, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi, patch_base);
 }
 
 template <int KO, int CI, int WGM, int WGN>
 int launch_halo(IGemmArgs& a, bool stats, hipStream_t st) {
-  using C = Cfg<128, KO, CI, WGM, WGN, false, true, 2>;
-  constexpr int LDS = cmax(cmax(10 * 18 * (CI * 2 + 16) + 9 * KO * CI * 2, C::EPI), C::RED);
-  a.n_tiles_n = cdiv(a.Co, KO);
-  a.n_blocks = (a.M / 128) * a.n_tiles_n;
+  using H = HaloCfg<KO, CI>;
+  a.n_tiles_n = 1;
+  const int n_m = a.M / 128;
+  a.n_blocks = n_m < H::PER_CU * 256 ? n_m : H::PER_CU * 256;
   static bool attr_done[2][ASM_MAX_DEVICES] = {};
   if (stats) {
     auto kern = conv_halo_kernel<KO, CI, WGM, WGN, true>;
-    if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done[1]); e != hipSuccess)
+    if (hipError_t e = asm_ensure_dyn_lds(kern, H::LDS, attr_done[1]); e != hipSuccess)
       ASM_FAIL(ASM_EHIP, "conv_halo_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), H::LDS, st, a);
   } else {
     auto kern = conv_halo_kernel<KO, CI, WGM, WGN, false>;
-    if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done[0]); e != hipSuccess)
+    if (hipError_t e = asm_ensure_dyn_lds(kern, H::LDS, attr_done[0]); e != hipSuccess)
       ASM_FAIL(ASM_EHIP, "conv_halo_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), H::LDS, st, a);
   }
   ASM_CHECK_LAUNCH("conv_halo_kernel");
   return ASM_OK;
