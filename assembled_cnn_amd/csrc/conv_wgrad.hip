@@ -302,6 +302,164 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// wgrad_halo_kernel: weight gradient of the NARROW 3x3 stride-1 layers at high resolution (C, K in {32, 64}; 112 x 112
+// maps), persistent.  The general kernel gathers one x tile PER TAP COLUMN GROUP, i.e. reads (nearly) the same pixels 9
+// times through L2; here a workgroup walks a contiguous run of 8 x 16 pixel patches, stages the patch's dy rows and the
+// 10 x 18 halo of x in LDS once, and accumulates ALL nine taps of dW[k][t][c] in registers from them (transposing
+// ds_read_b64_tr_b16 fragments, tap shifts are plain row offsets into the halo).  The next patch is prefetched into
+// registers under the MFMAs.  One fp32 slab per workgroup, summed by wgrad_reduce_kernel in fixed order (deterministic).
+template <int KF, int CI>
+struct WHalo {
+  static constexpr int XRB = CI == 32 ? 64 : 192;    // row strides = 16 dwords mod 64: the 4 pixel rows of a transposing
+  static constexpr int YRB = KF == 32 ? 64 : 192;    // read land on disjoint banks (C = 64: 128 data + 64 pad bytes)
+  static constexpr int XS = 180 * XRB, YS = 128 * YRB;
+  static constexpr int LDS = XS + YS;
+  static constexpr int KT = KF / 32, CT = CI / 32;
+  static constexpr int NU = KT * CT * 9;             // 32 x 32 accumulator units (tap, k-tile, c-tile)
+  static constexpr int UPW = (NU + 3) / 4;           // per wave
+  static constexpr int NVX = 180 * (CI / 8), NVY = 128 * (KF / 8);
+  static constexpr int HPX = (NVX + 255) / 256, HPY = NVY / 256;
+};
+
+template <int KF, int CI>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
+  using W = WHalo<KF, CI>;
+  constexpr int XRB = W::XRB, YRB = W::YRB, CPX = CI / 8, CPY = KF / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xs = smem;
+  unsigned char* ys = smem + W::XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const int n_m = p.M >> 7;
+  int t_begin, t_end, logical;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous runs of patches
+    const int per = n_m / nb, extra = n_m - per * nb;
+    t_begin = logical * per + (logical < extra ? logical : extra);
+    t_end = t_begin + per + (logical < extra ? 1 : 0);
+  }
+  const int tiles_x = p.Wi >> 4, tpi = tiles_x * (p.Hi >> 3);
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+
+  u32x4 hx[W::HPX], hy[W::HPY];
+  auto load_patch = [&](int tile) {
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 16;
+#pragma unroll
+    for (int k = 0; k < W::HPX; ++k) {
+      const int i = k * 256 + tid;
+      const int hp = i / CPX, ck = i - hp * CPX;
+      const int hyy = hp / 18, hxx = hp - hyy * 18;
+      const int gy = y0 - 1 + hyy, gx = x0 - 1 + hxx;
+      const bool ok = (i < W::NVX) && ((unsigned)gy < (unsigned)p.Hi) && ((unsigned)gx < (unsigned)p.Wi);
+      const unsigned off = (((unsigned)img * (unsigned)p.Hi + (unsigned)gy) * (unsigned)p.Wi + (unsigned)gx) * (unsigned)p.Ci * 2u +
+                           (unsigned)ck * 16u;
+      hx[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : ASM_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < W::HPY; ++k) {
+      const int i = k * 256 + tid;
+      const int row = i / CPY, ck = i - row * CPY;
+      const unsigned m = ((unsigned)img * (unsigned)p.Hi + (unsigned)(y0 + (row >> 4))) * (unsigned)p.Wi + (unsigned)(x0 + (row & 15));
+      hy[k] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (m * (unsigned)p.ldy + (unsigned)ck * 8u) * 2u, 0, 0);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int k = 0; k < W::HPX; ++k) {
+      const int i = k * 256 + tid;
+      const int hp = i / CPX, ck = i - hp * CPX;
+      if (i < W::NVX) *reinterpret_cast<u32x4*>(xs + hp * XRB + ck * 16) = hx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < W::HPY; ++k) {
+      const int i = k * 256 + tid;
+      const int row = i / CPY, ck = i - row * CPY;
+      *reinterpret_cast<u32x4*>(ys + row * YRB + ck * 16) = hy[k];
+    }
+  };
+
+  f32x16 acc[W::UPW];
+#pragma unroll
+  for (int i = 0; i < W::UPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // transposing-read lane geometry (see wgrad_kernel): lane l of a 32x32x16 operand = channel l & 31, pixels (l >> 5) * 8 ..
+  const int t16 = lane & 15, g = lane >> 4;
+  const int chan = (g & 1) * 16 + (t16 & 3) * 4;    // first of this lane's 4 source channels within a 32-channel tile
+  const int prow = (g >> 1) * 8 + (t16 >> 2);       // source pixel within the 16-pixel patch row (second read: + 4)
+
+  if (t_begin < t_end) load_patch(t_begin);
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                    // every wave is done with the previous patch
+    store_patch();
+    __syncthreads();
+    if (tile + 1 < t_end) load_patch(tile + 1);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {    // patch row kk = 16 reduction pixels
+      bf16x8 fy[W::KT];
+#pragma unroll
+      for (int kt = 0; kt < W::KT; ++kt) {
+        const unsigned char* a = ys + (kk * 16 + prow) * YRB + (kt * 32 + chan) * 2;
+        const bf16x4 y0 = ds_read_tr(a), y1 = ds_read_tr(a + 4 * YRB);
+        fy[kt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < W::UPW; ++i) {
+        const int u = wave + 4 * i;                 // wave-uniform
+        if (u < W::NU) {
+          const int t = u / (W::KT * W::CT), rem = u - t * (W::KT * W::CT);
+          const int kt = rem / W::CT, ct = rem - kt * W::CT;
+          const int r = t / 3, q = t - r * 3;
+          const unsigned char* b = xs + ((kk + r) * 18 + q + prow) * XRB + (ct * 32 + chan) * 2;
+          const bf16x4 x0 = ds_read_tr(b), x1 = ds_read_tr(b + 4 * XRB);
+          const bf16x8 fx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 fa = (W::KT == 1 || kt == 0) ? fy[0] : fy[W::KT - 1];   // static register indices only
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fx, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // this workgroup's partial dW: slab [logical][KF][9 * CI]
+  const int cols = 9 * CI;
+  float* out = p.out + (size_t)logical * KF * cols;
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < W::UPW; ++i) {
+    const int u = wave + 4 * i;
+    if (u < W::NU) {
+      const int t = u / (W::KT * W::CT), rem = u - t * (W::KT * W::CT);
+      const int kt = rem / W::CT, ct = rem - kt * W::CT;
+      const int col = t * CI + ct * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        out[(size_t)n * cols + col] = acc[i][r];
+      }
+    }
+  }
+}
+
+// workgroups of the persistent halo form for this layer, or 0 if it does not apply
+int wgrad_halo_blocks(const asm_conv_desc* d) {
+  const int mode = asm_env_int("ASM_WGRAD_HALO", 1);     // 0 off, 1 on for the large maps, 2 whenever the shape allows (tests)
+  if (!mode) return 0;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
+  if (d->H % 8 || d->W % 16 || d->x_img_pitch || d->x_row_pitch || d->x_pix_pitch) return 0;
+  if (!((d->C == 32 || d->C == 64) && (d->K == 32 || d->K == 64))) return 0;
+  const int n_m = d->N * (d->H / 8) * (d->W / 16);
+  if (mode != 2 && n_m < 512) return 0;   // a slab per workgroup only pays on the large maps
+  return n_m < 512 ? n_m : 512;           // 2 workgroups per CU
+}
+
 struct Plan {
   int bnw, bcw, tiles_n, tiles_c, splits, m_per_split;
 };
@@ -362,6 +520,7 @@ Plan make_plan(const asm_conv_desc* d) {
 
 extern "C" size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d) {
   if (!d) return 0;
+  if (const int hb = wgrad_halo_blocks(d)) return (size_t)hb * d->K * 9 * d->C * sizeof(float);
   Plan pl = make_plan(d);
   if (pl.splits <= 1) return 0;
   return (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float);
@@ -369,6 +528,11 @@ extern "C" size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d) {
 
 extern "C" int asm_conv2d_wgrad_plan(const asm_conv_desc* d, int32_t plan[6]) {
   ASM_REQUIRE(d && plan, "conv wgrad plan: null pointer");
+  if (const int hb = wgrad_halo_blocks(d)) {      // persistent halo form: {K, -1, 1, 1, workgroups, pixels per workgroup}
+    plan[0] = d->K; plan[1] = -1; plan[2] = 1; plan[3] = 1; plan[4] = hb;
+    plan[5] = (d->N * d->H * d->W + hb - 1) / hb;
+    return ASM_OK;
+  }
   const Plan pl = make_plan(d);
   plan[0] = pl.bnw; plan[1] = pl.bcw; plan[2] = pl.tiles_n; plan[3] = pl.tiles_c; plan[4] = pl.splits;
   plan[5] = pl.m_per_split;
@@ -390,6 +554,31 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   const size_t need = asm_conv2d_wgrad_workspace_bytes(d);
   ASM_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "conv wgrad: workspace too small (%zu < %zu)",
               workspace_bytes, need);
+  if (const int hb = wgrad_halo_blocks(d)) {
+    WgradArgs h;
+    h.dy = dy; h.x = x; h.out = reinterpret_cast<float*>(workspace);
+    h.dy_bytes = (unsigned)(dyelems * 2); h.x_bytes = (unsigned)(xelems * 2);
+    h.M = d->N * d->H * d->W; h.Hi = d->H; h.Wi = d->W; h.Ci = d->C; h.Co = d->K; h.ldy = ldy;
+    h.R = 3; h.S = 3; h.so = 1; h.pad = 1;
+    h.x_img_pitch = d->H * d->W * d->C; h.x_row_pitch = d->W * d->C; h.x_pix_pitch = d->C;
+    h.cols = 9 * d->C; h.tiles_n = h.tiles_c = 1; h.splits = hb; h.m_per_split = 0;
+    h.HoWo = d->H * d->W; h.Wo = d->W;
+    h.fd_howo = make_fastdiv((unsigned)h.HoWo); h.fd_wo = make_fastdiv((unsigned)h.Wo);
+    hipStream_t hs = (hipStream_t)stream;
+#define LAUNCH_WH(KF, CI)                                                                                        \
+    hipLaunchKernelGGL((wgrad_halo_kernel<KF, CI>), dim3(hb), dim3(256), (WHalo<KF, CI>::LDS), hs, h)
+    if (d->K == 32 && d->C == 64) LAUNCH_WH(32, 64);
+    else if (d->K == 64 && d->C == 32) LAUNCH_WH(64, 32);
+    else if (d->K == 32 && d->C == 32) LAUNCH_WH(32, 32);
+    else LAUNCH_WH(64, 64);
+#undef LAUNCH_WH
+    ASM_CHECK_LAUNCH("wgrad_halo_kernel");
+    const size_t n = (size_t)d->K * 9 * d->C;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 128)), dim3(256), 0, hs,
+                       reinterpret_cast<const float*>(workspace), dw, n, hb);
+    ASM_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return ASM_OK;
+  }
   WgradArgs a;
   a.dy = dy; a.x = x;
   a.out = pl.splits > 1 ? reinterpret_cast<float*>(workspace) : dw;

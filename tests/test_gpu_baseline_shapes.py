@@ -276,3 +276,34 @@ def test_igemm_variants_are_per_call_knobs(hip_lib, v2, parity, monkeypatch):
   assert hip_lib.asm_conv2d_dgrad_naive(C.byref(d), dy.data_ptr(), w.data_ptr(), dxn.data_ptr(), st) == 0
   assert util.rel_l2(out.float(), dxn.float()) <= 3e-3
   assert util.rel_l2(out.float(), ref.float()) <= 2e-3
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32, 64, 32), (3, 8, 16, 32, 64), (1, 24, 48, 32, 32), (2, 16, 16, 64, 64),
+                                   (8, 112, 112, 64, 32)], ids=lambda s: 'x'.join(map(str, s)))
+def test_wgrad_halo_kernel_forced_vs_oracle(hip_lib, shape, monkeypatch):
+  """wgrad_halo_kernel (persistent, halo-resident, all nine taps per patch) on small shapes and on an 8-image slice of
+  its own layer: against the oracle's autograd and bit-reproducible."""
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  monkeypatch.setenv('ASM_WGRAD_HALO', '2')
+  N, H, W, Cn, K = shape
+  g = torch.Generator().manual_seed(43)
+  x = torch.randn((N, H, W, Cn), generator=g).to(BF)
+  dy = torch.randn((N, H, W, K), generator=g).to(BF)
+  d = ops.make_conv_desc(N, H, W, Cn, K, 3, 3, 1)
+  plan = _plan(hip_lib, d)
+  assert plan[1] == -1, 'the halo form should be selected: %s' % plan
+  dw = torch.empty((K, 3, 3, Cn), dtype=torch.float32, device='cuda')
+  ops.conv_wgrad(d, x.cuda(), dy.cuda(), dw)
+  wr = torch.zeros((K, 3, 3, Cn), requires_grad=True)
+  yr = O._conv_raw(x.float().permute(0, 3, 1, 2), wr.permute(1, 2, 3, 0), 3, 1)
+  (gw,) = torch.autograd.grad(yr, [wr], dy.float().permute(0, 3, 1, 2))
+  r = util.rel_l2(dw.cpu(), gw)
+  assert r <= 2e-3, 'wgrad_halo rel_l2 %.3e (plan %s)' % (r, plan)
+  dw1 = torch.empty_like(dw)
+  ops.conv_wgrad(d, x.cuda(), dy.cuda(), dw1)
+  assert torch.equal(dw, dw1)
+  monkeypatch.setenv('ASM_WGRAD_HALO', '0')
+  dw0 = torch.empty_like(dw)
+  ops.conv_wgrad(d, x.cuda(), dy.cuda(), dw0)
+  assert _plan(hip_lib, d)[1] != -1 and util.rel_l2(dw, dw0) <= 1e-4
