@@ -36,7 +36,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
-PMC_FILE = 'round1_pmc_traffic.json'
+PMC_FILE = 'round2_pmc_traffic.json'
 HBM_PEAK_GBS = 8000.0            # spec; MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {

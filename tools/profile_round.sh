@@ -2,6 +2,7 @@
 # usage (on the GPU box, from the repo root): tools/profile_round.sh TAG [stats|traffic|sq ...]
 #   stats    rocprofv3 --kernel-trace --stats of bench.py (3 warm-up + 5 timed steps) -> gpurun_out/TAG_kernel_stats.md
 #   traffic  two --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain) -> gpurun_out/TAG_step_hbm_traffic.md
+#   dominant FETCH_SIZE / WRITE_SIZE of the layer bench.py's roofline object names -> gpurun_out/TAG_pmc_traffic.json
 #   sq       one --pmc pass of SQ occupancy / MFMA-busy counters -> gpurun_out/TAG_sq_counters.txt
 TAG=$1; shift
 WHAT="${*:-stats}"
@@ -21,6 +22,12 @@ for w in $WHAT; do
         rocprofv3 --pmc $c -d $REPO/gpurun_out/pmc_${TAG}_$c -o p --output-format csv -- $BENCH --steps 2 --warmup 1 > $REPO/gpurun_out/pmc_${TAG}_$c.log 2>&1
       done
       python $REPO/tools/pmc_traffic_step.py $REPO/gpurun_out/pmc_${TAG}_FETCH_SIZE $REPO/gpurun_out/pmc_${TAG}_WRITE_SIZE 3 > $REPO/gpurun_out/${TAG}_step_hbm_traffic.md
+      ;;
+    dominant)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rocprofv3 --pmc $c -d $REPO/gpurun_out/pmcd_${TAG}_$c -o p --output-format csv -- python $REPO/tools/conv_bench.py --only C512-K1024-3x3-H14 --kinds fprop,dgrad,wgrad --iters 2 > $REPO/gpurun_out/pmcd_${TAG}_$c.log 2>&1
+      done
+      python $REPO/tools/pmc_dominant.py $REPO/gpurun_out/pmcd_${TAG}_FETCH_SIZE $REPO/gpurun_out/pmcd_${TAG}_WRITE_SIZE $REPO/gpurun_out/${TAG}_pmc_traffic.json > /dev/null
       ;;
     sq)
       rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
