@@ -100,6 +100,7 @@ class Model(object):
     self.ldc = nn._round_up(num_classes, 8) if num_classes else 0
     self._ctx: Optional[Ctx] = None
     self._db_rng = None
+    self._bl_stream = None
 
   # -----------------------------------------------------------------------------------------------
   def build(self, input_hw=(224, 224), use_resnet_d=False, batch=2):
@@ -164,6 +165,16 @@ class Model(object):
     self.arena.join_side_stream()
 
   # -----------------------------------------------------------------------------------------------
+  def _branch_stream(self, ctx: Ctx, x: Var):
+    """second HIP stream for the big branch of a BigLittle stage (forward pass), or None"""
+    if ctx.dry or x.data is None or not x.data.is_cuda or os.environ.get('ASM_BL_STREAMS', '1') == '0':
+      return None
+    if getattr(ctx, 'keep_prob', 1.0) < 1.0:
+      return None          # DropBlock draws come from one generator in creation order
+    if self._bl_stream is None:
+      self._bl_stream = torch.cuda.Stream(device=x.data.device)
+    return self._bl_stream
+
   def _bottleneck(self, ctx: Ctx, x: Var, filters, projection, strides, zero_gamma, aa_size, aa_type,
                   last_relu=True, expansion=4, db_gamma_scale=None) -> Var:
     """_bottleneck_block_v1 (nets/resnet_model.py:35-97).  db_gamma_scale: DropBlock gamma multiplier of this
@@ -331,8 +342,20 @@ class Model(object):
       if v2 and i < 3:                                    # :455-516
         ctx.push_scope('stage{}'.format(i + 1))
         ctx.push_scope('big{}'.format(i + 1))
-        big = self._block_layer(ctx, x, num_filters, num_blocks - 1, 2, 'big{}'.format(i + 1),
-                                use_bl=True, last_relu=False, db_gamma_scale=dbs)
+        # The big branch (half resolution: small-M, deep-K tiles that leave CUs idle) and the little branch (full
+        # resolution, bandwidth-bound) are independent until the merge: in the FORWARD pass the big branch is
+        # enqueued on a second HIP stream so the two fill each other's gaps.  Both directions are fenced by
+        # stream waits, so every cross-stream tensor is produced before it is read and the caching allocator
+        # only ever recycles a block inside the stream that owns it.  ASM_BL_STREAMS=0 keeps one stream.
+        side = self._branch_stream(ctx, x)
+        if side is not None:
+          side.wait_stream(torch.cuda.current_stream())
+          with torch.cuda.stream(side):
+            big = self._block_layer(ctx, x, num_filters, num_blocks - 1, 2, 'big{}'.format(i + 1),
+                                    use_bl=True, last_relu=False, db_gamma_scale=dbs)
+        else:
+          big = self._block_layer(ctx, x, num_filters, num_blocks - 1, 2, 'big{}'.format(i + 1),
+                                  use_bl=True, last_relu=False, db_gamma_scale=dbs)
         ctx.pop_scope()
         ctx.push_scope('little{}'.format(i + 1))
         little = self._block_layer(ctx, x, num_filters // self.alpha, max(1, num_blocks // self.beta - 1), 1,
@@ -341,6 +364,8 @@ class Model(object):
         ce = L(lambda: ConvKernel(ctx, 1, cin_l, num_filters * 4))
         be = L(lambda: BatchNorm(ctx, num_filters * 4))
         ctx.pop_scope()
+        if side is not None:
+          torch.cuda.current_stream().wait_stream(side)
         # relu(BN(little_e) + UpSampling2D(big)) :493-501
         x = conv_bn(ctx, little, ce, be, 1, relu=True, residual=big, res_mode=2)
         ctx.push_scope('merge{}'.format(i + 1))
