@@ -209,6 +209,9 @@ def main():
   ap.add_argument('--workload', default='assemble-r50', choices=sorted(WORKLOADS))
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-roofline', action='store_true')
+  ap.add_argument('--overlap', action='store_true',
+                  help='time the step with the weight-gradient / BigLittle side streams on (the product default); '
+                       'without it the timed region is single-stream and the overlapped rate is reported as an extra')
   ap.add_argument('--dump-convs', default='', help='write the per-conv-shape HIP-event times of the instrumented step here (markdown)')
   args = ap.parse_args()
 
@@ -232,6 +235,13 @@ def main():
     dist.init_process_group('nccl', rank=rank, world_size=world)
     dist.barrier()
 
+  # The timed region runs every kernel on ONE stream: per-kernel HIP-event durations (the `roofline` and `step` objects)
+  # and the rocprofv3 summaries under profiles/ are then properties of the kernels.  With the side streams on (weight
+  # gradients beside the dgrad chain, the big branch of a BigLittle stage beside the little one) kernels share the CUs and
+  # their individual durations depend on what happens to run next to them; that rate is reported as `overlap`.
+  if not args.overlap:
+    os.environ['ASM_WGRAD_STREAM'] = '0'
+    os.environ['ASM_BL_STREAMS'] = '0'
   from assembled_cnn_amd import dp, ops
   from assembled_cnn_amd.train import HParams, Trainer
   wl = WORKLOADS[args.workload]
@@ -312,6 +322,26 @@ def main():
           by = 2.0 * N_ * (H_ * W_ * C_ + Ho_ * Ho_ * K_) * n
           f.write('| %s | %d %dx%dx%d -> %d, %dx%d/%d | %d | %.4f | %.0f | %.0f |\n' % (
               kind, N_, H_, W_, C_, K_, R_, S_, st_, n, ms, conv_flops(k) * n / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9))
+  overlap = None
+  if not args.overlap and not args.no_roofline:   # the same steps with the side streams on (product default)
+    os.environ['ASM_BL_STREAMS'] = '1'
+    if world == 1:
+      tr.model.arena.enable_side_stream()
+    for _ in range(2):
+      step()
+    sync()
+    t1 = time.time()
+    for _ in range(args.steps):
+      step()
+    sync()
+    el2 = time.time() - t1
+    if world > 1:
+      t = torch.tensor([el2], device=dev, dtype=torch.float64)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      el2 = float(t)
+    overlap = {'value': round(B * world * args.steps / el2, 2), 'ms_per_step': round(1000.0 * el2 / args.steps, 3),
+               'what': 'the same %d steps with weight gradients%s on a second HIP stream' % (
+                   args.steps, ' and the big branch of each BigLittle stage' if world == 1 else ' off (GradSync) but the big branch of each BigLittle stage')}
   loss = float(tr.cross_entropy())
   if not (loss == loss) or loss > 50:
     raise SystemExit('training diverged (loss=%r): the number would be invalid' % loss)
@@ -370,6 +400,9 @@ def main():
       out['step'] = st_obj
     except Exception as e:   # reporting extras must never lose the measured number
       out['step'] = {'error': repr(e)}
+    out['streams'] = 'overlapped (weight-gradient + BigLittle side streams)' if args.overlap else 'single'
+    if overlap is not None:
+      out['overlap'] = overlap
     if world == 1 and not args.no_cpu_baseline:
       try:
         out['cpu_baseline'] = cpu_baseline(args.workload)
