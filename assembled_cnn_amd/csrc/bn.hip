@@ -137,50 +137,71 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
 // block = 16 channels x FL partial-lanes.  These kernels are pure latency (one per BN layer and direction, ~200 per
 // step): 64 lanes keep the dependent trip count at <= 4 for the <= 512 partial rows the reducers emit.
 constexpr int FL = 64;
+// Rows b0 + lane, b0 + lane + nl, ... < b1 of the [blocks][2][C] partials for channel ch, summed in fp64.  SU row pairs
+// (2 * SU loads) are issued before any is consumed: the serial form was a chain of dependent L2 / HBM round trips -- ~5-6 us
+// per finalize launch, ~190 such launches per training step.  The summation order is fixed (bit-reproducible).
+constexpr int SU = 8;
+__device__ __forceinline__ void sum_rows(const float* __restrict__ partial, int b0, int b1, int lane, int nl, int C, int ch,
+                                         double& s0, double& s1) {
+  double a[SU], c[SU];
+#pragma unroll
+  for (int u = 0; u < SU; ++u) a[u] = c[u] = 0.0;
+  int b = b0 + lane;
+  for (; b + (SU - 1) * nl < b1; b += SU * nl) {
+    float v0[SU], v1[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      v0[u] = partial[((size_t)(b + u * nl) * 2 + 0) * C + ch];
+      v1[u] = partial[((size_t)(b + u * nl) * 2 + 1) * C + ch];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      a[u] += (double)v0[u];
+      c[u] += (double)v1[u];
+    }
+  }
+  {   // tail: up to SU - 1 rows, still issued together
+    float v0[SU], v1[SU];
+#pragma unroll
+    for (int u = 0; u < SU - 1; ++u) {
+      const bool ok = b + u * nl < b1;
+      v0[u] = ok ? partial[((size_t)(b + u * nl) * 2 + 0) * C + ch] : 0.f;
+      v1[u] = ok ? partial[((size_t)(b + u * nl) * 2 + 1) * C + ch] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SU - 1; ++u) {
+      a[u] += (double)v0[u];
+      c[u] += (double)v1[u];
+    }
+  }
+  s0 = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  s1 = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+}
 __device__ __forceinline__ void sum_partials(const float* partial, int blocks, int C, int ch, int ry,
                                              double& s0, double& s1) {
   s0 = 0.0;
   s1 = 0.0;
-  if (ch < C) {
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-    int b = ry;
-    for (; b + FL < blocks; b += 2 * FL) {   // two independent chains: loads overlap
-      a0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
-      b0 += (double)partial[((size_t)b * 2 + 1) * C + ch];
-      a1 += (double)partial[((size_t)(b + FL) * 2 + 0) * C + ch];
-      b1 += (double)partial[((size_t)(b + FL) * 2 + 1) * C + ch];
-    }
-    if (b < blocks) {
-      a0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
-      b0 += (double)partial[((size_t)b * 2 + 1) * C + ch];
-    }
-    s0 = a0 + a1;
-    s1 = b0 + b1;
-  }
+  if (ch < C) sum_rows(partial, 0, blocks, ry, FL, C, ch, s0, s1);
 }
 
 // partial compaction: [blocks][2][C] -> [groups][2][C]; each output group sums a contiguous range of
 // input blocks (fp64 accumulate).  Keeps the finalize kernels short when a conv epilogue emitted
 // thousands of 128-row partials (25088 for the 112x112 stem at batch 256).
-__global__ __launch_bounds__(256) void partials_compact_kernel(const float* __restrict__ in, int blocks, int C,
-                                                               float* __restrict__ out, int per_group) {
-  __shared__ double red[2][16][16];
+__global__ __launch_bounds__(16 * FL) void partials_compact_kernel(const float* __restrict__ in, int blocks, int C,
+                                                                   float* __restrict__ out, int per_group) {
+  __shared__ double red[2][FL][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cx;
   const int b0 = blockIdx.y * per_group;
   const int b1 = min(blocks, b0 + per_group);
   double s0 = 0.0, s1 = 0.0;
-  if (ch < C)
-    for (int b = b0 + ry; b < b1; b += 16) {
-      s0 += (double)in[((size_t)b * 2 + 0) * C + ch];
-      s1 += (double)in[((size_t)b * 2 + 1) * C + ch];
-    }
+  if (ch < C) sum_rows(in, b0, b1, ry, FL, C, ch, s0, s1);
   red[0][ry][cx] = s0;
   red[1][ry][cx] = s1;
   __syncthreads();
   if (ry < 2 && ch < C) {
     double t = 0.0;
-    for (int r = 0; r < 16; ++r) t += red[ry][r][cx];
+    for (int r = 0; r < FL; ++r) t += red[ry][r][cx];
     out[((size_t)blockIdx.y * 2 + ry) * C + ch] = (float)t;
   }
 }
@@ -574,7 +595,7 @@ extern "C" int asm_bn_partials_compact(const float* partial, int blocks, int C, 
   ASM_REQUIRE(partial && out && blocks > 0 && C > 0 && groups > 0 && groups <= blocks, "bn_partials_compact: bad arguments");
   const int per_group = cdiv(blocks, groups);
   ASM_REQUIRE(cdiv(blocks, per_group) == groups, "bn_partials_compact: groups=%d does not tile blocks=%d", groups, blocks);
-  hipLaunchKernelGGL(partials_compact_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(partials_compact_kernel, dim3(cdiv(C, 16), groups), dim3(16 * FL), 0, (hipStream_t)stream, partial,
                      blocks, C, out, per_group);
   ASM_CHECK_LAUNCH("bn_partials_compact");
   return ASM_OK;

@@ -140,6 +140,10 @@ SIGNATURES = {
     'asm_bn_small_max_rows': (_I, []),
     'asm_bn_small_fwd': (_I, [_P, _P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _P]),
     'asm_bn_small_bwd': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'asm_dense_bn_max_rows': (_I, []),
+    'asm_dense_small': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
+    'asm_dense_bn_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'asm_dense_dgrad_bn_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_resize_crop_flip': (_I, [_P, C.c_int64, _P, _I, _I, _I, _I, _P, _P]),
     'asm_model_plan': (_I, [C.POINTER(ModelCfg), _I, _I, _I, C.POINTER(PlanEntry), _I, C.POINTER(PlanSummary)]),
 }

@@ -229,7 +229,7 @@ class Var(object):
   that dominate (the input gradient of the next 1x1 convolution, which adds it in its epilogue, and the batch-norm
   backward of a projection shortcut) read (dy, mask) directly, so dz is never written; anything else just reads
   ``.grad``, which materialises it."""
-  __slots__ = ('data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad')
+  __slots__ = ('data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'fuse_dgrad', 'pending')
 
   def __init__(self, data, shape=None, needs_grad=True):
     self.data = data
@@ -238,6 +238,11 @@ class Var(object):
     self.grad_mask = None
     self.grad_owned = False
     self.needs_grad = needs_grad
+    # squeeze-layer fusion (csrc/dense_small.hip): the output of a fused dense + batch-norm layer may receive its gradient
+    # as a PENDING input gradient (dy, CRSK weights, descriptor of its one consumer), which the batch-norm backward then
+    # computes inside its own launch
+    self.fuse_dgrad = False
+    self.pending = None
 
   @property
   def grad(self):
@@ -428,10 +433,8 @@ class ConvKernel(object):
       ops.conv_wgrad(d, x, dy, a.g(self.name))
     a.notify_grad(self.name)
 
-  def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool,
-               addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None
-               ) -> Optional[torch.Tensor]:
-    """dW into the gradient arena; returns dx [+ addend [where addend_mask]] (or None)."""
+  def wgrad_streamed(self, d, x: torch.Tensor, dy: torch.Tensor):
+    """dW into the gradient arena, on the weight-gradient side stream when there is one"""
     a = self.arena
     side = a.side_stream if a.on_grad is None else None
     if side is not None:
@@ -442,6 +445,13 @@ class ConvKernel(object):
       dy.record_stream(side)
     else:
       self._wgrad(d, x, dy)
+
+  def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool,
+               addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None
+               ) -> Optional[torch.Tensor]:
+    """dW into the gradient arena; returns dx [+ addend [where addend_mask]] (or None)."""
+    a = self.arena
+    self.wgrad_streamed(d, x, dy)
     if self.stem:
       return None
     if not need_dx:
@@ -496,7 +506,12 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
   # [N, 1, 1, d] squeeze layers (SK / SE fc): the whole BN is one launch per direction instead of 3-4 latency-bound ones
   small = ctx.training and residual is None and d.Ho * d.Wo == 1 and not conv.stem and ops.bn_small_ok(M)
   mask_t = None
-  if small:
+  # ... and when the layer is a plain dense product over <= 256 rows, the product itself joins that launch
+  dense = small and conv.k == 1 and d.H == 1 and d.W == 1 and ops.dense_bn_ok(M, conv.cin, Cn)
+  if dense:
+    y, out_t, mask_t, mean, invstd = ops.dense_bn_fwd(d, x.data, conv.weight(), gamma, beta, BN_EPS, ctx.bn_momentum,
+                                                      a.st(bn.mm), a.st(bn.mv), relu, want_mask=taped)
+  elif small:
     y, _ = conv.fprop(d, x.data, False)
     out_t, mask_t, mean, invstd = ops.bn_small_fwd(y, M, Cn, gamma, beta, BN_EPS, ctx.bn_momentum, a.st(bn.mm),
                                                    a.st(bn.mv), relu, want_mask=taped)
@@ -521,11 +536,22 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
   else:
     out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, rm, relu, d.Ho, d.Wo), None
   out = Var(out_t)
+  out.fuse_dgrad = dense and taped
 
   if ctx.tape is not None:
     x_t = x.data
 
     def bwd():
+      if out.pending is not None:     # fused squeeze layer: (input gradient of the one consumer) + this BN's backward, one launch
+        d_next, dy_next, wt_next = out.pending
+        out.pending = None
+        dy = ops.dense_dgrad_bn_bwd(d_next, dy_next, wt_next, y, mask_t if relu else None, gamma, mean, invstd,
+                                    a.g(bn.gamma), a.g(bn.beta))
+        a.notify_grad(bn.gamma)
+        dx = conv.backward(d, x_t, dy, x.needs_grad, addend=x.grad)
+        if dx is not None:
+          x.grad, x.grad_owned = dx, True
+        return
       # the incoming gradient may be lazily masked by the ReLU of the block this layer's output was the shortcut of:
       # a BN without its own ReLU takes that mask as if it were its own (dz = dout * mask is exactly what it needs)
       dout, in_mask = out.take_masked_grad()
@@ -576,6 +602,13 @@ def conv_plain(ctx: Ctx, x: Var, conv: ConvKernel, out_f32: bool, ldy: int = 0):
     # the backward descriptor is always a bf16 one; dy's row stride is ldy when the logits were padded
     dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo,
                             ldy=ldy if (ldy and ldy != conv.cout) else 0)
+    if (x.fuse_dgrad and x.needs_grad and x._grad is None and conv.need_dgrad and conv.kpad == conv.cout and not dd.ldy
+        and conv.cout % 16 == 0 and ops.dense_small_on()):
+      # x is the output of a fused dense + batch-norm layer and this is its only consumer: hand the input gradient over
+      # un-computed; that layer's batch-norm backward evaluates it inside its own launch (csrc/dense_small.hip)
+      conv.wgrad_streamed(dd, x_t, dy)
+      x.pending = (dd, dy, conv.arena.wt_view(conv._wts))
+      return
     dx = conv.backward(dd, x_t, dy, x.needs_grad, addend=x.grad)
     if dx is not None:
       x.grad, x.grad_owned = dx, True

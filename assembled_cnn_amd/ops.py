@@ -8,6 +8,7 @@ in this package without a GPU; the double lives under tests/ and is never used b
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -138,6 +139,59 @@ def _bn_ev(nbytes):
   return _TIMER.start_class('bn', nbytes) if (_TIMER is not None and _TIMER.classes) else None
 
 
+def dense_small_on() -> bool:
+  """ASM_DENSE_SMALL=0 keeps the [N,1,1,C] layers on the implicit-GEMM convolution (A/B runs, tests); read per call."""
+  return os.environ.get('ASM_DENSE_SMALL', '1') != '0'
+
+
+def _is_dense(d: ConvDesc) -> bool:
+  return (d.H == 1 and d.W == 1 and d.Ho == 1 and d.Wo == 1 and d.R == 1 and d.S == 1 and d.x_img_pitch in (0, d.C)
+          and d.x_row_pitch in (0, d.C) and d.x_pix_pitch in (0, d.C) and d.C % 8 == 0)
+
+
+_DENSE_BN_ROWS = None
+
+
+def dense_bn_ok(M: int, K: int, N: int) -> bool:
+  """fc + training-mode batch norm (and its backward twin) in one launch: every row of 32 channels in one workgroup"""
+  global _DENSE_BN_ROWS
+  if not dense_small_on():
+    return False
+  if _DENSE_BN_ROWS is None:
+    _DENSE_BN_ROWS = int(L().asm_dense_bn_max_rows())
+  return M <= _DENSE_BN_ROWS and K % 16 == 0 and N % 8 == 0
+
+
+def dense_bn_fwd(d: ConvDesc, x, w, gamma, beta, eps, momentum, mm, mv, relu, want_mask):
+  """[N,1,1,C] -> 1x1 conv -> training-mode BN [-> ReLU] in ONE launch -> (ypre, z, mask or None, mean, invstd)"""
+  M, K, N = d.N, d.C, d.K
+  ypre = empty((M, 1, 1, N), BF16, x)
+  z = empty((M, 1, 1, N), BF16, x)
+  co = empty((2, N), F32, x)
+  mask = empty((M, N // 8), torch.uint8, x) if (want_mask and relu) else None
+  ev = _TIMER.start('fprop', d) if _TIMER is not None else None
+  check(L().asm_dense_bn_fwd(_ptr(x), K, _ptr(w), K, M, K, N, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(mm), _ptr(mv),
+                             _ptr(ypre), _ptr(z), _ptr(co[0]), _ptr(co[1]), 1 if relu else 0, _ptr(mask), _stream()),
+        'dense_bn_fwd')
+  if ev is not None:
+    ev.record()
+  return ypre, z, mask, co[0], co[1]
+
+
+def dense_dgrad_bn_bwd(d_next: ConvDesc, dy_next, wt_next, ypre, mask, gamma, mean, invstd, dgamma, dbeta):
+  """input gradient of the NEXT 1x1 layer (dy_next [M][K], wt_next = its CRSK copy [N][K]) + the backward of the batch
+  norm that produced that layer's input (ypre [M][N], mask) in ONE launch -> dx [M,1,1,N]"""
+  M, K, N = d_next.N, d_next.K, d_next.C
+  dx = torch.empty_like(ypre)
+  ev = _TIMER.start('dgrad', d_next) if _TIMER is not None else None
+  check(L().asm_dense_dgrad_bn_bwd(_ptr(dy_next), K, _ptr(wt_next), K, M, K, N, _ptr(ypre), _ptr(mask), _ptr(gamma),
+                                   _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dx), _stream()),
+        'dense_dgrad_bn_bwd')
+  if ev is not None:
+    ev.record()
+  return dx
+
+
 def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool = False
                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
   """y [N,Ho,Wo,ldy] (bf16 or f32) and, if want_stats, the BN partials [blocks,2,K] (f32)."""
@@ -147,7 +201,12 @@ def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool =
   if want_stats:
     stats = empty((L().asm_conv2d_stats_blocks(C.byref(d)), 2, d.K), F32, x)
   ev = _TIMER.start('fprop', d) if _TIMER is not None else None
-  check(L().asm_conv2d_fprop(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(stats), _stream()), 'conv2d_fprop')
+  if not want_stats and _is_dense(d) and d.C % 16 == 0 and dense_small_on():
+    # [N,1,1,C] squeeze / excite / classifier layer: row-major product, no implicit-GEMM machinery (csrc/dense_small.hip)
+    check(L().asm_dense_small(_ptr(x), d.C, _ptr(w), d.C, d.N, d.K, d.C, _ptr(y), ldy, 1 if d.out_f32 else 0, None,
+                              _stream()), 'dense_small')
+  else:
+    check(L().asm_conv2d_fprop(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(stats), _stream()), 'conv2d_fprop')
   if ev is not None:
     ev.record()
   return y, stats
@@ -169,7 +228,11 @@ def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional
   """dx = conv_transpose(dy, w) [+ addend [where addend_mask]]"""
   dx = empty((d.N, d.H, d.W, d.C), BF16, dy)
   ev = _TIMER.start('dgrad', d) if _TIMER is not None else None
-  if addend_mask is not None:
+  if addend_mask is None and _is_dense(d) and d.K % 16 == 0 and dense_small_on():
+    # dy [N][K] (row stride K: a padded Cout arrives as K = kpad), wt = CRSK copy [C][K]
+    check(L().asm_dense_small(_ptr(dy), d.K, _ptr(wt), d.K, d.N, d.C, d.K, _ptr(dx), d.C, 0, _ptr(addend), _stream()),
+          'dense_small')
+  elif addend_mask is not None:
     check(L().asm_conv2d_dgrad_masked(C.byref(d), _ptr(dy), _ptr(wt), _ptr(addend), _ptr(addend_mask), _ptr(dx),
                                       _stream()), 'conv2d_dgrad_masked')
   else:

@@ -176,6 +176,31 @@ int asm_bn_small_fwd(const void* x, void* y, int M, int C, const float* gamma, c
 int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* relu_mask, int M, int C, const float* gamma,
                      const float* mean, const float* invstd, float* dgamma, float* dbeta, void* dx, void* stream);
 
+/* Small dense layers (csrc/dense_small.hip): the [N,1,1,C] squeeze / excite / classifier layers -- sk_fc_1 / sk_fc_2
+ * (nets/blocks.py:136-148), se_block's dense pair (:165-178), tf.layers.dense of the head (nets/resnet_model.py:595-597)
+ * -- and their input gradients, as plain row-major products with the reduction index contiguous in both operands:
+ *   asm_dense_small:        out[m][n] = sum_k p[m][k] * q[n][k] (+ addend[m][n], bf16 [M][ldo]); bf16 operands, fp32
+ *                           accumulation, out f32 or bf16 with row stride ldo.  K % 16 == 0; ldp, ldq % 8 == 0.
+ *                           fprop: p = x [M][Cin], q = kernel [Cout][Cin]; input gradient: p = dy [M][ldy], q = the
+ *                           CRSK copy [Cin][ldk] (asm_filter_transpose), K = ldk.
+ *   asm_dense_bn_fwd:       ypre = bf16(x . w^T) [M][N]; training-mode batch norm of ypre over the M rows (statistics of
+ *                           the bf16-rounded values, moving-statistics update, mean / invstd out), z = bn(ypre) [relu],
+ *                           optional packed ReLU mask [M][N/8] -- one launch (== asm_conv2d_fprop + asm_bn_small_fwd).
+ *   asm_dense_dgrad_bn_bwd: g = bf16(dy . wt^T) [M][N] (the input gradient of the NEXT dense layer: dy [M][lddy],
+ *                           wt = its CRSK copy [N][ldwt], reduction K), then the backward of the batch norm that produced
+ *                           that layer's input: dgamma, dbeta, dx [M][N] from g, ypre and the mask (NULL = no ReLU)
+ *                           (== asm_conv2d_dgrad + asm_bn_small_bwd).
+ * The two batch-norm forms need M <= asm_dense_bn_max_rows() (one workgroup owns every row of 32 channels). */
+int asm_dense_bn_max_rows(void);
+int asm_dense_small(const void* p, int ldp, const void* q, int ldq, int M, int N, int K, void* out, int ldo,
+                    int out_f32, const void* addend, void* stream);
+int asm_dense_bn_fwd(const void* x, int ldx, const void* w, int ldw, int M, int K, int N, const float* gamma,
+                     const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                     void* ypre, void* z, float* mean, float* invstd, int relu, uint8_t* relu_mask_out, void* stream);
+int asm_dense_dgrad_bn_bwd(const void* dy, int lddy, const void* wt, int ldwt, int M, int K, int N, const void* ypre,
+                           const uint8_t* relu_mask, const float* gamma, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, void* dx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pooling / resampling (NHWC bf16)
  * ---------------------------------------------------------------------------------------------- */

@@ -432,3 +432,135 @@ def test_sk_unit_with_bn_applied_on_the_fly_equals_materialised_path(hip_lib, N,
   assert util.rel_l2(v1.float().cpu(), vr.detach()) <= 4e-3
   assert util.rel_l2(s1.float().cpu(), sr.detach()) <= 4e-3
   assert util.rel_l2(dy1.float().cpu(), gy) <= 8e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# small dense layers (csrc/dense_small.hip): the [N,1,1,C] squeeze / excite / classifier layers
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K,ldo,f32,addend', [
+    (256, 512, 128, 512, True, False),      # sk_fc_2 forward (fp32 logits)
+    (256, 128, 256, 128, False, False),     # sk_fc_1 input gradient
+    (256, 1001, 2048, 1008, True, False),   # the classifier: N tail inside a quad, padded rows
+    (256, 2048, 1008, 2048, False, True),   # its input gradient over the zero-padded 1008 logits, with an addend
+    (7, 40, 48, 40, False, False),          # ragged rows / channel tile
+    (33, 36, 16, 36, True, False),
+])
+def test_dense_small_vs_fp32(hip_lib, M, N, K, ldo, f32, addend):
+  from assembled_cnn_amd.ops import L, _ptr, _stream, check
+  p = _rand((M, K), 1)
+  q = _rand((N, K), 2, scale=K ** -0.5)
+  add = _rand((M, ldo), 3) if addend else None
+  out = torch.full((M, ldo), 7.0, dtype=torch.float32 if f32 else BF).cuda()
+  pc, qc = p.cuda(), q.cuda()
+  addc = add.cuda() if addend else None
+  check(L().asm_dense_small(_ptr(pc), K, _ptr(qc), K, M, N, K, _ptr(out), ldo, 1 if f32 else 0, _ptr(addc), _stream()), 'dense_small')
+  ref = p.float() @ q.float().t()
+  if addend:
+    ref = ref + add.float()[:, :N]
+  got = out.float().cpu()
+  if f32:
+    assert util.rel_l2(got[:, :N], ref) <= 2e-6, util.rel_l2(got[:, :N], ref)
+  else:
+    _close(got[:, :N], ref, name='dense_small')
+  assert bool((got[:, N:] == 7.0).all()), 'columns past N must not be written'
+
+
+def test_dense_layers_route_through_dense_small_and_match_the_conv_kernels(hip_lib, monkeypatch):
+  """ops.conv_fprop / conv_dgrad of a [N,1,1,C] layer: the dense kernel == the implicit-GEMM convolution (A/B knob)"""
+  from assembled_cnn_amd import ops
+  N_, Cn, K = 256, 128, 512
+  x = _rand((N_, 1, 1, Cn), 1).cuda()
+  w = _rand((K, 1, 1, Cn), 2, scale=Cn ** -0.5).cuda()
+  dy = _rand((N_, 1, 1, K), 3).cuda()
+  wt = torch.zeros((Cn, 1, 1, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w, wt, K, 1, 1, Cn)
+  outs = {}
+  for knob in ('1', '0'):
+    monkeypatch.setenv('ASM_DENSE_SMALL', knob)
+    d = ops.make_conv_desc(N_, 1, 1, Cn, K, 1, 1, 1, out_f32=True)
+    y, _ = ops.conv_fprop(d, x, w, False)
+    db = ops.make_conv_desc(N_, 1, 1, Cn, K, 1, 1, 1)
+    yb, _ = ops.conv_fprop(db, x, w, False)
+    dx = ops.conv_dgrad(db, dy, wt)
+    outs[knob] = (y.float().cpu(), yb.float().cpu(), dx.float().cpu())
+  assert util.rel_l2(outs['1'][0], outs['0'][0]) <= 2e-6
+  _close(outs['1'][1], outs['0'][1], name='dense fprop bf16')
+  _close(outs['1'][2], outs['0'][2], name='dense dgrad')
+
+
+@pytest.mark.parametrize('M,K,N,relu', [(256, 512, 256, True), (256, 64, 32, True), (128, 256, 128, True), (37, 48, 40, False),
+                                        (256, 128, 64, False)])
+def test_dense_bn_fused_equals_conv_plus_bn_small(hip_lib, M, K, N, relu, monkeypatch):
+  """fc + training-mode BN (+ReLU) in one launch == asm_conv2d_fprop + asm_bn_small_fwd; and its backward twin
+  (input gradient of the next dense layer + BN backward) == asm_conv2d_dgrad + asm_bn_small_bwd."""
+  from assembled_cnn_amd import ops
+  monkeypatch.setenv('ASM_DENSE_SMALL', '1')
+  x = _rand((M, 1, 1, K), 1).cuda()
+  w = _rand((N, 1, 1, K), 2, scale=K ** -0.5).cuda()
+  gamma = (torch.rand(N, generator=torch.Generator().manual_seed(2)) + 0.5).cuda()
+  beta = (torch.randn(N, generator=torch.Generator().manual_seed(3)) * 0.1).cuda()
+  mm, mv = torch.zeros(N).cuda(), torch.ones(N).cuda()
+  d = ops.make_conv_desc(M, 1, 1, K, N, 1, 1, 1)
+  assert ops.dense_bn_ok(M, K, N)
+  ypre, z, mask, mean, invstd = ops.dense_bn_fwd(d, x, w, gamma, beta, 1e-5, 0.997, mm, mv, relu, True)
+  # the two-launch path
+  monkeypatch.setenv('ASM_DENSE_SMALL', '0')
+  y2, _ = ops.conv_fprop(d, x, w, False)
+  mm2, mv2 = torch.zeros(N).cuda(), torch.ones(N).cuda()
+  z2, mask2, mean2, invstd2 = ops.bn_small_fwd(y2, M, N, gamma, beta, 1e-5, 0.997, mm2, mv2, relu, True)
+  _close(ypre, y2.float().cpu(), name='dense_bn ypre')
+  assert torch.allclose(mean, mean2, rtol=1e-3, atol=2e-3) and torch.allclose(invstd, invstd2, rtol=2e-3)
+  assert torch.allclose(mm, mm2, rtol=1e-3, atol=1e-5) and torch.allclose(mv, mv2, rtol=1e-3)
+  _close(z, z2.float().cpu(), rel=8e-3, name='dense_bn z')      # 1-ulp flips of ypre move the batch statistics slightly
+  # fp32 reference on the kernel's own bf16 product
+  yf = ypre.float().cpu().view(M, N)
+  mu, var = yf.mean(0), yf.var(0, unbiased=False)
+  ref = (yf - mu) / torch.sqrt(var + 1e-5) * gamma.cpu() + beta.cpu()
+  _close(z.view(M, N), ref.clamp(min=0) if relu else ref, name='dense_bn z vs fp32')
+  if relu:
+    bits = ((mask.cpu().to(torch.int32)[..., None] >> torch.arange(8, dtype=torch.int32)) & 1).view(M, N).bool()
+    zf = z.float().cpu().view(M, N)
+    assert bool((bits == (zf > 0)).all()) or float((bits != (zf > 0)).float().mean()) < 1e-3
+  # backward: next layer = dense N -> K2
+  K2 = 2 * K if 2 * K <= 1024 else 1024
+  w2 = _rand((K2, 1, 1, N), 5, scale=N ** -0.5).cuda()
+  wt2 = torch.zeros((N, 1, 1, K2), dtype=BF, device='cuda')
+  ops.filter_transpose(w2, wt2, K2, 1, 1, N)
+  dy2 = _rand((M, 1, 1, K2), 6).cuda()
+  d2 = ops.make_conv_desc(M, 1, 1, N, K2, 1, 1, 1)
+  dg, db = torch.empty(N).cuda(), torch.empty(N).cuda()
+  dx = ops.dense_dgrad_bn_bwd(d2, dy2, wt2, ypre, mask if relu else None, gamma, mean, invstd, dg, db)
+  g2 = ops.conv_dgrad(d2, dy2, wt2)                     # ASM_DENSE_SMALL=0: the implicit-GEMM input gradient
+  dg2, db2 = torch.empty(N).cuda(), torch.empty(N).cuda()
+  dx2 = ops.bn_small_bwd(g2, ypre, mask if relu else None, M, N, gamma, mean, invstd, dg2, db2)
+  _close(dx, dx2.float().cpu(), rel=6e-3, name='dense_dgrad_bn_bwd dx')
+  assert torch.allclose(dg, dg2, rtol=2e-3, atol=2e-2) and torch.allclose(db, db2, rtol=2e-3, atol=2e-2)
+
+
+def test_sk_attention_path_fused_vs_unfused_whole_unit(hip_lib, monkeypatch):
+  """One SK bottleneck network step with the squeeze layers on csrc/dense_small.hip vs on the convolution kernels:
+  logits and every parameter gradient agree to bf16 noise."""
+  from tests import model_parity as MP
+  res = {}
+  for knob in ('1', '0'):
+    monkeypatch.setenv('ASM_DENSE_SMALL', knob)
+    om, pm = MP.make_pair('a-r50', 'cuda', 8, 64)
+    _, x, _ = MP.inputs(8, 64)
+    lp = pm(x.cuda(), True, use_resnet_d=False)
+    dl = torch.zeros((8, 1, 1, pm.ldc), dtype=BF, device='cuda')
+    dl[:, 0, 0, :1001] = (torch.softmax(lp.float(), 1) / 8).to(BF)
+    pm.backward(dl)
+    torch.cuda.synchronize()
+    grads = {n: pm.arena.g(n).float().cpu().clone() for n in pm.arena.specs}
+    res[knob] = (lp.float().cpu().clone(), grads)
+  assert util.rel_l2(res['1'][0], res['0'][0]) <= 6e-2
+  ga, gb = res['1'][1], res['0'][1]
+  worst = 1.0
+  for n in ga:
+    if 'sk_block' in n and float(gb[n].norm()) > 0:
+      cos = float((ga[n] * gb[n]).sum() / (ga[n].norm() * gb[n].norm() + 1e-30))
+      worst = min(worst, cos)
+      assert cos >= 0.9, '%s: gradient cosine %.3f between the two squeeze-layer paths' % (n, cos)
+  fa = torch.cat([g.reshape(-1) for g in ga.values()])
+  fb = torch.cat([g.reshape(-1) for g in gb.values()])
+  assert float((fa * fb).sum() / (fa.norm() * fb.norm())) >= 0.95
