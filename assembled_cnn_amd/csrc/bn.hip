@@ -177,11 +177,29 @@ __device__ __forceinline__ void sum_rows(const float* __restrict__ partial, int 
   s0 = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   s1 = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
 }
+// finalize kernels: two independent chains per lane.  (Issuing all 16 rows of a lane at once, as sum_rows does, was
+// measured SLOWER here -- 12.5 vs 6.5 us for the 1024-row backward partials -- while it helps the compaction, whose lanes
+// walk hundreds of rows.)
 __device__ __forceinline__ void sum_partials(const float* partial, int blocks, int C, int ch, int ry,
                                              double& s0, double& s1) {
   s0 = 0.0;
   s1 = 0.0;
-  if (ch < C) sum_rows(partial, 0, blocks, ry, FL, C, ch, s0, s1);
+  if (ch < C) {
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    int b = ry;
+    for (; b + FL < blocks; b += 2 * FL) {   // two independent chains: loads overlap
+      a0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
+      b0 += (double)partial[((size_t)b * 2 + 1) * C + ch];
+      a1 += (double)partial[((size_t)(b + FL) * 2 + 0) * C + ch];
+      b1 += (double)partial[((size_t)(b + FL) * 2 + 1) * C + ch];
+    }
+    if (b < blocks) {
+      a0 += (double)partial[((size_t)b * 2 + 0) * C + ch];
+      b0 += (double)partial[((size_t)b * 2 + 1) * C + ch];
+    }
+    s0 = a0 + a1;
+    s1 = b0 + b1;
+  }
 }
 
 // partial compaction: [blocks][2][C] -> [groups][2][C]; each output group sums a contiguous range of

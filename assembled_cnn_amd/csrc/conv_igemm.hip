@@ -126,6 +126,42 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
   } else {
     constexpr int LDO = C::LDO, CPO = C::CPO, RPO = C::RPO, OP = C::OP;
     unsigned char* os = smem;
+    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+    const int oc = tid % CPO, orow = tid / CPO;
+    const int n0 = tile_n * BN + oc * 8;
+    const int co8 = (p.Co + 7) & ~7;
+    auto row_off = [&](int row, int m) -> size_t {
+      if (patch_base >= 0) return (size_t)(patch_base + (row >> 4) * p.Wi + (row & 15)) * p.ldy + n0;
+      if (p.y_strided) {   // workgroup-uniform: rows of a parity class scatter into the full-resolution tensor
+        const unsigned img = fd_div((unsigned)m, p.fd_howo);
+        const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
+        const unsigned ho = fd_div(rem, p.fd_wo);
+        const unsigned wo = rem - ho * (unsigned)p.Wo;
+        return (size_t)p.y_base + (size_t)img * p.y_img_pitch + (size_t)ho * p.y_row_pitch + (size_t)wo * p.y_pix_pitch + n0;
+      }
+      return (size_t)m * p.ldy + n0;
+    };
+    // The gradient fan-in addend (and its ReLU mask) of up to PF output passes is fetched BEFORE the passes run -- the
+    // first group even before the accumulators go to LDS: in the pass loop itself every addend load sat behind the
+    // previous pass's store (they may alias: in-place accumulation is allowed), i.e. one exposed HBM round trip per pass,
+    // 8-16 per workgroup, on every input-gradient launch that closes a residual fan-in.  A thread only ever re-reads the
+    // addresses it writes itself, so in-place accumulation stays exact.
+    constexpr int PF = OP < 8 ? OP : 8;
+    u32x4 av[PF];
+    unsigned amk[PF];
+    auto prefetch = [&](int ps0) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int row = (ps0 + i) * RPO + orow;
+        const int m = tile_m * BM + row;
+        const bool ok = m < p.M && n0 < co8;
+        const size_t yo = row_off(row, ok ? m : 0);
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        av[i] = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) + yo) : z4;
+        amk[i] = (ok && p.addend_mask) ? (unsigned)p.addend_mask[yo >> 3] : 0xffu;
+      }
+    };
+    if (p.addend) prefetch(0);      // workgroup-uniform
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -141,10 +177,6 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         }
       }
     __syncthreads();
-    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-    const int oc = tid % CPO, orow = tid / CPO;
-    const int n0 = tile_n * BN + oc * 8;
-    const int co8 = (p.Co + 7) & ~7;
     // statistics partials are per STATS_BM (=128) rows: a 256-row tile emits two of them
     constexpr int SG = STATS ? BM / STATS_BM : 1;
     float s[SG][8], ss[SG][8];
@@ -154,21 +186,12 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       for (int e = 0; e < 8; ++e) s[q][e] = ss[q][e] = 0.f;
 #pragma unroll
     for (int ps = 0; ps < OP; ++ps) {
+      if (p.addend && ps > 0 && ps % PF == 0) prefetch(ps);
       const int row = ps * RPO + orow;
       const int m = tile_m * BM + row;
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
       if (m < p.M && n0 < co8) {
-        size_t yoff = (size_t)m * p.ldy + n0;
-        if (patch_base >= 0) {
-          yoff = (size_t)(patch_base + (row >> 4) * p.Wi + (row & 15)) * p.ldy + n0;
-        } else if (p.y_strided) {   // workgroup-uniform: rows of a parity class scatter into the full-resolution tensor
-          const unsigned img = fd_div((unsigned)m, p.fd_howo);
-          const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
-          const unsigned ho = fd_div(rem, p.fd_wo);
-          const unsigned wo = rem - ho * (unsigned)p.Wo;
-          yoff = (size_t)p.y_base + (size_t)img * p.y_img_pitch + (size_t)ho * p.y_row_pitch +
-                 (size_t)wo * p.y_pix_pitch + n0;
-        }
+        const size_t yoff = row_off(row, m);
         if (p.addend || p.bn_scale) {   // workgroup-uniform
           float fv[8];
           unpack8(v, fv);
@@ -182,16 +205,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
             }
           }
           if (p.addend) {
-            const u32x4 av = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) + yoff);
             float fa[8];
-            unpack8(av, fa);
-            if (p.addend_mask) {          // workgroup-uniform: the addend is a not-yet-masked gradient (dz = dy * [y > 0])
-              const unsigned mk = p.addend_mask[yoff >> 3];
+            unpack8(av[ps % PF], fa);
+            const unsigned mk = amk[ps % PF];     // 0xff without a mask: the addend is a not-yet-masked gradient (dz = dy * [y > 0]) otherwise
 #pragma unroll
-              for (int e = 0; e < 8; ++e) fa[e] = ((mk >> e) & 1u) ? fa[e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fv[e] += fa[e];
+            for (int e = 0; e < 8; ++e) fv[e] += ((mk >> e) & 1u) ? fa[e] : 0.f;
           }
           if (p.bn_relu) {
 #pragma unroll
@@ -977,7 +995,12 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
   //    (3-8 workgroups per CU hide the load round trip of the very short K loops);
   //  * MFMA-bound layers (K = R*S*C >= 512): register staging with a 2-deep prefetch wins at 128x128,
   //    and 256x256 / 8 waves / LDS-DMA wins once there are >= 192 such tiles (C>=256 outputs).
-  const bool bk64 = (a.Ci % 64 == 0 && a.R * a.S > 1);
+  // 1x1 layers stage 32 channels per step (smallest footprint: the bandwidth-bound ones want many workgroups per CU) --
+  // except deep reductions on few tiles (7x7 / 14x14 maps), where each of the K / 32 steps is an exposed DMA round trip
+  // behind a barrier: ASM_IGEMM_BK64_1X1=<max 128x128 tiles> moves those to 64-channel steps (A/B knob).
+  const long long t128_all = (long long)cdiv(a.M, 128) * cdiv(a.Co, 128);
+  const int bk64_tiles = asm_env_int("ASM_IGEMM_BK64_1X1", 0);
+  const bool bk64 = a.Ci % 64 == 0 && (a.R * a.S > 1 || (bk64_tiles > 0 && a.Ci >= 256 && t128_all <= bk64_tiles));
   const bool heavy = a.Ci % 64 == 0 && (long long)a.R * a.S * a.Ci >= 512;
   const int fmode = env_int("ASM_IGEMM_MODE"), ftile = env_int("ASM_IGEMM_TILE");
   a.fd_howo = make_fastdiv((unsigned)a.HoWo);

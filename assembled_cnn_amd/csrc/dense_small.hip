@@ -338,6 +338,63 @@ __global__ __launch_bounds__(512) void dense_dgrad_bn_bwd_kernel(DenseBnBwdArgs 
   }
 }
 
+// ---- weight gradient: dw[n][k] = sum_m dy[m][n] * x[m][k] --------------------------------------------------------------
+// Both operands are reduction-MAJOR here (rows m), so a lane's fragment (8 consecutive m of one column) is 8 two-byte
+// loads, coalesced across the 32 lanes that hold consecutive columns; at M <= a few hundred rows that is ~64 loads per
+// lane and launch.  grid (ceil(Cin/32), ceil(Cout/32)), 4 waves split the rows; fp32 out [Cout][ldw].
+struct DenseWgradArgs {
+  const bf16_t* x; const bf16_t* dy; float* dw; int ldx, ldy, ldw, M, Cin, Cout;
+};
+
+__device__ __forceinline__ bf16x8 gather8(const bf16_t* base, int ld, int r0, int M, bool col_ok) {
+  unsigned short v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (col_ok && r0 + j < M) ? base[(size_t)(r0 + j) * ld] : (unsigned short)0;
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (short)v[j];
+  return f;
+}
+
+__global__ __launch_bounds__(256) void dense_small_wgrad_kernel(DenseWgradArgs a) {
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const bool k_ok = k0 + l31 < a.Cin, n_ok = n0 + l31 < a.Cout;
+  const bf16_t* xp = a.x + (k_ok ? k0 + l31 : 0);
+  const bf16_t* yp = a.dy + (n_ok ? n0 + l31 : 0);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int steps = (a.M + 15) >> 4;
+  for (int s = wave; s < steps; s += 8) {          // two steps (32 loads) in flight
+    const int r0 = s * 16 + lhi * 8, r1 = (s + 4) * 16 + lhi * 8;
+    const bf16x8 fx0 = gather8(xp, a.ldx, r0, a.M, k_ok), fy0 = gather8(yp, a.ldy, r0, a.M, n_ok);
+    const bf16x8 fx1 = gather8(xp, a.ldx, r1, a.M, k_ok), fy1 = gather8(yp, a.ldy, r1, a.M, n_ok);   // rows >= M read as 0
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx0, fy0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx1, fy1, acc, 0, 0, 0);
+  }
+  // acc[r] = dw[n = n0 + l31][k = k0 + (r & 3) + 8 * (r >> 2) + 4 * lhi]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][l31][(r & 3) + 8 * (r >> 2) + 4 * lhi] = acc[r];
+  __syncthreads();
+  const int n = tid >> 3, kq = (tid & 7) * 4;
+  const int gn = n0 + n, gk = k0 + kq;
+  if (gn >= a.Cout || gk >= a.Cin) return;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (red[0][n][kq + j] + red[1][n][kq + j]) + (red[2][n][kq + j] + red[3][n][kq + j]);
+  float* o = a.dw + (size_t)gn * a.ldw + gk;
+  if (gk + 3 < a.Cin) {
+    f32x4 w = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o) = w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (gk + j < a.Cin) o[j] = v[j];
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -396,5 +453,18 @@ extern "C" int asm_dense_dgrad_bn_bwd(const void* dy, int lddy, const void* wt, 
   if (relu_mask) hipLaunchKernelGGL(dense_dgrad_bn_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dense_dgrad_bn_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
   ASM_CHECK_LAUNCH("dense_dgrad_bn_bwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_dense_small_wgrad(const void* x, int ldx, const void* dy, int ldy, int M, int Cin, int Cout, float* dw,
+                                     int ldw, void* stream) {
+  ASM_REQUIRE(x && dy && dw && M > 0 && Cin > 0 && Cout > 0, "dense_small_wgrad: bad arguments");
+  ASM_REQUIRE(ldx >= Cin && ldy >= Cout && ldw >= Cin && ldw % 4 == 0, "dense_small_wgrad: bad row strides");
+  ASM_REQUIRE(aligned16(dw), "dense_small_wgrad: unaligned pointer");
+  DenseWgradArgs a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw; a.ldx = ldx; a.ldy = ldy; a.ldw = ldw;
+  a.M = M; a.Cin = Cin; a.Cout = Cout;
+  hipLaunchKernelGGL(dense_small_wgrad_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32)), dim3(256), 0, (hipStream_t)stream, a);
+  ASM_CHECK_LAUNCH("dense_small_wgrad");
   return ASM_OK;
 }

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libasm_hip.so')
+# ASM_HIP_LIB=<path>: load another build of the same ABI (same-box A/B runs of a kernel change; tools/ab/)
+LIB_PATH = os.environ.get('ASM_HIP_LIB') or os.path.join(HERE, 'libasm_hip.so')
 
 ASM_OK, ASM_EINVAL, ASM_ENOTSUP, ASM_EHIP = 0, -1, -2, -3
 ABI_VERSION = 1
@@ -142,6 +143,7 @@ SIGNATURES = {
     'asm_bn_small_bwd': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'asm_dense_bn_max_rows': (_I, []),
     'asm_dense_small': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
+    'asm_dense_small_wgrad': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P]),
     'asm_dense_bn_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asm_dense_dgrad_bn_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_resize_crop_flip': (_I, [_P, C.c_int64, _P, _I, _I, _I, _I, _P, _P]),

@@ -263,6 +263,12 @@ def conv_wgrad(d: ConvDesc, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor)
   need = L().asm_conv2d_wgrad_workspace_bytes(C.byref(d))
   ws = _workspace(need, x)
   ev = _TIMER.start('wgrad', d) if _TIMER is not None else None
+  if _is_dense(d) and d.N <= 1024 and dense_small_on():     # [N,1,1,C] layer: dw = dy^T . x over a few hundred rows
+    check(L().asm_dense_small_wgrad(_ptr(x), d.C, _ptr(dy), d.ldy if d.ldy else d.K, d.N, d.C, d.K, _ptr(dw), d.C,
+                                    _stream()), 'dense_small_wgrad')
+    if ev is not None:
+      ev.record()
+    return
   check(L().asm_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), need, _stream()), 'conv2d_wgrad')
   if ev is not None:
     ev.record()

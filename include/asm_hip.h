@@ -190,10 +190,13 @@ int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* relu_mask, in
  *                           wt = its CRSK copy [N][ldwt], reduction K), then the backward of the batch norm that produced
  *                           that layer's input: dgamma, dbeta, dx [M][N] from g, ypre and the mask (NULL = no ReLU)
  *                           (== asm_conv2d_dgrad + asm_bn_small_bwd).
+ *   asm_dense_small_wgrad:  dw[n][k] = sum_m dy[m][n] * x[m][k]  (fp32 [Cout][ldw]; x [M][ldx], dy [M][ldy]).
  * The two batch-norm forms need M <= asm_dense_bn_max_rows() (one workgroup owns every row of 32 channels). */
 int asm_dense_bn_max_rows(void);
 int asm_dense_small(const void* p, int ldp, const void* q, int ldq, int M, int N, int K, void* out, int ldo,
                     int out_f32, const void* addend, void* stream);
+int asm_dense_small_wgrad(const void* x, int ldx, const void* dy, int ldy, int M, int Cin, int Cout, float* dw, int ldw,
+                          void* stream);
 int asm_dense_bn_fwd(const void* x, int ldx, const void* w, int ldw, int M, int K, int N, const float* gamma,
                      const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
                      void* ypre, void* z, float* mean, float* invstd, int relu, uint8_t* relu_mask_out, void* stream);

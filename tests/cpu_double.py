@@ -313,6 +313,15 @@ class CpuDouble(object):
     o[:, :N] = acc.to(o.dtype)
     return 0
 
+  def asm_dense_small_wgrad(self, x, ldx, dy, ldy, M, Cin, Cout, dw, ldw, stream):
+    if ldx < Cin or ldy < Cout or ldw < Cin or ldw % 4:
+      self._err = b'dense_small_wgrad: bad row strides'
+      return -1
+    xv = T(x, (M, ldx), 'bf16').float()[:, :Cin]
+    gv = T(dy, (M, ldy), 'bf16').float()[:, :Cout]
+    T(dw, (Cout, ldw), 'f32')[:, :Cin] = gv.t() @ xv
+    return 0
+
   def asm_dense_bn_fwd(self, x, ldx, w, ldw, M, K, N, gamma, beta, eps, momentum, mm, mv, ypre, z, mean, invstd, relu,
                        mask, stream):
     if M <= 0 or M > 256 or N % 8 or K % 16:

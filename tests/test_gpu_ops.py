@@ -564,3 +564,22 @@ def test_sk_attention_path_fused_vs_unfused_whole_unit(hip_lib, monkeypatch):
   fa = torch.cat([g.reshape(-1) for g in ga.values()])
   fb = torch.cat([g.reshape(-1) for g in gb.values()])
   assert float((fa * fb).sum() / (fa.norm() * fb.norm())) >= 0.95
+
+
+@pytest.mark.parametrize('M,Cin,Cout,ldy', [(256, 256, 1024, 1024), (256, 2048, 1001, 1008), (37, 40, 24, 24), (128, 64, 32, 32)])
+def test_dense_small_wgrad_vs_fp32_and_conv_kernel(hip_lib, M, Cin, Cout, ldy, monkeypatch):
+  from assembled_cnn_amd import ops
+  x = _rand((M, 1, 1, Cin), 1).cuda()
+  dy = torch.zeros((M, 1, 1, ldy), dtype=BF)
+  dy[..., :Cout] = _rand((M, 1, 1, Cout), 2)
+  dy = dy.cuda()
+  d = ops.make_conv_desc(M, 1, 1, Cin, Cout, 1, 1, 1, ldy=ldy if ldy != Cout else 0)
+  ref = dy.float().cpu().view(M, ldy)[:, :Cout].t() @ x.float().cpu().view(M, Cin)
+  got = {}
+  for knob in ('1', '0'):
+    monkeypatch.setenv('ASM_DENSE_SMALL', knob)
+    dw = torch.full((Cout, 1, 1, Cin), 3.0, device='cuda')
+    ops.conv_wgrad(d, x, dy, dw)
+    got[knob] = dw.cpu().view(Cout, Cin)
+  assert util.rel_l2(got['1'], ref) <= 2e-6, util.rel_l2(got['1'], ref)
+  assert util.rel_l2(got['0'], ref) <= 1e-4
