@@ -98,7 +98,7 @@ struct Cfg {
 // m_local = wm*WTM + b*32 + l31.
 // patch_base >= 0: the tile's 128 rows are an 8 x 16 pixel patch of one image (conv_halo_kernel): row r is pixel
 // patch_base + (r >> 4) * W + (r & 15) of the [N*H*W] output.
-template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS>
+template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS, bool PFA = false>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[TN][TM], unsigned char* smem,
                                                int tile_m, int tile_n, int tid, int wm, int wn, int l31, int lhi,
                                                int patch_base = -1) {
@@ -141,12 +141,15 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       }
       return (size_t)m * p.ldy + n0;
     };
-    // The gradient fan-in addend (and its ReLU mask) of up to PF output passes is fetched BEFORE the passes run -- the
-    // first group even before the accumulators go to LDS: in the pass loop itself every addend load sat behind the
-    // previous pass's store (they may alias: in-place accumulation is allowed), i.e. one exposed HBM round trip per pass,
-    // 8-16 per workgroup, on every input-gradient launch that closes a residual fan-in.  A thread only ever re-reads the
-    // addresses it writes itself, so in-place accumulation stays exact.
-    constexpr int PF = OP < 8 ? OP : 8;
+    // PFA kernels fetch the gradient fan-in addend (and its ReLU mask) of up to PF output passes BEFORE the passes run --
+    // the first group even before the accumulators go to LDS.  In the pass loop every addend load sits behind the previous
+    // pass's store (they may alias: in-place accumulation is allowed), i.e. one exposed HBM round trip per pass, 8-16 per
+    // workgroup: that is what bounds the input gradients of the small maps (7x7 / 14x14: a few hundred workgroups, nothing
+    // to overlap with; measured -20..-25 % there).  On the large maps the extra ~40 registers cost occupancy and the
+    // bandwidth-bound 1x1 layers lose 10-30 %, so the launcher picks the variant per layer (launch2_cfg).  A thread only
+    // ever re-reads the addresses it writes itself, so in-place accumulation stays exact.
+    constexpr bool PF_ON = PFA && !STATS;
+    constexpr int PF = !PF_ON ? 1 : (OP < 8 ? OP : 8);
     u32x4 av[PF];
     unsigned amk[PF];
     auto prefetch = [&](int ps0) {
@@ -161,7 +164,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         amk[i] = (ok && p.addend_mask) ? (unsigned)p.addend_mask[yo >> 3] : 0xffu;
       }
     };
-    if (p.addend) prefetch(0);      // workgroup-uniform
+    if constexpr (PF_ON) {
+      if (p.addend) prefetch(0);      // workgroup-uniform
+    }
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -186,7 +191,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       for (int e = 0; e < 8; ++e) s[q][e] = ss[q][e] = 0.f;
 #pragma unroll
     for (int ps = 0; ps < OP; ++ps) {
-      if (p.addend && ps > 0 && ps % PF == 0) prefetch(ps);
+      if constexpr (PF_ON) {
+        if (p.addend && ps > 0 && ps % PF == 0) prefetch(ps);
+      }
       const int row = ps * RPO + orow;
       const int m = tile_m * BM + row;
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
@@ -205,6 +212,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
             }
           }
           if (p.addend) {
+            if constexpr (!PF_ON) {
+              av[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.addend) + yoff);
+              amk[0] = p.addend_mask ? (unsigned)p.addend_mask[yoff >> 3] : 0xffu;
+            }
             float fa[8];
             unpack8(av[ps % PF], fa);
             const unsigned mk = amk[ps % PF];     // 0xff without a mask: the addend is a not-yet-masked gradient (dz = dy * [y > 0]) otherwise
@@ -530,7 +541,7 @@ struct Cfg2 {
   static_assert(LDS <= 160 * 1024, "lds");
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS, bool PFA = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
   using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
   using C2 = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
@@ -700,7 +711,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
     }
   }
 
-  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS, PFA>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -907,11 +918,11 @@ int try_halo(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   return 1;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2, bool PFA = false>
 int launch2_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
   constexpr int NTHR = 64 * WGM * WGN;
-  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS>;
+  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm2_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
@@ -928,14 +939,21 @@ int launch2_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   a.kchunks = cdiv(a.Ci, BK);
   a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
   if (a.Ci % BK != 0 && a.kchunks != 1) return 1;
+  // addend-prefetching epilogue (see igemm_epilogue): where a launch is one round of few workgroups, or one 256-row
+  // workgroup per CU anyway; ASM_IGEMM_PFA=0 / 1 forces it off / on (tests, A/B)
+  const int pfa_env = asm_env_int("ASM_IGEMM_PFA", -1);
+  const bool pfa = a.addend != nullptr && !a.y_strided &&
+                   (pfa_env >= 0 ? pfa_env != 0 : (BM == 256 || a.n_blocks <= 1024));
   if (a.R == 1 && a.S == 1) {
     if (out_f32) return launch2_one<BM, BN, BK, WGM, WGN, true, false, 1, 1>(a, st);
     if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 1, 1>(a, st);
+    if (pfa) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 1, 2, true>(a, st);
     return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 1>(a, st);
   }
   if (out_f32) return 1;
   if (a.R == 3 && a.S == 3) {
     if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 3, 3>(a, st);
+    if (pfa) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 3, 3, 2, true>(a, st);
     return launch2_one<BM, BN, BK, WGM, WGN, false, false, 3, 3>(a, st);
   }
   if (!stats) {   // parity classes of a stride-2 3x3 input gradient (asm_conv2d_dgrad)

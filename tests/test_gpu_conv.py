@@ -66,6 +66,7 @@ SHAPES = [
 def test_fprop_dgrad_wgrad_vs_oracle(hip_lib, shape, mode, monkeypatch):
   from assembled_cnn_amd import ops
   monkeypatch.setenv('ASM_IGEMM_MODE', str(mode))   # global->LDS staging flavour of the igemm kernel
+  monkeypatch.setenv('ASM_DENSE_SMALL', '0')        # [N,1,1,C] shapes too: this test is about the convolution kernels
   N, H, W, Cn, K, k, stride = shape
   x = _rand((N, H, W, Cn), 1)
   w = _rand((K, k, k, Cn), 2, scale=(1.0 / (k * k * Cn)) ** 0.5)
@@ -316,10 +317,13 @@ def test_fprop_with_folded_inference_bn(hip_lib, shape, res, relu):
 
 @pytest.mark.parametrize('shape', [(4, 14, 14, 128, 512, 1, 1), (2, 28, 28, 64, 256, 1, 1), (2, 14, 14, 64, 64, 3, 1),
                                    (32, 14, 14, 256, 1024, 1, 1)], ids=lambda s: 'x'.join(map(str, s)))
-def test_dgrad_with_masked_addend(hip_lib, shape):
+@pytest.mark.parametrize('pfa', [0, 1], ids=['addend-inline', 'addend-prefetched'])
+def test_dgrad_with_masked_addend(hip_lib, shape, pfa, monkeypatch):
   """asm_conv2d_dgrad_masked(addend, mask) == asm_conv2d_dgrad(addend * mask) bit for bit, and asm_mask_apply is that
-  product: the lazily masked shortcut gradient is the same gradient."""
+  product: the lazily masked shortcut gradient is the same gradient.  Both epilogue variants (addend fetched inside the
+  store passes / prefetched ahead of them, ASM_IGEMM_PFA) and in-place accumulation (dx == addend)."""
   from assembled_cnn_amd import ops
+  monkeypatch.setenv('ASM_IGEMM_PFA', str(pfa))
   N, H, W, Cn, K, k, stride = shape
   g = torch.Generator(device='cuda').manual_seed(17)
   d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
@@ -335,3 +339,11 @@ def test_dgrad_with_masked_addend(hip_lib, shape):
   a = ops.conv_dgrad(d, dy, wt, addend, mask)
   b = ops.conv_dgrad(d, dy, wt, masked)
   assert torch.equal(a, b)
+  monkeypatch.setenv('ASM_IGEMM_PFA', str(1 - pfa))
+  assert torch.equal(a, ops.conv_dgrad(d, dy, wt, addend, mask)), 'the two epilogue variants must agree bit for bit'
+  # in-place fan-in accumulation through the C ABI: dx aliases the addend
+  from assembled_cnn_amd.ops import L, _ptr, _stream, check
+  import ctypes as C
+  inplace = masked.clone()
+  check(L().asm_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(inplace), _ptr(inplace), _stream()), 'dgrad in place')
+  assert torch.equal(inplace, b)
