@@ -1014,10 +1014,12 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
   //  * MFMA-bound layers (K = R*S*C >= 512): register staging with a 2-deep prefetch wins at 128x128,
   //    and 256x256 / 8 waves / LDS-DMA wins once there are >= 192 such tiles (C>=256 outputs).
   // 1x1 layers stage 32 channels per step (smallest footprint: the bandwidth-bound ones want many workgroups per CU) --
-  // except deep reductions on few tiles (7x7 / 14x14 maps), where each of the K / 32 steps is an exposed DMA round trip
-  // behind a barrier: ASM_IGEMM_BK64_1X1=<max 128x128 tiles> moves those to 64-channel steps (A/B knob).
+  // except deep reductions on few tiles (7x7 / 14x14 / 28x28 maps), where each of the K / 32 steps is an exposed DMA
+  // round trip behind a barrier: up to ASM_IGEMM_BK64_1X1 (default 4000) 128 x 128 tiles they take 64-channel steps
+  // (tools/conv_bench.py, all 1x1 shapes of the network: fprop 2.36 -> 2.31 ms, input gradients 2.11 -> 2.03 ms per step;
+  // 0 = off).
   const long long t128_all = (long long)cdiv(a.M, 128) * cdiv(a.Co, 128);
-  const int bk64_tiles = asm_env_int("ASM_IGEMM_BK64_1X1", 0);
+  const int bk64_tiles = asm_env_int("ASM_IGEMM_BK64_1X1", 4000);
   const bool bk64 = a.Ci % 64 == 0 && (a.R * a.S > 1 || (bk64_tiles > 0 && a.Ci >= 256 && t128_all <= bk64_tiles));
   const bool heavy = a.Ci % 64 == 0 && (long long)a.R * a.S * a.Ci >= 512;
   const int fmode = env_int("ASM_IGEMM_MODE"), ftile = env_int("ASM_IGEMM_TILE");

@@ -197,8 +197,11 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restri
 }
 
 // ---- UpSampling2D((2,2)) backward: 2x2 block sum ---------------------------------------------------
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
-                                                           int N, int Hs, int Ws, int C) {
+// MASKED: dy is a not-yet-masked gradient and `mask` the packed ReLU mask ([N*H*W][C/8] bytes) of the full-resolution
+// tensor: the block sum runs over dy * [bit set], so the masked gradient dz is never written (exact: masking is exact).
+template <bool MASKED>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                           bf16_t* __restrict__ dx, int N, int Hs, int Ws, int C) {
   const int vcols = C >> 3;
   const size_t nvec = (size_t)N * Hs * Ws * vcols;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -213,7 +216,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restr
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       float g[8];
-      unpack8(ldv(dy, (((size_t)p.n * H + p.h * 2 + r) * W + p.w * 2 + s) * C + p.vc * 8), g);
+      const size_t pix = ((size_t)p.n * H + p.h * 2 + r) * W + p.w * 2 + s;
+      unpack8(ldv(dy, pix * C + p.vc * 8), g);
+      if (MASKED) {
+        const unsigned mk = mask[pix * vcols + p.vc];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += g[e];
     }
@@ -469,9 +478,20 @@ extern "C" int asm_upsample2x_bwd(const void* dy, void* dx, int N, int Hs, int W
   ASM_REQUIRE(dy && dx && N > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0, "upsample2x_bwd: bad arguments");
   const size_t nvec = (size_t)N * Hs * Ws * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                     (bf16_t*)dx, N, Hs, Ws, C);
+  hipLaunchKernelGGL(upsample_bwd_kernel<false>, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     nullptr, (bf16_t*)dx, N, Hs, Ws, C);
   ASM_CHECK_LAUNCH("upsample2x_bwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_upsample2x_bwd_masked(const void* dy, const uint8_t* relu_mask, void* dx, int N, int Hs, int Ws, int C,
+                                         void* stream) {
+  ASM_REQUIRE(dy && relu_mask && dx && N > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0, "upsample2x_bwd_masked: bad arguments");
+  const size_t nvec = (size_t)N * Hs * Ws * (C / 8);
+  ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
+  hipLaunchKernelGGL(upsample_bwd_kernel<true>, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     relu_mask, (bf16_t*)dx, N, Hs, Ws, C);
+  ASM_CHECK_LAUNCH("upsample2x_bwd_masked");
   return ASM_OK;
 }
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     'asm_avgpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'asm_avgpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'asm_upsample2x_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'asm_upsample2x_bwd_masked': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'asm_blurpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'asm_blurpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'asm_gap_fwd': (_I, [_P, _P, _I, _I, _I, _P]),

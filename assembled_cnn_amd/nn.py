@@ -564,7 +564,9 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
         else:
           bmask, brelu = in_mask, True
       lazy = LAZY_DZ and residual is not None and relu and res_mode == 1 and mask_t is not None and residual.needs_grad
-      want_dz = residual is not None and relu and not lazy
+      # BigLittle merge (res_mode 2): the 2x2 block sum reads (dout, mask) as well, so dz is not written there either
+      lazy_up = LAZY_DZ and residual is not None and relu and res_mode == 2 and mask_t is not None
+      want_dz = residual is not None and relu and not lazy and not lazy_up
       if small:
         dy, dz = ops.bn_small_bwd(dout, y, bmask, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta)), None
       else:
@@ -576,7 +578,7 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
         else:
           dres = dz if relu else dout
           if res_mode == 2:
-            accum_grad(residual, ops.upsample2x_bwd(dres), True)
+            accum_grad(residual, ops.upsample2x_bwd(dout, mask_t) if lazy_up else ops.upsample2x_bwd(dres), True)
           else:
             accum_grad(residual, dres, relu)
       xg, xmask = x.take_masked_grad()

@@ -450,10 +450,15 @@ def avgpool_bwd(dy, in_shape, k, stride, pad, count_valid, addend=None):
   return dx
 
 
-def upsample2x_bwd(dy):
+def upsample2x_bwd(dy, mask=None):
+  """2x2 block sums of dy [* mask bit] (mask: packed ReLU mask [N*H*W, C/8] of the full-resolution tensor)"""
   N, H, W, Cn = dy.shape
   dx = empty((N, H // 2, W // 2, Cn), BF16, dy)
-  check(L().asm_upsample2x_bwd(_ptr(dy), _ptr(dx), N, H // 2, W // 2, Cn, _stream()), 'upsample2x_bwd')
+  if mask is not None:
+    check(L().asm_upsample2x_bwd_masked(_ptr(dy), _ptr(mask), _ptr(dx), N, H // 2, W // 2, Cn, _stream()),
+          'upsample2x_bwd_masked')
+  else:
+    check(L().asm_upsample2x_bwd(_ptr(dy), _ptr(dx), N, H // 2, W // 2, Cn, _stream()), 'upsample2x_bwd')
   return dx
 
 

@@ -222,6 +222,10 @@ int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k,
                     int Ho, int Wo, int count_valid, const void* addend, void* stream);
 /* gradient of UpSampling2D((2,2)): dx[n,i,j,c] = sum of the 2x2 block of dy */
 int asm_upsample2x_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int C, void* stream);
+/* the same over dy * [mask bit]: dy is the un-masked gradient behind the merge's ReLU, relu_mask its packed mask
+ * ([N*2Hs*2Ws][C/8] bytes, asm_bn_apply): the masked full-resolution gradient is never materialised */
+int asm_upsample2x_bwd_masked(const void* dy, const uint8_t* relu_mask, void* dx, int N, int Hs, int Ws, int C,
+                              void* stream);
 /* blocks.anti_aliased_downsample (nets/blocks.py:45-107): REFLECT pad (k-1)/2, binomial k x k, stride 2 */
 int asm_blurpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, void* stream);
 int asm_blurpool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, void* stream);

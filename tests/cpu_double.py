@@ -506,6 +506,14 @@ class CpuDouble(object):
     T(dx, (N, Hs, Ws, Cn), 'bf16').copy_(g)
     return 0
 
+  def asm_upsample2x_bwd_masked(self, dy, mask, dx, N, Hs, Ws, Cn, stream):
+    g = T(dy, (N * Hs * 2 * Ws * 2, Cn), 'bf16').float()
+    mk = T(mask, (N * Hs * 2 * Ws * 2, Cn // 8), 'u8').to(torch.int32)
+    bits = ((mk[..., None] >> torch.arange(8, dtype=torch.int32)) & 1).view(-1, Cn).bool()
+    g = torch.where(bits, g, torch.zeros_like(g)).view(N, Hs, 2, Ws, 2, Cn).sum(dim=(2, 4))
+    T(dx, (N, Hs, Ws, Cn), 'bf16').copy_(g)
+    return 0
+
   @staticmethod
   def _blur(x, k, stride):
     tri = {2: [1., 1.], 3: [1., 2., 1.], 4: [1., 3., 3., 1.], 5: [1., 4., 6., 4., 1.],

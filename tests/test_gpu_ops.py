@@ -197,6 +197,10 @@ def test_gap_and_upsample(hip_lib):
   _close(dx, (dy.float() / 49).expand(3, 7, 7, 2048), name='gap bwd')
   g = _rand((2, 8, 8, 16), 3)
   _close(ops.upsample2x_bwd(g.cuda()), g.float().view(2, 4, 2, 4, 2, 16).sum((2, 4)), name='upsample bwd')
+  # the lazily masked form: block sums of g * [mask bit] == block sums of the materialised masked gradient, bit for bit
+  gg = _rand((3, 14, 14, 72), 4).cuda()
+  mask = torch.randint(0, 256, (3 * 14 * 14, 9), generator=torch.Generator().manual_seed(5), dtype=torch.uint8).cuda()
+  assert torch.equal(ops.upsample2x_bwd(gg, mask), ops.upsample2x_bwd(ops.mask_apply(gg, mask)))
 
 
 # ---------------------------------------------------------------------------------------------------
