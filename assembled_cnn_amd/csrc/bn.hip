@@ -427,6 +427,144 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
+// ---- two batch norms behind ONE ReLU: the block-final BN and the projection-shortcut BN of a bottleneck ---------------
+// out = relu(bn_a(ya) + bn_b(yb)): both backward passes consume the same masked gradient g = dout * [out > 0].  Run as two
+// independent BN backwards that is 2 x (reduce: dout, y, mask; apply: dout, y, mask -> dy) = 20.5 B per element; here dout
+// and the mask are read once per pass for both: 16.25 B per element and two launches fewer per projection block.
+// Partials: pa = [blocks][2][C] (sum g, sum g * xhat_a), pb likewise for b (sum g repeated, so the finalize is unchanged).
+__global__ __launch_bounds__(256) void rowreduce2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xa,
+                                                         const bf16_t* __restrict__ xb, const uint8_t* __restrict__ mask,
+                                                         int M, int C, const float* __restrict__ mean_a,
+                                                         const float* __restrict__ invstd_a, const float* __restrict__ mean_b,
+                                                         const float* __restrict__ invstd_b, RowTiling t,
+                                                         float* __restrict__ pa, float* __restrict__ pb) {
+  __shared__ float red[3 * 2048];
+  const int tid = threadIdx.x;
+  const int vc0 = tid % t.vcb;
+  const int rr = tid / t.vcb;
+  const bool active = rr < t.rpb;
+  const int row_begin = blockIdx.x * t.rows_per_block;
+  const int row_end = min(M, row_begin + t.rows_per_block);
+  for (int vcbase = 0; vcbase < t.vcols; vcbase += t.vcb) {
+    const int vc = vcbase + vc0;
+    float s[8], sa[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = sa[e] = sb[e] = 0.f;
+    if (active && vc < t.vcols) {
+      float ma[8], ia[8], mb[8], ib[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ma[e] = mean_a[vc * 8 + e];
+        ia[e] = invstd_a[vc * 8 + e];
+        mb[e] = mean_b[vc * 8 + e];
+        ib[e] = invstd_b[vc * 8 + e];
+      }
+      constexpr int U = 2;
+      for (int row = row_begin + rr; row < row_end; row += U * t.rpb) {
+        u32x4 vg[U], va[U], vb[U];
+        unsigned mk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = row + u * t.rpb;
+          const size_t rq = (size_t)(r < row_end ? r : row);
+          const size_t off = rq * C + vc * 8;
+          vg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dy + off));
+          va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xa + off));
+          vb[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xb + off));
+          mk[u] = mask[rq * t.vcols + vc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (row + u * t.rpb >= row_end) break;
+          float g[8], fa[8], fb[8];
+          unpack8(vg[u], g);
+          unpack8(va[u], fa);
+          unpack8(vb[u], fb);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float ge = ((mk[u] >> e) & 1u) ? g[e] : 0.f;
+            s[e] += ge;
+            sa[e] += ge * ((fa[e] - ma[e]) * ia[e]);
+            sb[e] += ge * ((fb[e] - mb[e]) * ib[e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int ncol = t.vcb * 8;
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(0 * t.rpb + rr) * ncol + vc0 * 8 + e] = s[e];
+        red[(1 * t.rpb + rr) * ncol + vc0 * 8 + e] = sa[e];
+        red[(2 * t.rpb + rr) * ncol + vc0 * 8 + e] = sb[e];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * ncol; i += 256) {
+      const int which = i / ncol, col = i - which * ncol;
+      float acc = 0.f;
+      for (int r = 0; r < t.rpb; ++r) acc += red[(which * t.rpb + r) * ncol + col];
+      const int ch = vcbase * 8 + col;
+      if (ch < C) {
+        if (which == 0) {
+          pa[((size_t)blockIdx.x * 2 + 0) * C + ch] = acc;
+          pb[((size_t)blockIdx.x * 2 + 0) * C + ch] = acc;
+        } else if (which == 1) {
+          pa[((size_t)blockIdx.x * 2 + 1) * C + ch] = acc;
+        } else {
+          pb[((size_t)blockIdx.x * 2 + 1) * C + ch] = acc;
+        }
+      }
+    }
+  }
+}
+
+// dxa = A_a * g + B_a * xa + C_a ; dxb likewise ; g = dy * [mask bit].  co = [6][C]: A_a, B_a, C_a, A_b, B_b, C_b.
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xa,
+                                                            const bf16_t* __restrict__ xb, const uint8_t* __restrict__ mask,
+                                                            size_t nvec, int C, FastDiv fd_vcols,
+                                                            const float* __restrict__ co, bf16_t* __restrict__ dxa,
+                                                            bf16_t* __restrict__ dxb) {
+  const int vcols = C >> 3;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const bool fixed = (stride % (size_t)vcols) == 0;   // see bn_apply_kernel
+  float k[6][8];
+  if (fixed) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int vc0 = (int)(i0 % (size_t)vcols);
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) k[q][e] = co[(size_t)q * C + vc0 * 8 + e];
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    float g[8], fa[8], fb[8];
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dy + i * 8)), g);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xa + i * 8)), fa);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xb + i * 8)), fb);
+    const unsigned mk = mask[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
+    if (!fixed) {
+      const unsigned m = fd_div((unsigned)i, fd_vcols);
+      const int vc = (int)((unsigned)i - m * (unsigned)vcols);
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) k[q][e] = co[(size_t)q * C + vc * 8 + e];
+    }
+    float oa[8], ob[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      oa[e] = k[0][e] * g[e] + k[1][e] * fa[e] + k[2][e];
+      ob[e] = k[3][e] * g[e] + k[4][e] * fb[e] + k[5][e];
+    }
+    __builtin_nontemporal_store(pack8(oa), reinterpret_cast<u32x4*>(dxa + i * 8));
+    __builtin_nontemporal_store(pack8(ob), reinterpret_cast<u32x4*>(dxb + i * 8));
+  }
+}
+
 // ---- small-tensor batch norm: statistics + finalize + apply in ONE launch (and reduce + finalize + apply backward) ----
 // The SK / SE squeeze layers normalise [N, 1, 1, d] tensors (256 x 32..256 elements): three to four ~5 us launches
 // of pure latency per direction in the general path.  Here one workgroup owns 64 channels x all M rows (M <= 4096):
@@ -740,5 +878,30 @@ extern "C" int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* re
     hipLaunchKernelGGL(bn_small_bwd_kernel<0>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
                        nullptr, M, C, gamma, mean, invstd, dgamma, dbeta, (bf16_t*)dx);
   ASM_CHECK_LAUNCH("bn_small_bwd");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_bwd_reduce2(const void* dy, const void* xa, const void* xb, const uint8_t* relu_mask, int M, int C,
+                                  const float* mean_a, const float* invstd_a, const float* mean_b, const float* invstd_b,
+                                  float* partial_a, float* partial_b, void* stream) {
+  ASM_REQUIRE(dy && xa && xb && relu_mask && mean_a && invstd_a && mean_b && invstd_b && partial_a && partial_b && M > 0 &&
+                  C > 0 && C % 8 == 0, "bn_bwd_reduce2: bad arguments");
+  RowTiling t = make_tiling(M, C);
+  hipLaunchKernelGGL(rowreduce2_kernel, dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)xa, (const bf16_t*)xb, relu_mask, M, C, mean_a, invstd_a, mean_b, invstd_b, t, partial_a,
+                     partial_b);
+  ASM_CHECK_LAUNCH("bn_bwd_reduce2");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_bwd_apply2(const void* dy, const void* xa, const void* xb, const uint8_t* relu_mask, int M, int C,
+                                 const float* coef6, void* dxa, void* dxb, void* stream) {
+  ASM_REQUIRE(dy && xa && xb && relu_mask && coef6 && dxa && dxb && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply2: bad arguments");
+  ASM_REQUIRE((size_t)M * (C / 8) < 0x7fffffffull, "bn_bwd_apply2: tensor too large");
+  const size_t nvec = (size_t)M * (C / 8);
+  hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)xa, (const bf16_t*)xb, relu_mask, nvec, C, make_fastdiv((unsigned)(C / 8)), coef6,
+                     (bf16_t*)dxa, (bf16_t*)dxb);
+  ASM_CHECK_LAUNCH("bn_bwd_apply2");
   return ASM_OK;
 }

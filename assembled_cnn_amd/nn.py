@@ -27,6 +27,11 @@ BN_EPS = 1e-5  # nets/model_helper.py:26
 LAZY_DZ = os.environ.get('ASM_LAZY_DZ', '1') != '0'
 
 
+def dual_bn_on() -> bool:
+  """ASM_BN_DUAL=0: two separate batch-norm backwards for a projection block (A/B runs, tests); read per call"""
+  return os.environ.get('ASM_BN_DUAL', '1') != '0'
+
+
 def _round_up(n: int, m: int) -> int:
   return (n + m - 1) // m * m
 
@@ -229,7 +234,8 @@ class Var(object):
   that dominate (the input gradient of the next 1x1 convolution, which adds it in its epilogue, and the batch-norm
   backward of a projection shortcut) read (dy, mask) directly, so dz is never written; anything else just reads
   ``.grad``, which materialises it."""
-  __slots__ = ('data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'fuse_dgrad', 'pending')
+  __slots__ = ('data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'fuse_dgrad', 'pending', 'bn_ctx',
+               'pre_dy')
 
   def __init__(self, data, shape=None, needs_grad=True):
     self.data = data
@@ -243,6 +249,11 @@ class Var(object):
     # computes inside its own launch
     self.fuse_dgrad = False
     self.pending = None
+    # projection-shortcut fusion: the output of a ReLU-less conv + batch norm carries what its BN backward needs (bn_ctx);
+    # the block-final layer that adds it behind one ReLU then runs BOTH batch-norm backwards in one reduce + one apply
+    # (ops.bn_bwd_dual) and leaves this layer's dy here (pre_dy)
+    self.bn_ctx = None
+    self.pre_dy = None
 
   @property
   def grad(self):
@@ -537,11 +548,21 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
     out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, rm, relu, d.Ho, d.Wo), None
   out = Var(out_t)
   out.fuse_dgrad = dense and taped
+  if taped and ctx.training and not small and not relu and residual is None:
+    out.bn_ctx = (y, gamma, mean, invstd, bn, M, Cn)
 
   if ctx.tape is not None:
     x_t = x.data
 
     def bwd():
+      if out.pre_dy is not None:      # projection shortcut: the block-final layer already ran this batch norm's backward
+        dy, out.pre_dy = out.pre_dy, None
+        a.notify_grad(bn.gamma)
+        xg, xmask = x.take_masked_grad()
+        dx = conv.backward(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask)
+        if dx is not None:
+          x.grad, x.grad_owned = dx, True
+        return
       if out.pending is not None:     # fused squeeze layer: (input gradient of the one consumer) + this BN's backward, one launch
         d_next, dy_next, wt_next = out.pending
         out.pending = None
@@ -567,13 +588,25 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
       # BigLittle merge (res_mode 2): the 2x2 block sum reads (dout, mask) as well, so dz is not written there either
       lazy_up = LAZY_DZ and residual is not None and relu and res_mode == 2 and mask_t is not None
       want_dz = residual is not None and relu and not lazy and not lazy_up
+      rc = residual.bn_ctx if residual is not None else None
+      dual = (lazy and rc is not None and residual._grad is None and residual.pre_dy is None and rc[5] == M and rc[6] == Cn
+              and in_mask is None and dual_bn_on())
       if small:
         dy, dz = ops.bn_small_bwd(dout, y, bmask, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta)), None
+      elif dual:
+        # out = relu(bn(y) + bn_sc(y_sc)): both batch norms see the same masked gradient -> one reduce, one apply
+        sc_bn = rc[4]
+        dy, residual.pre_dy = ops.bn_bwd_dual(dout, y, rc[0], mask_t, M, Cn,
+                                              (gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta)),
+                                              (rc[1], rc[2], rc[3], a.g(sc_bn.gamma), a.g(sc_bn.beta)))
+        dz = None
       else:
         dy, dz = ops.bn_bwd(dout, y, bmask, brelu, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), want_dz)
       a.notify_grad(bn.gamma)
       if residual is not None:
-        if lazy:           # dz = dout * mask is NOT written: the shortcut branch receives (dout, mask)
+        if dual:
+          pass             # the shortcut layer's gradient is complete: its dy waits in residual.pre_dy
+        elif lazy:           # dz = dout * mask is NOT written: the shortcut branch receives (dout, mask)
           accum_grad(residual, dout, False, mask=mask_t)
         else:
           dres = dz if relu else dout

@@ -387,6 +387,28 @@ def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz
   return dx, dz
 
 
+def bn_bwd_dual(dy, xa, xb, mask, M, Cn, bn_a, bn_b):
+  """Backward of out = relu(bn_a(xa) + bn_b(xb)) from the un-masked gradient dy and the packed ReLU mask of out, both
+  batch norms in one reduce + one apply.  bn_x = (gamma, mean, invstd, dgamma, dbeta) -> (dxa, dxb)."""
+  ev = _bn_ev(M * Cn * (2 * 6.0 + 4.0 + 2 * 0.125))
+  blocks = L().asm_bn_stats_blocks(M, Cn)
+  pa, pb = empty((blocks, 2, Cn), F32, dy), empty((blocks, 2, Cn), F32, dy)
+  check(L().asm_bn_bwd_reduce2(_ptr(dy), _ptr(xa), _ptr(xb), _ptr(mask), M, Cn, _ptr(bn_a[1]), _ptr(bn_a[2]),
+                               _ptr(bn_b[1]), _ptr(bn_b[2]), _ptr(pa), _ptr(pb), _stream()), 'bn_bwd_reduce2')
+  co = empty((6, Cn), F32, dy)
+  for i, (part, (gamma, mean, invstd, dgamma, dbeta)) in enumerate(((pa, bn_a), (pb, bn_b))):
+    part = _compact(part, Cn)
+    check(L().asm_bn_bwd_finalize(_ptr(part), part.shape[0], M, Cn, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma),
+                                  _ptr(dbeta), _ptr(co[3 * i]), _ptr(co[3 * i + 1]), _ptr(co[3 * i + 2]), _stream()),
+          'bn_bwd_finalize')
+  dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+  check(L().asm_bn_bwd_apply2(_ptr(dy), _ptr(xa), _ptr(xb), _ptr(mask), M, Cn, _ptr(co), _ptr(dxa), _ptr(dxb), _stream()),
+        'bn_bwd_apply2')
+  if ev is not None:
+    ev.record()
+  return dxa, dxb
+
+
 _SMALL_BN_ROWS = None
 
 

@@ -165,6 +165,16 @@ int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout, int relu, 
                      const float* coefA, const float* coefB, const float* coefC, void* dx,
                      void* dz_out, void* stream);
 
+/* Two batch norms behind one ReLU -- out = relu(bn_a(xa) + bn_b(xb)), the block-final and the projection-shortcut batch
+ * norm of a bottleneck (nets/resnet_model.py:92-96) -- share the masked gradient g = dy * [mask bit]: one reduce and one
+ * apply for both.  partial_a / partial_b: [asm_bn_stats_blocks(M, C)][2][C] (sum g, sum g * xhat), each finished by
+ * asm_bn_bwd_finalize; coef6 = [6][C]: coefA, coefB, coefC of a, then of b. */
+int asm_bn_bwd_reduce2(const void* dy, const void* xa, const void* xb, const uint8_t* relu_mask, int M, int C,
+                       const float* mean_a, const float* invstd_a, const float* mean_b, const float* invstd_b,
+                       float* partial_a, float* partial_b, void* stream);
+int asm_bn_bwd_apply2(const void* dy, const void* xa, const void* xb, const uint8_t* relu_mask, int M, int C,
+                      const float* coef6, void* dxa, void* dxb, void* stream);
+
 /* Small tensors (M <= asm_bn_small_max_rows(), e.g. the [N,1,1,d] squeeze layers of sk_conv2d / se_block,
  * nets/blocks.py:139-146): the whole training-mode batch norm in one launch per direction.
  * fwd: batch statistics of x (bf16-rounded, as above), moving-statistics update, mean / invstd out, y = bn(x) [relu],

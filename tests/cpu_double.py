@@ -246,6 +246,22 @@ class CpuDouble(object):
       st[b, 1] = (blk * blk).sum(0)
     return 0
 
+  def asm_bn_bwd_reduce2(self, dy, xa, xb, mask, M, Cn, mean_a, invstd_a, mean_b, invstd_b, pa, pb, stream):
+    for x, mean, invstd, part in ((xa, mean_a, invstd_a, pa), (xb, mean_b, invstd_b, pb)):
+      rc = self.asm_bn_bwd_reduce(dy, x, mask, 2, M, Cn, mean, invstd, part, stream)
+      if rc:
+        return rc
+    return 0
+
+  def asm_bn_bwd_apply2(self, dy, xa, xb, mask, M, Cn, coef6, dxa, dxb, stream):
+    f = C.sizeof(C.c_float)
+    for i, (x, dx) in enumerate(((xa, dxa), (xb, dxb))):
+      base = coef6 + 3 * i * Cn * f
+      rc = self.asm_bn_bwd_apply(dy, x, mask, 2, M, Cn, base, base + Cn * f, base + 2 * Cn * f, dx, None, stream)
+      if rc:
+        return rc
+    return 0
+
   def asm_bn_small_max_rows(self):
     return 4096
 

@@ -587,3 +587,29 @@ def test_dense_small_wgrad_vs_fp32_and_conv_kernel(hip_lib, M, Cin, Cout, ldy, m
     got[knob] = dw.cpu().view(Cout, Cin)
   assert util.rel_l2(got['1'], ref) <= 2e-6, util.rel_l2(got['1'], ref)
   assert util.rel_l2(got['0'], ref) <= 1e-4
+
+
+@pytest.mark.parametrize('M,Cn', [(2 * 28 * 28, 256), (1000, 72), (256 * 7 * 7, 2048), (3 * 56 * 56, 128)])
+def test_bn_bwd_dual_equals_two_separate_backwards(hip_lib, M, Cn):
+  """out = relu(bn_a(xa) + bn_b(xb)) (block-final + projection-shortcut batch norm): one reduce + one apply for both
+  == two asm_bn_bwd_reduce / finalize / apply chains on the same (dout, mask)."""
+  from assembled_cnn_amd import ops
+  g = torch.Generator(device='cuda').manual_seed(5)
+  xa = torch.randn((M, Cn), generator=g, device='cuda').to(BF)
+  xb = (torch.randn((M, Cn), generator=g, device='cuda') * 2 + 0.3).to(BF)
+  dy = torch.randn((M, Cn), generator=g, device='cuda').to(BF)
+  mask = torch.randint(0, 256, (M, Cn // 8), generator=g, device='cuda', dtype=torch.uint8)
+  bns = []
+  for x in (xa, xb):
+    gamma = torch.rand(Cn, generator=g, device='cuda') + 0.5
+    xf = x.float()
+    mean = xf.mean(0)
+    invstd = 1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)
+    bns.append((gamma, mean.contiguous(), invstd.contiguous()))
+  outs = [torch.empty(Cn, device='cuda') for _ in range(4)]
+  dxa, dxb = ops.bn_bwd_dual(dy, xa, xb, mask, M, Cn, bns[0] + (outs[0], outs[1]), bns[1] + (outs[2], outs[3]))
+  for x, (gamma, mean, invstd), dx, dg, db in ((xa, bns[0], dxa, outs[0], outs[1]), (xb, bns[1], dxb, outs[2], outs[3])):
+    dg2, db2 = torch.empty(Cn, device='cuda'), torch.empty(Cn, device='cuda')
+    dx2, _ = ops.bn_bwd(dy, x, mask, True, M, Cn, gamma, mean, invstd, dg2, db2, False)
+    _close(dx, dx2.float().cpu(), rel=1e-3, name='dual dx')
+    assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-3) and torch.allclose(db, db2, rtol=1e-4, atol=1e-3)
