@@ -565,6 +565,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const bf16_t* __rest
   }
 }
 
+// ---- forward twin of the pair above: out = [relu](bn_a(xa) + bf16(bn_b(xb))) in one pass -----------------------------
+// The projection-shortcut batch norm has no consumer but this add, so its normalised tensor need not exist in HBM: it is
+// evaluated on the fly (and rounded to bf16 exactly where the separate pass stored it: results are bit-identical).
+// Saves the 4 B / element the shortcut's own apply pass moved.  co = [4][C]: scale_a, shift_a, scale_b, shift_b.
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_apply2_kernel(const bf16_t* __restrict__ xa, const bf16_t* __restrict__ xb,
+                                                        bf16_t* __restrict__ y, size_t nvec, int C, FastDiv fd_vcols,
+                                                        const float* __restrict__ sa, const float* __restrict__ ha,
+                                                        const float* __restrict__ sb, const float* __restrict__ hb,
+                                                        uint8_t* __restrict__ mask) {
+  const int vcols = C >> 3;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const bool fixed = (stride % (size_t)vcols) == 0;   // see bn_apply_kernel
+  float k[4][8];
+  auto load_coef = [&](int vc) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      k[0][e] = sa[vc * 8 + e];
+      k[1][e] = ha[vc * 8 + e];
+      k[2][e] = sb[vc * 8 + e];
+      k[3][e] = hb[vc * 8 + e];
+    }
+  };
+  if (fixed) load_coef((int)(((size_t)blockIdx.x * 256 + threadIdx.x) % (size_t)vcols));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    float fa[8], fb[8];
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xa + i * 8)), fa);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xb + i * 8)), fb);
+    if (!fixed) {
+      const unsigned m = fd_div((unsigned)i, fd_vcols);
+      load_coef((int)((unsigned)i - m * (unsigned)vcols));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fb[e] = fb[e] * k[2][e] + k[3][e];
+    float rb[8];
+    unpack8(pack8(fb), rb);                 // the bf16 rounding of the materialised shortcut tensor
+    unsigned mk = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      fa[e] = fa[e] * k[0][e] + k[1][e] + rb[e];
+      if (RELU) {
+        mk |= (fa[e] > 0.f ? 1u : 0u) << e;
+        fa[e] = fmaxf(fa[e], 0.f);
+      }
+    }
+    if (RELU && mask) mask[i] = (uint8_t)mk;
+    __builtin_nontemporal_store(pack8(fa), reinterpret_cast<u32x4*>(y + i * 8));
+  }
+}
+
 // ---- small-tensor batch norm: statistics + finalize + apply in ONE launch (and reduce + finalize + apply backward) ----
 // The SK / SE squeeze layers normalise [N, 1, 1, d] tensors (256 x 32..256 elements): three to four ~5 us launches
 // of pure latency per direction in the general path.  Here one workgroup owns 64 channels x all M rows (M <= 4096):
@@ -903,5 +953,23 @@ extern "C" int asm_bn_bwd_apply2(const void* dy, const void* xa, const void* xb,
                      (const bf16_t*)xa, (const bf16_t*)xb, relu_mask, nvec, C, make_fastdiv((unsigned)(C / 8)), coef6,
                      (bf16_t*)dxa, (bf16_t*)dxb);
   ASM_CHECK_LAUNCH("bn_bwd_apply2");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_apply2(const void* xa, const void* xb, void* y, int M, int C, const float* scale_a,
+                             const float* shift_a, const float* scale_b, const float* shift_b, int relu,
+                             uint8_t* relu_mask_out, void* stream) {
+  ASM_REQUIRE(xa && xb && y && scale_a && shift_a && scale_b && shift_b && M > 0 && C > 0 && C % 8 == 0, "bn_apply2: bad arguments");
+  ASM_REQUIRE((size_t)M * (C / 8) < 0x7fffffffull, "bn_apply2: tensor too large");
+  const size_t nvec = (size_t)M * (C / 8);
+  const FastDiv fv = make_fastdiv((unsigned)(C / 8));
+  const dim3 grid(ew_grid(nvec)), block(256);
+  if (relu)
+    hipLaunchKernelGGL(bn_apply2_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)xa, (const bf16_t*)xb,
+                       (bf16_t*)y, nvec, C, fv, scale_a, shift_a, scale_b, shift_b, relu_mask_out);
+  else
+    hipLaunchKernelGGL(bn_apply2_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)xa, (const bf16_t*)xb,
+                       (bf16_t*)y, nvec, C, fv, scale_a, shift_a, scale_b, shift_b, nullptr);
+  ASM_CHECK_LAUNCH("bn_apply2");
   return ASM_OK;
 }

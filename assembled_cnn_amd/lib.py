@@ -139,6 +139,7 @@ SIGNATURES = {
     'asm_eval_accumulate': (_I, [_P, _P, _P, _I, _P, _P]),
     'asm_sgd_momentum': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P]),
     'asm_conv2d_fprop_bn': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'asm_bn_apply2': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     'asm_bn_bwd_reduce2': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'asm_bn_bwd_apply2': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     'asm_bn_small_max_rows': (_I, []),

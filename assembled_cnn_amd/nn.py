@@ -25,6 +25,8 @@ from . import ops
 BN_EPS = 1e-5  # nets/model_helper.py:26
 # ASM_LAZY_DZ=0: materialise the masked shortcut gradient dz in the BN backward apply (the pre-round-2 path; A/B runs)
 LAZY_DZ = os.environ.get('ASM_LAZY_DZ', '1') != '0'
+# ASM_BN_DEFER=0: a projection shortcut's batch norm is applied by its own pass (materialised) instead of inside the add
+DEFER_BN = os.environ.get('ASM_BN_DEFER', '1') != '0'
 
 
 def dual_bn_on() -> bool:
@@ -234,11 +236,15 @@ class Var(object):
   that dominate (the input gradient of the next 1x1 convolution, which adds it in its epilogue, and the batch-norm
   backward of a projection shortcut) read (dy, mask) directly, so dz is never written; anything else just reads
   ``.grad``, which materialises it."""
-  __slots__ = ('data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'fuse_dgrad', 'pending', 'bn_ctx',
-               'pre_dy')
+  __slots__ = ('_data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'fuse_dgrad', 'pending', 'bn_ctx',
+               'pre_dy', 'deferred')
 
   def __init__(self, data, shape=None, needs_grad=True):
-    self.data = data
+    self._data = data
+    # A ReLU-less conv + batch-norm output whose normalisation has NOT been applied yet: (y, M, C, scale, shift).  The
+    # block-final layer that adds it as the shortcut applies both batch norms in one pass (ops.bn_apply_dual); any other
+    # reader just touches .data, which runs the ordinary apply pass once.
+    self.deferred = None
     self.shape = tuple(data.shape) if data is not None else tuple(shape)
     self._grad = None
     self.grad_mask = None
@@ -254,6 +260,17 @@ class Var(object):
     # (ops.bn_bwd_dual) and leaves this layer's dy here (pre_dy)
     self.bn_ctx = None
     self.pre_dy = None
+
+  @property
+  def data(self):
+    if self._data is None and self.deferred is not None:
+      y, M, Cn, scale, shift = self.deferred
+      self._data = ops.bn_apply(y, M, Cn, scale, shift, None, 0, False)
+    return self._data
+
+  @data.setter
+  def data(self, t):
+    self._data = t
 
   @property
   def grad(self):
@@ -511,9 +528,11 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
   M = N * d.Ho * d.Wo
   Cn = conv.cout
   gamma, beta = a.w(bn.gamma), a.w(bn.beta)
-  res_t = residual.data if residual is not None else None
   taped = ctx.tape is not None
   rm = res_mode if residual is not None else 0
+  # the shortcut's batch norm rides in this layer's apply pass when nobody else has asked for its output
+  res_def = residual.deferred if (residual is not None and rm == 1 and residual._data is None and ctx.training) else None
+  res_t = residual.data if (residual is not None and res_def is None) else None
   # [N, 1, 1, d] squeeze layers (SK / SE fc): the whole BN is one launch per direction instead of 3-4 latency-bound ones
   small = ctx.training and residual is None and d.Ho * d.Wo == 1 and not conv.stem and ops.bn_small_ok(M)
   mask_t = None
@@ -540,13 +559,25 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
     mean = invstd = None
   if tap_pre is not None:
     ctx.taps[tap_pre] = y
+  defer = (DEFER_BN and ctx.training and not small and not relu and residual is None and tap_pre is None and Cn % 8 == 0)
   if small:
     pass
+  elif res_def is not None and res_def[1] == M and res_def[2] == Cn:
+    if taped and relu:
+      out_t, mask_t = ops.bn_apply_dual(y, res_def[0], M, Cn, scale, shift, res_def[3], res_def[4], True, want_mask=True)
+    else:
+      out_t, mask_t = ops.bn_apply_dual(y, res_def[0], M, Cn, scale, shift, res_def[3], res_def[4], relu), None
+  elif defer:
+    out_t = None
   elif taped and relu:   # keep the 1-bit ReLU mask for the backward kernels (16x less traffic than re-reading out)
-    out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, rm, True, d.Ho, d.Wo, want_mask=True)
+    out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, residual.data if residual is not None else None, rm, True,
+                                 d.Ho, d.Wo, want_mask=True)
   else:
-    out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, res_t, rm, relu, d.Ho, d.Wo), None
-  out = Var(out_t)
+    out_t, mask_t = ops.bn_apply(y, M, Cn, scale, shift, residual.data if residual is not None else None, rm, relu,
+                                 d.Ho, d.Wo), None
+  out = Var(out_t, out_shape)
+  if out_t is None:
+    out.deferred = (y, M, Cn, scale, shift)
   out.fuse_dgrad = dense and taped
   if taped and ctx.training and not small and not relu and residual is None:
     out.bn_ctx = (y, gamma, mean, invstd, bn, M, Cn)

@@ -387,6 +387,18 @@ def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz
   return dx, dz
 
 
+def bn_apply_dual(xa, xb, M, Cn, scale_a, shift_a, scale_b, shift_b, relu, want_mask=False):
+  """[relu](bn_a(xa) + bf16(bn_b(xb))) in one pass -> y, or (y, packed ReLU mask) with want_mask"""
+  y = torch.empty_like(xa)
+  mask = empty((M, Cn // 8), torch.uint8, xa) if (want_mask and relu) else None
+  ev = _bn_ev(M * Cn * (6.0 + (0.125 if mask is not None else 0.0)))
+  check(L().asm_bn_apply2(_ptr(xa), _ptr(xb), _ptr(y), M, Cn, _ptr(scale_a), _ptr(shift_a), _ptr(scale_b), _ptr(shift_b),
+                          1 if relu else 0, _ptr(mask), _stream()), 'bn_apply2')
+  if ev is not None:
+    ev.record()
+  return (y, mask) if want_mask else y
+
+
 def bn_bwd_dual(dy, xa, xb, mask, M, Cn, bn_a, bn_b):
   """Backward of out = relu(bn_a(xa) + bn_b(xb)) from the un-masked gradient dy and the packed ReLU mask of out, both
   batch norms in one reduce + one apply.  bn_x = (gamma, mean, invstd, dgamma, dbeta) -> (dxa, dxb)."""

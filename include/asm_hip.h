@@ -169,6 +169,10 @@ int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout, int relu, 
  * norm of a bottleneck (nets/resnet_model.py:92-96) -- share the masked gradient g = dy * [mask bit]: one reduce and one
  * apply for both.  partial_a / partial_b: [asm_bn_stats_blocks(M, C)][2][C] (sum g, sum g * xhat), each finished by
  * asm_bn_bwd_finalize; coef6 = [6][C]: coefA, coefB, coefC of a, then of b. */
+/* forward twin: y = [relu](xa * scale_a + shift_a + bf16(xb * scale_b + shift_b)) -- the shortcut's normalised tensor is
+ * evaluated on the fly (rounded to bf16 where the separate asm_bn_apply pass stored it: bit-identical results) */
+int asm_bn_apply2(const void* xa, const void* xb, void* y, int M, int C, const float* scale_a, const float* shift_a,
+                  const float* scale_b, const float* shift_b, int relu, uint8_t* relu_mask_out, void* stream);
 int asm_bn_bwd_reduce2(const void* dy, const void* xa, const void* xb, const uint8_t* relu_mask, int M, int C,
                        const float* mean_a, const float* invstd_a, const float* mean_b, const float* invstd_b,
                        float* partial_a, float* partial_b, void* stream);

@@ -246,6 +246,13 @@ class CpuDouble(object):
       st[b, 1] = (blk * blk).sum(0)
     return 0
 
+  def asm_bn_apply2(self, xa, xb, y, M, Cn, sa, ha, sb, hb, relu, mask, stream):
+    zb = torch.empty((M, Cn), dtype=torch.bfloat16)
+    rc = self.asm_bn_apply(xb, zb.data_ptr(), M, Cn, sb, hb, None, 0, 0, 0, 0, None, stream)
+    if rc:
+      return rc
+    return self.asm_bn_apply(xa, y, M, Cn, sa, ha, zb.data_ptr(), 1, relu, 0, 0, mask, stream)
+
   def asm_bn_bwd_reduce2(self, dy, xa, xb, mask, M, Cn, mean_a, invstd_a, mean_b, invstd_b, pa, pb, stream):
     for x, mean, invstd, part in ((xa, mean_a, invstd_a, pa), (xb, mean_b, invstd_b, pb)):
       rc = self.asm_bn_bwd_reduce(dy, x, mask, 2, M, Cn, mean, invstd, part, stream)

@@ -613,3 +613,22 @@ def test_bn_bwd_dual_equals_two_separate_backwards(hip_lib, M, Cn):
     dx2, _ = ops.bn_bwd(dy, x, mask, True, M, Cn, gamma, mean, invstd, dg2, db2, False)
     _close(dx, dx2.float().cpu(), rel=1e-3, name='dual dx')
     assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-3) and torch.allclose(db, db2, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('M,Cn,relu', [(2 * 28 * 28, 256, True), (1000, 72, True), (3 * 56 * 56, 128, False)])
+def test_bn_apply_dual_is_bit_identical_to_two_passes(hip_lib, M, Cn, relu):
+  """[relu](bn_a(xa) + bf16(bn_b(xb))) in one pass == asm_bn_apply(xb) followed by asm_bn_apply(xa, residual)"""
+  from assembled_cnn_amd import ops
+  g = torch.Generator(device='cuda').manual_seed(9)
+  xa = torch.randn((M, Cn), generator=g, device='cuda').to(BF)
+  xb = (torch.randn((M, Cn), generator=g, device='cuda') * 2 + 0.3).to(BF)
+  co = [torch.randn(Cn, generator=g, device='cuda') * 0.5 + (1.0 if i % 2 == 0 else 0.0) for i in range(4)]
+  zb = ops.bn_apply(xb, M, Cn, co[2], co[3], relu=False)
+  if relu:
+    y1, m1 = ops.bn_apply(xa, M, Cn, co[0], co[1], zb, 1, True, want_mask=True)
+    y2, m2 = ops.bn_apply_dual(xa, xb, M, Cn, co[0], co[1], co[2], co[3], True, want_mask=True)
+    assert torch.equal(m1, m2)
+  else:
+    y1 = ops.bn_apply(xa, M, Cn, co[0], co[1], zb, 1, False)
+    y2 = ops.bn_apply_dual(xa, xb, M, Cn, co[0], co[1], co[2], co[3], False)
+  assert torch.equal(y1, y2)
