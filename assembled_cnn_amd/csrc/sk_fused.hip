@@ -48,24 +48,76 @@ __device__ __forceinline__ void gate8(const float* __restrict__ att, int n, int 
   }
 }
 
-// ---- s[n][c] = mean_hw( f0 + f1 ) ----------------------------------------------------------------------------------
+// Cross-row-lane sum of 8 per-thread values: red[thread][0..7] -> `out` in the rl == 0 thread of each vector column.
 template <int NT>
-__global__ __launch_bounds__(NT) void sk_gap_bn_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+__device__ __forceinline__ void lane_sum8(float (*red)[9], const float* v, float* out, int vcb, int vcl, int nrl, bool leader) {
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = v[e];
+  __syncthreads();
+  if (leader) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      for (int r = 0; r < nrl; ++r) t += red[r * vcb + vcl][e];
+      out[e] = t;
+    }
+  }
+}
+
+// f, its ReLU mask ([y * sc + sh > 0], as in the backward kernels) and the masked raw value of 8 channels of y.  The
+// statistics are sums of mask and mask * y (and the same times dV); xhat = (y - mean) / sigma is affine in y, so the
+// finalize turns them into the xhat sums per image -- the streaming loops carry no mean / sigma registers.
+__device__ __forceinline__ void bnrelu8m(const u32x4& vy, const Coef8& k, float* f, float* m, float* my) {
+  float y[8];
+  unpack8(vy, y);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float t = y[e] * k.sc[e] + k.sh[e];
+    f[e] = rbf(fmaxf(t, 0.f));
+    m[e] = t > 0.f ? 1.f : 0.f;
+    my[e] = t > 0.f ? y[e] : 0.f;
+  }
+}
+
+// ---- s[n][c] = mean_hw( f0 + f1 ) ----------------------------------------------------------------------------------
+// ST: also the per-image mask statistics the factorised batch-norm backward needs (see sk_bn_bwd_finalize_kernel):
+//     stats[n][0][ch] = sum_hw [f > 0],  stats[n][1][ch] = sum_hw [f > 0] * y     (ch over the 2F conv channels)
+template <int NT, bool ST>
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void sk_gap_bn_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, bf16_t* __restrict__ s, int HW,
-                                                       int F, int vcb) {
+                                                       int F, int vcb, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, float* __restrict__ stats) {
   __shared__ float red[NT][9];
   const int vcols = F >> 3;
   const int vcl = threadIdx.x % vcb, rl = threadIdx.x / vcb, nrl = NT / vcb;
   const int vc = blockIdx.x * vcb + vcl;
   const int n = blockIdx.y;
-  float acc[8];
+  float acc[8], c0[8], x0[8], c1[8], x1[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int e = 0; e < 8; ++e) acc[e] = c0[e] = x0[e] = c1[e] = x1[e] = 0.f;
   if (vc < vcols && rl < nrl) {
     Coef8 k0, k1;
     load_coef(scale, shift, vc * 8, k0);
     load_coef(scale, shift, F + vc * 8, k1);
-    constexpr int U = 4;
+    auto consume = [&](const u32x4& v, const u32x4& w) {
+      if (ST) {
+        float f[8], m[8], my[8];
+        bnrelu8m(v, k0, f, m, my);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] += f[e]; c0[e] += m[e]; x0[e] += my[e]; }
+        bnrelu8m(w, k1, f, m, my);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] += f[e]; c1[e] += m[e]; x1[e] += my[e]; }
+      } else {
+        float f0[8], f1[8];
+        bnrelu8(v, k0, f0);
+        bnrelu8(w, k1, f1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += f0[e] + f1[e];
+      }
+    };
+    constexpr int U = ST ? 2 : 4;   // the statistics variant carries 40 accumulators: fewer vectors in flight, same occupancy
     const bf16_t* base = y + (size_t)n * HW * 2 * F + vc * 8;
     int r = rl;
     for (; r + (U - 1) * nrl < HW; r += U * nrl) {
@@ -77,36 +129,34 @@ __global__ __launch_bounds__(NT) void sk_gap_bn_kernel(const bf16_t* __restrict_
         w[u] = ldv(base, off + F);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        float f0[8], f1[8];
-        bnrelu8(v[u], k0, f0);
-        bnrelu8(w[u], k1, f1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += f0[e] + f1[e];
-      }
+      for (int u = 0; u < U; ++u) consume(v[u], w[u]);
     }
     for (; r < HW; r += nrl) {
       const size_t off = (size_t)r * 2 * F;
-      float f0[8], f1[8];
-      bnrelu8(ldv(base, off), k0, f0);
-      bnrelu8(ldv(base, off + F), k1, f1);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += f0[e] + f1[e];
+      consume(ldv(base, off), ldv(base, off + F));
     }
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
-  __syncthreads();
-  if (rl == 0 && vc < vcols) {
-    float o[8];
+  const bool leader = rl == 0 && vc < vcols;
+  float o[8];
+  lane_sum8<NT>(red, acc, o, vcb, vcl, nrl, leader);
+  if (leader) {
     const float inv = 1.0f / (float)HW;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = 0.f;
-      for (int r = 0; r < nrl; ++r) t += red[r * vcb + vcl][e];
-      o[e] = t * inv;
-    }
+    for (int e = 0; e < 8; ++e) o[e] *= inv;
     *reinterpret_cast<u32x4*>(s + (size_t)n * F + vc * 8) = pack8(o);
+  }
+  if (ST) {
+    float* st = stats + (size_t)n * 4 * F;     // [2][2F]
+    const float* src[4] = {c0, c1, x0, x1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      lane_sum8<NT>(red, src[q], o, vcb, vcl, nrl, leader);
+      if (leader) {
+        float* dst = st + (q >> 1) * 2 * F + (q & 1) * F + vc * 8;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
+    }
   }
 }
 
@@ -137,24 +187,46 @@ __global__ __launch_bounds__(256) void sk_select_bn_fwd_kernel(const bf16_t* __r
 }
 
 // ---- datt[n][c] = a0 a1 sum_hw (f0 - f1) dV ;  datt[n][F + c] = -that ----------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(NT) void sk_bn_bwd_att_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+// ST: also the per-image gradient statistics of the factorised batch-norm backward:
+//     stats[n][0][ch] = sum_hw [f > 0] dV,  stats[n][1][ch] = sum_hw [f > 0] dV y    (ch over the 2F conv channels)
+template <int NT, bool ST>
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void sk_bn_bwd_att_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const bf16_t* __restrict__ dv,
                                                            const float* __restrict__ att, bf16_t* __restrict__ datt,
-                                                           int HW, int F, int vcb) {
+                                                           int HW, int F, int vcb, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* __restrict__ stats) {
   __shared__ float red[NT][9];
   const int vcols = F >> 3;
   const int vcl = threadIdx.x % vcb, rl = threadIdx.x / vcb, nrl = NT / vcb;
   const int vc = blockIdx.x * vcb + vcl;
   const int n = blockIdx.y;
-  float acc[8];
+  float acc[8], g0[8], x0[8], g1[8], x1[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int e = 0; e < 8; ++e) acc[e] = g0[e] = x0[e] = g1[e] = x1[e] = 0.f;
   if (vc < vcols && rl < nrl) {
     Coef8 k0, k1;
     load_coef(scale, shift, vc * 8, k0);
     load_coef(scale, shift, F + vc * 8, k1);
-    constexpr int U = 2;
+    auto consume = [&](const u32x4& v0, const u32x4& v1, const u32x4& vg) {
+      float g[8];
+      unpack8(vg, g);
+      if (ST) {
+        float f[8], m[8], my[8];
+        bnrelu8m(v0, k0, f, m, my);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] += f[e] * g[e]; g0[e] += m[e] * g[e]; x0[e] += my[e] * g[e]; }
+        bnrelu8m(v1, k1, f, m, my);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] -= f[e] * g[e]; g1[e] += m[e] * g[e]; x1[e] += my[e] * g[e]; }
+      } else {
+        float f0[8], f1[8];
+        bnrelu8(v0, k0, f0);
+        bnrelu8(v1, k1, f1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (f0[e] - f1[e]) * g[e];
+      }
+    };
+    constexpr int U = ST ? 1 : 2;
     int r = rl;
     for (; r + (U - 1) * nrl < HW; r += U * nrl) {
       u32x4 v0[U], v1[U], vg[U];
@@ -166,40 +238,39 @@ __global__ __launch_bounds__(NT) void sk_bn_bwd_att_kernel(const bf16_t* __restr
         vg[u] = ldv(dv, m * F + vc * 8);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        float f0[8], f1[8], g[8];
-        bnrelu8(v0[u], k0, f0);
-        bnrelu8(v1[u], k1, f1);
-        unpack8(vg[u], g);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (f0[e] - f1[e]) * g[e];
-      }
+      for (int u = 0; u < U; ++u) consume(v0[u], v1[u], vg[u]);
     }
     for (; r < HW; r += nrl) {
       const size_t m = (size_t)n * HW + r;
-      float f0[8], f1[8], g[8];
-      bnrelu8(ldv(y, m * 2 * F + vc * 8), k0, f0);
-      bnrelu8(ldv(y, m * 2 * F + F + vc * 8), k1, f1);
-      unpack8(ldv(dv, m * F + vc * 8), g);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (f0[e] - f1[e]) * g[e];
+      consume(ldv(y, m * 2 * F + vc * 8), ldv(y, m * 2 * F + F + vc * 8), ldv(dv, m * F + vc * 8));
     }
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
-  __syncthreads();
-  if (rl == 0 && vc < vcols) {
+  const bool leader = rl == 0 && vc < vcols;
+  float o[8];
+  lane_sum8<NT>(red, acc, o, vcb, vcl, nrl, leader);
+  if (leader) {
     float a0[8], d0[8], d1[8];
     gate8(att, n, F, vc * 8, a0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t = 0.f;
-      for (int r = 0; r < nrl; ++r) t += red[r * vcb + vcl][e];
-      d0[e] = a0[e] * (1.0f - a0[e]) * t;
+      d0[e] = a0[e] * (1.0f - a0[e]) * o[e];
       d1[e] = -d0[e];
     }
     *reinterpret_cast<u32x4*>(datt + (size_t)n * 2 * F + vc * 8) = pack8(d0);
     *reinterpret_cast<u32x4*>(datt + (size_t)n * 2 * F + F + vc * 8) = pack8(d1);
+  }
+  if (ST) {
+    float* st = stats + (size_t)n * 4 * F;     // [2][2F]
+    const float* src[4] = {g0, g1, x0, x1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      lane_sum8<NT>(red, src[q], o, vcb, vcl, nrl, leader);
+      if (leader) {
+        float* dst = st + (q >> 1) * 2 * F + (q & 1) * F + vc * 8;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
+    }
   }
 }
 
@@ -301,6 +372,63 @@ __global__ __launch_bounds__(256) void sk_bn_bwd_reduce_kernel(const bf16_t* __r
   }
 }
 
+// ---- factorised reduce + finalize ---------------------------------------------------------------------------------------
+// dz = [f > 0] (a_b dV + ds / HW) with a_b and ds constant over an image, so the two batch-norm backward sums are
+//   sum dz      = sum_n  a_b[n] * G0[n] + (ds[n] / HW) * M0[n]          G0 = sum_hw [f>0] dV        M0 = sum_hw [f>0]
+//   sum dz xhat = sum_n  a_b[n] * G1[n] + (ds[n] / HW) * M1[n]          G1 = sum_hw [f>0] dV xhat   M1 = sum_hw [f>0] xhat
+// (the passes accumulate y in place of xhat = (y - mean) / sigma, which is affine in y: mean and sigma enter here)
+// G comes out of the gate-gradient pass (which reads y and dV anyway), M out of the forward pooled-sum pass: the reduce
+// pass over the whole tensor (y and dV once more) disappears.  One block = 16 channels x 64 image lanes, fp64 sums.
+__global__ __launch_bounds__(1024) void sk_bn_bwd_finalize_kernel(const float* __restrict__ gst, const float* __restrict__ mst,
+                                                                  const float* __restrict__ att, const bf16_t* __restrict__ ds,
+                                                                  int N, int HW, int F, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, float* dgamma,
+                                                                  float* dbeta, float* coefA, float* coefB, float* coefC) {
+  __shared__ double red[2][64][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int C2 = 2 * F;
+  const int ch = blockIdx.x * 16 + cx;
+  double s0 = 0.0, s1 = 0.0;
+  if (ch < C2) {
+    const int b = ch >= F ? 1 : 0, c = ch - b * F;
+    const float inv = 1.0f / (float)HW;
+    for (int n = ry; n < N; n += 64) {
+      const float l0 = att[(size_t)n * C2 + c], l1 = att[(size_t)n * C2 + F + c];
+      const float a0 = 1.0f / (1.0f + __expf(l1 - l0));
+      const float ab = b ? (1.0f - a0) : a0;
+      const float u = bf2f(ds[(size_t)n * F + c]) * inv;
+      const float* gs = gst + (size_t)n * 2 * C2;
+      const float* ms = mst + (size_t)n * 2 * C2;
+      const double g0 = gs[ch], m0 = ms[ch];
+      const double w = (double)ab * g0 + (double)u * m0;                               // sum_hw dz of this image
+      s0 += w;
+      s1 += (double)ab * (double)gs[C2 + ch] + (double)u * (double)ms[C2 + ch];        // sum_hw dz * y
+      s1 -= (double)mean[ch] * w;                                                       // -> sum_hw dz * (y - mean)
+    }
+    s1 *= (double)invstd[ch];     // xhat = (y - mean) * invstd
+  }
+  red[0][ry][cx] = s0;
+  red[1][ry][cx] = s1;
+  __syncthreads();
+  if (ry == 0 && ch < C2) {
+    double db = 0.0, dg = 0.0;
+    for (int r = 0; r < 64; ++r) {
+      db += red[0][r][cx];
+      dg += red[1][r][cx];
+    }
+    dbeta[ch] = (float)db;
+    dgamma[ch] = (float)dg;
+    const double M = (double)N * (double)HW;
+    const double g = gamma[ch], is = invstd[ch], mu = mean[ch];
+    const double A = g * is;
+    const double B = -g * is * is * dg / M;
+    coefA[ch] = (float)A;
+    coefB[ch] = (float)B;
+    coefC[ch] = (float)(-g * is * db / M - B * mu);
+  }
+}
+
 // pass 2: dy = A * dz + B * y + C   (coefficients from asm_bn_bwd_finalize)
 // Same (chunk, image) x (vector column, row lane) decomposition as the reducer: a thread keeps its 8 channels, so the
 // gates, ds / HW and the five per-channel coefficient vectors are loaded ONCE and the loop streams y, dV -> dy (the
@@ -382,19 +510,32 @@ SkBnGeom make_geom(int N, int HW, int F) {
   ASM_REQUIRE(N > 0 && HW > 0 && F > 0 && F % 8 == 0 && 2 * F / 8 <= 256, name ": bad shape (N=%d HW=%d F=%d)", N, HW, F); \
   ASM_REQUIRE((size_t)N * HW * (2 * F / 8) < 0x7fffffffull, name ": tensor too large for 32-bit indexing")
 
-extern "C" int asm_sk_gap_bn(const void* y, const float* scale, const float* shift, void* s, int N, int HW, int F,
-                             void* stream) {
+static int sk_gap_bn_impl(const void* y, const float* scale, const float* shift, void* s, int N, int HW, int F,
+                          const float* mean, const float* invstd, float* stats, void* stream) {
   SKF_OK("sk_gap_bn");
   ASM_REQUIRE(y && scale && shift && s, "sk_gap_bn: null pointer");
   const int vcb = F / 8 < 32 ? F / 8 : 32;
-  if (HW >= 512)
-    hipLaunchKernelGGL(sk_gap_bn_kernel<1024>, dim3(cdiv(F / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
-                       (const bf16_t*)y, scale, shift, (bf16_t*)s, HW, F, vcb);
-  else
-    hipLaunchKernelGGL(sk_gap_bn_kernel<256>, dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)y, scale, shift, (bf16_t*)s, HW, F, vcb);
+  const dim3 grid(cdiv(F / 8, vcb), N);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_GAP(NT, ST)                                                                                       \
+  hipLaunchKernelGGL((sk_gap_bn_kernel<NT, ST>), grid, dim3(NT), 0, st, (const bf16_t*)y, scale, shift, (bf16_t*)s, HW, F, \
+                     vcb, mean, invstd, stats)
+  if (stats) { if (HW >= 512) LAUNCH_GAP(1024, true); else LAUNCH_GAP(256, true); }
+  else { if (HW >= 512) LAUNCH_GAP(1024, false); else LAUNCH_GAP(256, false); }
+#undef LAUNCH_GAP
   ASM_CHECK_LAUNCH("sk_gap_bn");
   return ASM_OK;
+}
+
+extern "C" int asm_sk_gap_bn(const void* y, const float* scale, const float* shift, void* s, int N, int HW, int F,
+                             void* stream) {
+  return sk_gap_bn_impl(y, scale, shift, s, N, HW, F, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int asm_sk_gap_bn_stats(const void* y, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, void* s, float* mask_stats, int N, int HW, int F, void* stream) {
+  ASM_REQUIRE(mean && invstd && mask_stats, "sk_gap_bn_stats: null pointer");
+  return sk_gap_bn_impl(y, scale, shift, s, N, HW, F, mean, invstd, mask_stats, stream);
 }
 
 extern "C" int asm_sk_select_bn_fwd(const void* y, const float* scale, const float* shift, const float* att, void* v,
@@ -408,18 +549,44 @@ extern "C" int asm_sk_select_bn_fwd(const void* y, const float* scale, const flo
   return ASM_OK;
 }
 
-extern "C" int asm_sk_select_bn_bwd_att(const void* y, const float* scale, const float* shift, const void* dv,
-                                        const float* att, void* datt, int N, int HW, int F, void* stream) {
+static int sk_att_impl(const void* y, const float* scale, const float* shift, const void* dv, const float* att, void* datt,
+                       int N, int HW, int F, const float* mean, const float* invstd, float* stats, void* stream) {
   SKF_OK("sk_select_bn_bwd_att");
   ASM_REQUIRE(y && scale && shift && dv && att && datt, "sk_select_bn_bwd_att: null pointer");
   const int vcb = F / 8 < 32 ? F / 8 : 32;
-  if (HW >= 512)
-    hipLaunchKernelGGL(sk_bn_bwd_att_kernel<1024>, dim3(cdiv(F / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
-                       (const bf16_t*)y, scale, shift, (const bf16_t*)dv, att, (bf16_t*)datt, HW, F, vcb);
-  else
-    hipLaunchKernelGGL(sk_bn_bwd_att_kernel<256>, dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)y, scale, shift, (const bf16_t*)dv, att, (bf16_t*)datt, HW, F, vcb);
+  const dim3 grid(cdiv(F / 8, vcb), N);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_ATT(NT, ST)                                                                                          \
+  hipLaunchKernelGGL((sk_bn_bwd_att_kernel<NT, ST>), grid, dim3(NT), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)dv, \
+                     att, (bf16_t*)datt, HW, F, vcb, mean, invstd, stats)
+  if (stats) { if (HW >= 512) LAUNCH_ATT(1024, true); else LAUNCH_ATT(256, true); }
+  else { if (HW >= 512) LAUNCH_ATT(1024, false); else LAUNCH_ATT(256, false); }
+#undef LAUNCH_ATT
   ASM_CHECK_LAUNCH("sk_select_bn_bwd_att");
+  return ASM_OK;
+}
+
+extern "C" int asm_sk_select_bn_bwd_att(const void* y, const float* scale, const float* shift, const void* dv,
+                                        const float* att, void* datt, int N, int HW, int F, void* stream) {
+  return sk_att_impl(y, scale, shift, dv, att, datt, N, HW, F, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int asm_sk_select_bn_bwd_att_stats(const void* y, const float* scale, const float* shift, const float* mean,
+                                              const float* invstd, const void* dv, const float* att, void* datt,
+                                              float* grad_stats, int N, int HW, int F, void* stream) {
+  ASM_REQUIRE(mean && invstd && grad_stats, "sk_select_bn_bwd_att_stats: null pointer");
+  return sk_att_impl(y, scale, shift, dv, att, datt, N, HW, F, mean, invstd, grad_stats, stream);
+}
+
+extern "C" int asm_sk_bn_bwd_finalize(const float* grad_stats, const float* mask_stats, const float* att, const void* ds,
+                                      int N, int HW, int F, const float* gamma, const float* mean, const float* invstd,
+                                      float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC, void* stream) {
+  SKF_OK("sk_bn_bwd_finalize");
+  ASM_REQUIRE(grad_stats && mask_stats && att && ds && gamma && mean && invstd && dgamma && dbeta && coefA && coefB && coefC,
+              "sk_bn_bwd_finalize: null pointer");
+  hipLaunchKernelGGL(sk_bn_bwd_finalize_kernel, dim3(cdiv(2 * F, 16)), dim3(1024), 0, (hipStream_t)stream, grad_stats,
+                     mask_stats, att, (const bf16_t*)ds, N, HW, F, gamma, mean, invstd, dgamma, dbeta, coefA, coefB, coefC);
+  ASM_CHECK_LAUNCH("sk_bn_bwd_finalize");
   return ASM_OK;
 }
 

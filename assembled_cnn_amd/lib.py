@@ -110,6 +110,9 @@ SIGNATURES = {
     'asm_sk_gap_bn': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'asm_sk_select_bn_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'asm_sk_select_bn_bwd_att': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_gap_bn_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_select_bn_bwd_att_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_bn_bwd_finalize': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_sk_bn_bwd_blocks': (_I, [_I, _I, _I]),
     'asm_sk_bn_bwd_reduce': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'asm_sk_bn_bwd_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -744,7 +744,14 @@ class SKUnit(object):
     y, part = conv.fprop(d, x.data, True)                               # conv + fused statistics :115-118
     mean, invstd, scale, shift = ops.bn_finalize(part, M, C2, gamma, beta, BN_EPS, ctx.bn_momentum, a.st(bn.mm),
                                                  a.st(bn.mv))
-    s = Var(ops.sk_gap_bn(y, scale, shift, F_))                         # mean_hw(f0 + f1)  :131-134
+    # factorised BN backward (csrc/sk_fused.hip): the pooled-sum pass and the gate-gradient pass also emit per-image
+    # statistics, from which the batch-norm reduction follows without another pass over y and dV (ASM_SK_FACTOR=0: off)
+    factor = ctx.tape is not None and os.environ.get('ASM_SK_FACTOR', '1') != '0'
+    if factor:
+      s_t, mask_stats = ops.sk_gap_bn(y, scale, shift, F_, mean, invstd)
+      s = Var(s_t)
+    else:
+      s = Var(ops.sk_gap_bn(y, scale, shift, F_))                       # mean_hw(f0 + f1)  :131-134
     z = conv_bn(ctx, s, self.fc1, self.bn1, 1, relu=True)               # :137-143
     att, fc2_bwd, _ = conv_plain(ctx, z, self.fc2, out_f32=True)         # :144-148 (fp32 logits)
     v = Var(ops.sk_select_bn_fwd(y, scale, shift, att, F_))             # :149-152
@@ -756,10 +763,14 @@ class SKUnit(object):
         dv = v.grad
         if dv is None:
           raise RuntimeError('sk unit backward: no gradient reached this layer')
-        datt = ops.sk_select_bn_bwd_att(y, scale, shift, dv, att, F_)
+        if factor:
+          datt, grad_stats = ops.sk_select_bn_bwd_att(y, scale, shift, dv, att, F_, mean, invstd)
+        else:
+          datt, grad_stats = ops.sk_select_bn_bwd_att(y, scale, shift, dv, att, F_), None
         fc2_bwd(datt)                      # -> z.grad
         bwd_z()                            # -> s.grad
-        dy = ops.sk_bn_bwd(dv, att, s.grad, y, scale, shift, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), F_)
+        dy = ops.sk_bn_bwd(dv, att, s.grad, y, scale, shift, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), F_,
+                           grad_stats, mask_stats if factor else None)
         s.grad = None
         a.notify_grad(bn.gamma)
         dx = conv.backward(d, x_t, dy, x.needs_grad, addend=x.grad)     # fan-in add fused into the dgrad epilogue

@@ -561,9 +561,15 @@ def sk_select_bwd_f(dv, att, ds, F_):
 
 
 # fused form: the 3x3 convolution's batch norm + ReLU applied on the fly (y = conv output [N,H,W,2F], never normalised in HBM)
-def sk_gap_bn(y, scale, shift, F_):
+def sk_gap_bn(y, scale, shift, F_, mean=None, invstd=None):
+  """-> s, or with (mean, invstd): (s, per-image mask statistics [N, 2, 2F] f32 for the factorised BN backward)"""
   N, H, W, _ = y.shape
   s = empty((N, 1, 1, F_), BF16, y)
+  if mean is not None:
+    st = empty((N, 2, 2 * F_), F32, y)
+    check(L().asm_sk_gap_bn_stats(_ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(s), _ptr(st), N, H * W,
+                                  F_, _stream()), 'sk_gap_bn_stats')
+    return s, st
   check(L().asm_sk_gap_bn(_ptr(y), _ptr(scale), _ptr(shift), _ptr(s), N, H * W, F_, _stream()), 'sk_gap_bn')
   return s
 
@@ -576,18 +582,37 @@ def sk_select_bn_fwd(y, scale, shift, att, F_):
   return v
 
 
-def sk_select_bn_bwd_att(y, scale, shift, dv, att, F_):
+def sk_select_bn_bwd_att(y, scale, shift, dv, att, F_, mean=None, invstd=None):
+  """-> datt, or with (mean, invstd): (datt, per-image gradient statistics [N, 2, 2F] f32)"""
   N, H, W, _ = y.shape
   datt = empty((N, 1, 1, 2 * F_), BF16, y)
+  if mean is not None:
+    st = empty((N, 2, 2 * F_), F32, y)
+    check(L().asm_sk_select_bn_bwd_att_stats(_ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(dv), _ptr(att),
+                                             _ptr(datt), _ptr(st), N, H * W, F_, _stream()), 'sk_select_bn_bwd_att_stats')
+    return datt, st
   check(L().asm_sk_select_bn_bwd_att(_ptr(y), _ptr(scale), _ptr(shift), _ptr(dv), _ptr(att), _ptr(datt), N, H * W, F_,
                                      _stream()), 'sk_select_bn_bwd_att')
   return datt
 
 
-def sk_bn_bwd(dv, att, ds, y, scale, shift, gamma, mean, invstd, dgamma, dbeta, F_):
-  """BN backward of the SK unit's 2F-channel batch norm from dV (df is rebuilt in registers) -> dy [N,H,W,2F]."""
+def sk_bn_bwd(dv, att, ds, y, scale, shift, gamma, mean, invstd, dgamma, dbeta, F_, grad_stats=None, mask_stats=None):
+  """BN backward of the SK unit's 2F-channel batch norm from dV (df is rebuilt in registers) -> dy [N,H,W,2F].
+  With the per-image statistics of sk_select_bn_bwd_att / sk_gap_bn the reduce pass is replaced by a tiny finalize."""
   N, H, W, C2 = y.shape
   HW, M = H * W, N * H * W
+  if grad_stats is not None and mask_stats is not None:
+    ev = _bn_ev(M * (2.0 * C2 + 2.0 * F_ + 2.0 * C2))         # one pass over (y, dV), one write of dy
+    co = empty((3, C2), F32, y)
+    check(L().asm_sk_bn_bwd_finalize(_ptr(grad_stats), _ptr(mask_stats), _ptr(att), _ptr(ds), N, HW, F_, _ptr(gamma),
+                                     _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(co[0]), _ptr(co[1]),
+                                     _ptr(co[2]), _stream()), 'sk_bn_bwd_finalize')
+    dy = torch.empty_like(y)
+    check(L().asm_sk_bn_bwd_apply(_ptr(dv), _ptr(att), _ptr(ds), _ptr(y), _ptr(scale), _ptr(shift), _ptr(co[0]),
+                                  _ptr(co[1]), _ptr(co[2]), _ptr(dy), N, HW, F_, _stream()), 'sk_bn_bwd_apply')
+    if ev is not None:
+      ev.record()
+    return dy
   blocks = L().asm_sk_bn_bwd_blocks(N, HW, F_)
   if blocks <= 0:
     raise ValueError('sk_bn_bwd: bad shape')

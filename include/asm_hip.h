@@ -279,6 +279,20 @@ int asm_sk_bn_bwd_reduce(const void* dv, const float* att, const void* ds, const
 int asm_sk_bn_bwd_apply(const void* dv, const float* att, const void* ds, const void* y, const float* scale,
                         const float* shift, const float* coefA, const float* coefB, const float* coefC, void* dy,
                         int N, int HW, int F, void* stream);
+/* Factorised form of that reduce: a_b and ds are constant over an image, so
+ *   sum dz = sum_n a_b[n] G0[n] + (ds[n]/HW) M0[n],  sum dz*y = sum_n a_b[n] G1[n] + (ds[n]/HW) M1[n]
+ * with per-image statistics [N][2][2F] (fp32): mask_stats = (sum_hw [f>0], sum_hw [f>0] y) out of the pooled-sum pass
+ * (asm_sk_gap_bn_stats) and grad_stats = (sum_hw [f>0] dV, sum_hw [f>0] dV y) out of the gate-gradient pass
+ * (asm_sk_select_bn_bwd_att_stats), both of which read y (and dV) anyway.  asm_sk_bn_bwd_finalize turns them into
+ * dgamma, dbeta and the apply coefficients (xhat is affine in y): the reduce pass over the whole tensor disappears. */
+int asm_sk_gap_bn_stats(const void* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                        void* s, float* mask_stats, int N, int HW, int F, void* stream);
+int asm_sk_select_bn_bwd_att_stats(const void* y, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const void* dv, const float* att, void* datt, float* grad_stats,
+                                   int N, int HW, int F, void* stream);
+int asm_sk_bn_bwd_finalize(const float* grad_stats, const float* mask_stats, const float* att, const void* ds, int N,
+                           int HW, int F, const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                           float* dbeta, float* coefA, float* coefB, float* coefC, void* stream);
 /* SE: y = x * sigmoid(e[n][c]);  e float32 [N, C] (pre-sigmoid) */
 int asm_se_scale_fwd(const void* x, const float* e, void* y, int N, int HW, int C, void* stream);
 /* de[n][c] = sigmoid'(e) * sum_hw x*dy (bf16 out) */

@@ -635,6 +635,48 @@ class CpuDouble(object):
     out[:, 1] = (-d0).to(torch.bfloat16)
     return 0
 
+  def _sk_mask_y(self, y, scale, shift, N, HW, F_):
+    yy = T(y, (N, HW, 2 * F_), 'bf16').float()
+    m = ((yy * T(scale, (2 * F_,), 'f32') + T(shift, (2 * F_,), 'f32')) > 0).float()
+    return m, yy
+
+  def asm_sk_gap_bn_stats(self, y, scale, shift, mean, invstd, s, mst, N, HW, F_, stream):
+    self.asm_sk_gap_bn(y, scale, shift, s, N, HW, F_, stream)
+    m, yy = self._sk_mask_y(y, scale, shift, N, HW, F_)
+    out = T(mst, (N, 2, 2 * F_), 'f32')
+    out[:, 0] = m.sum(1)
+    out[:, 1] = (m * yy).sum(1)
+    return 0
+
+  def asm_sk_select_bn_bwd_att_stats(self, y, scale, shift, mean, invstd, dv, att, datt, gst, N, HW, F_, stream):
+    self.asm_sk_select_bn_bwd_att(y, scale, shift, dv, att, datt, N, HW, F_, stream)
+    m, yy = self._sk_mask_y(y, scale, shift, N, HW, F_)
+    g = T(dv, (N, HW, F_), 'bf16').float().repeat(1, 1, 2)
+    out = T(gst, (N, 2, 2 * F_), 'f32')
+    out[:, 0] = (m * g).sum(1)
+    out[:, 1] = (m * g * yy).sum(1)
+    return 0
+
+  def asm_sk_bn_bwd_finalize(self, gst, mst, att, ds, N, HW, F_, gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, stream):
+    C2 = 2 * F_
+    a0 = self._a0(att, N, F_)
+    ab = torch.cat([a0, 1 - a0], 1).double()                                   # [N, 2F]
+    u = (T(ds, (N, F_), 'bf16').float() / HW).repeat(1, 2).double()
+    gs, ms = T(gst, (N, 2, C2), 'f32').double(), T(mst, (N, 2, C2), 'f32').double()
+    mu, isd, gm = T(mean, (C2,), 'f32').double(), T(invstd, (C2,), 'f32').double(), T(gamma, (C2,), 'f32').double()
+    w = ab * gs[:, 0] + u * ms[:, 0]
+    db = w.sum(0)
+    dg = ((ab * gs[:, 1] + u * ms[:, 1] - mu * w).sum(0)) * isd
+    M = N * HW
+    T(dbeta, (C2,), 'f32').copy_(db.float())
+    T(dgamma, (C2,), 'f32').copy_(dg.float())
+    A = gm * isd
+    B = -gm * isd * isd * dg / M
+    T(cA, (C2,), 'f32').copy_(A.float())
+    T(cB, (C2,), 'f32').copy_(B.float())
+    T(cC, (C2,), 'f32').copy_((-gm * isd * db / M - B * mu).float())
+    return 0
+
   def asm_sk_bn_bwd_blocks(self, N, HW, F_):
     return N
 

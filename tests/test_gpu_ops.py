@@ -436,6 +436,17 @@ def test_sk_unit_with_bn_applied_on_the_fly_equals_materialised_path(hip_lib, N,
   assert util.rel_l2(v1.float().cpu(), vr.detach()) <= 4e-3
   assert util.rel_l2(s1.float().cpu(), sr.detach()) <= 4e-3
   assert util.rel_l2(dy1.float().cpu(), gy) <= 8e-3
+  # factorised batch-norm reduction: per-image statistics out of the pooled-sum and gate-gradient passes + a tiny finalize
+  # == the reduce pass over the whole tensor (same dz, sums regrouped per image)
+  s2, mst = ops.sk_gap_bn(y, scale, shift, F_, mean, invstd)
+  datt2, gst = ops.sk_select_bn_bwd_att(y, scale, shift, dv, att, F_, mean, invstd)
+  assert torch.equal(s2, s1)
+  assert util.rel_l2(datt2.float(), datt1.float()) <= 1e-3          # (f0 - f1) dV summed as f0 dV - f1 dV
+  dg2, db2 = torch.empty(C2, device='cuda'), torch.empty(C2, device='cuda')
+  dy2 = ops.sk_bn_bwd(dv, att, ds, y, scale, shift, gamma, mean, invstd, dg2, db2, F_, gst, mst)
+  assert util.rel_l2(dg2, dg1) <= 1e-3 and util.rel_l2(db2, db1) <= 1e-3, (util.rel_l2(dg2, dg1), util.rel_l2(db2, db1))
+  assert util.rel_l2(dy2.float(), dy1.float()) <= 2e-3
+  assert util.rel_l2(dy2.float().cpu(), gy) <= 8e-3
 
 
 # ---------------------------------------------------------------------------------------------------
