@@ -441,7 +441,7 @@ def test_sk_unit_with_bn_applied_on_the_fly_equals_materialised_path(hip_lib, N,
   s2, mst = ops.sk_gap_bn(y, scale, shift, F_, mean, invstd)
   datt2, gst = ops.sk_select_bn_bwd_att(y, scale, shift, dv, att, F_, mean, invstd)
   assert torch.equal(s2, s1)
-  assert util.rel_l2(datt2.float(), datt1.float()) <= 1e-3          # (f0 - f1) dV summed as f0 dV - f1 dV
+  assert util.rel_l2(datt2.float(), datt1.float()) <= 2e-3          # (f0 - f1) dV summed as f0 dV - f1 dV
   dg2, db2 = torch.empty(C2, device='cuda'), torch.empty(C2, device='cuda')
   dy2 = ops.sk_bn_bwd(dv, att, ds, y, scale, shift, gamma, mean, invstd, dg2, db2, F_, gst, mst)
   assert util.rel_l2(dg2, dg1) <= 1e-3 and util.rel_l2(db2, db1) <= 1e-3, (util.rel_l2(dg2, dg1), util.rel_l2(db2, db1))
