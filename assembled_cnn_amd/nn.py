@@ -744,9 +744,12 @@ class SKUnit(object):
     y, part = conv.fprop(d, x.data, True)                               # conv + fused statistics :115-118
     mean, invstd, scale, shift = ops.bn_finalize(part, M, C2, gamma, beta, BN_EPS, ctx.bn_momentum, a.st(bn.mm),
                                                  a.st(bn.mv))
-    # factorised BN backward (csrc/sk_fused.hip): the pooled-sum pass and the gate-gradient pass also emit per-image
-    # statistics, from which the batch-norm reduction follows without another pass over y and dV (ASM_SK_FACTOR=0: off)
-    factor = ctx.tape is not None and os.environ.get('ASM_SK_FACTOR', '1') != '0'
+    # Factorised BN backward (csrc/sk_fused.hip): the pooled-sum pass and the gate-gradient pass also emit per-image
+    # statistics, from which the batch-norm reduction follows without another pass over y and dV.  Exact and tested, but
+    # OFF by default: the two per-image passes are latency-bound (one workgroup per image, 3.4 TB/s), the 32 extra
+    # accumulators slow them by more than the removed reduce pass costs (28.98 vs 28.37 ms per step, same box).
+    # ASM_SK_FACTOR=1 turns it on.
+    factor = ctx.tape is not None and os.environ.get('ASM_SK_FACTOR', '0') == '1'
     if factor:
       s_t, mask_stats = ops.sk_gap_bn(y, scale, shift, F_, mean, invstd)
       s = Var(s_t)
