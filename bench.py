@@ -9,6 +9,11 @@ One "step" = one pass of the whole hot path over one synthetic minibatch already
 mean-subtract(+mixup) -> forward -> softmax-CE(+label smoothing) -> backward -> [gradient all-reduce]
 -> momentum-SGD.  Weak scaling: the per-GPU batch is fixed as N grows.  Rank 0 prints ONE JSON line.
 
+The timed region runs every kernel on ONE HIP stream, so that the per-kernel figures below (and the rocprofv3 summaries under
+profiles/, taken from this same command) are properties of the kernels; `overlap` (N = 1) is the rate of the same steps with
+the product's side streams on (weight gradients beside the dgrad chain, the big branch of a BigLittle stage beside the
+little one), where kernels share the CUs and individual durations depend on their neighbours.
+
 Extra objects on the line:
   roofline      the dominant convolution kernel class (picked from HIP-event timings of every conv
                 launch in a warm-up step), timed with HIP events on the launch stream during the timed
@@ -323,10 +328,9 @@ def main():
           f.write('| %s | %d %dx%dx%d -> %d, %dx%d/%d | %d | %.4f | %.0f | %.0f |\n' % (
               kind, N_, H_, W_, C_, K_, R_, S_, st_, n, ms, conv_flops(k) * n / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9))
   overlap = None
-  if not args.overlap and not args.no_roofline:   # the same steps with the side streams on (product default)
+  if world == 1 and not args.overlap and not args.no_roofline:   # the same steps with the side streams on (product default)
     os.environ['ASM_BL_STREAMS'] = '1'
-    if world == 1:
-      tr.model.arena.enable_side_stream()
+    tr.model.arena.enable_side_stream()
     for _ in range(2):
       step()
     sync()
@@ -335,13 +339,9 @@ def main():
       step()
     sync()
     el2 = time.time() - t1
-    if world > 1:
-      t = torch.tensor([el2], device=dev, dtype=torch.float64)
-      dist.all_reduce(t, op=dist.ReduceOp.MAX)
-      el2 = float(t)
     overlap = {'value': round(B * world * args.steps / el2, 2), 'ms_per_step': round(1000.0 * el2 / args.steps, 3),
-               'what': 'the same %d steps with weight gradients%s on a second HIP stream' % (
-                   args.steps, ' and the big branch of each BigLittle stage' if world == 1 else ' off (GradSync) but the big branch of each BigLittle stage')}
+               'what': 'the same %d steps with weight gradients and the big branch of each BigLittle stage on a second '
+                       'HIP stream (the product default; per-kernel durations are then contention-dependent)' % args.steps}
   loss = float(tr.cross_entropy())
   if not (loss == loss) or loss > 50:
     raise SystemExit('training diverged (loss=%r): the number would be invalid' % loss)
