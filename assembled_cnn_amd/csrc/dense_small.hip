@@ -33,23 +33,38 @@ __device__ __forceinline__ void load_batch(const bf16_t* qp, const bf16_t* pp, i
     p[j] = ldg8(pp + t * 16);
   }
 }
+// even / odd steps go to two accumulators: back-to-back MFMAs on ONE accumulator wait out the 16-pass result latency
 template <int B, int STRIDE>
-__device__ __forceinline__ void mma_batch(int s, int steps, const bf16x8 (&q)[B], const bf16x8 (&p)[B], f32x16& acc) {
+__device__ __forceinline__ void mma_batch(int s, int steps, const bf16x8 (&q)[B], const bf16x8 (&p)[B], f32x16& acc,
+                                          f32x16& acc2) {
 #pragma unroll
   for (int j = 0; j < B; ++j)
-    if (s + j * STRIDE < steps) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[j], p[j], acc, 0, 0, 0);
+    if (s + j * STRIDE < steps) {
+      if (j & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[j], p[j], acc2, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[j], p[j], acc, 0, 0, 0);
+    }
 }
 template <int B, int STRIDE>
 __device__ __forceinline__ void gemm_steps(const bf16_t* qp, const bf16_t* pp, int s0, int steps, f32x16& acc) {
   bf16x8 qa[B], pa[B], qb[B], pb[B];
-  if (s0 >= steps) return;     // wave-uniform
+  // MFMA ignores EXEC: every branch around one must be a SCALAR branch.  The step cursor derives from the wave index
+  // (a VGPR as far as the compiler knows), so pin it to SGPRs -- with a per-lane condition the compiler may predicate
+  // the block by EXEC and drop the skip branch, and the "skipped" MFMA still executes.
+  s0 = __builtin_amdgcn_readfirstlane(s0);
+  steps = __builtin_amdgcn_readfirstlane(steps);
+  if (s0 >= steps) return;
+  f32x16 acc2;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
   load_batch<B, STRIDE>(qp, pp, s0, steps, qa, pa);
   for (int s = s0; s < steps; s += 2 * B * STRIDE) {
     load_batch<B, STRIDE>(qp, pp, s + B * STRIDE, steps, qb, pb);
-    mma_batch<B, STRIDE>(s, steps, qa, pa, acc);
+    mma_batch<B, STRIDE>(s, steps, qa, pa, acc, acc2);
     load_batch<B, STRIDE>(qp, pp, s + 2 * B * STRIDE, steps, qa, pa);
-    mma_batch<B, STRIDE>(s + B * STRIDE, steps, qb, pb, acc);
+    mma_batch<B, STRIDE>(s + B * STRIDE, steps, qb, pb, acc, acc2);
   }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
 }
 
 struct DenseArgs {
@@ -146,14 +161,17 @@ __device__ __forceinline__ void tile_to_lds(const f32x16& acc, bf16_t (*ys)[YS_L
   }
 }
 
-// per-channel sums over the 128 row lanes: red[stat][rl][32] -> tot[stat] (double) for channel `col`, by 32 x 16 threads
-__device__ __forceinline__ void reduce_lanes(float (*red)[128][32], float (*red2)[16][32], int tid) {
+// per-channel sums over the 128 row lanes.  red is [stat][channel][row lane] with rows padded to 129 floats: the 64 lanes of
+// a wave (4 vector columns x 16 row lanes) then write 64 different banks (channel-major rows of 32 floats put 16 lanes
+// on each of 4 banks: every store was a 16-way conflict).  32 x 16 threads sum 8 lanes each into red2.
+constexpr int RED_LD = 129;
+__device__ __forceinline__ void reduce_lanes(float (*red)[32][RED_LD], float (*red2)[16][32], int tid) {
   const int col = tid & 31, grp = tid >> 5;   // 16 groups of 8 row lanes
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[which][grp * 8 + r][col];
+    for (int r = 0; r < 8; ++r) t += red[which][col][grp * 8 + r];
     red2[which][grp][col] = t;
   }
 }
@@ -167,7 +185,7 @@ struct DenseBnFwdArgs {
 template <bool RELU>
 __global__ __launch_bounds__(512) void dense_bn_fwd_kernel(DenseBnFwdArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t ys[DENSE_BN_MAX_ROWS][YS_LD];
-  __shared__ float red[2][128][32];
+  __shared__ float red[2][32][RED_LD];
   __shared__ float red2[2][16][32];
   __shared__ float coef[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -191,8 +209,8 @@ __global__ __launch_bounds__(512) void dense_bn_fwd_kernel(DenseBnFwdArgs a) {
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    red[0][rl][vc * 8 + e] = s[e];
-    red[1][rl][vc * 8 + e] = ss[e];
+    red[0][vc * 8 + e][rl] = s[e];
+    red[1][vc * 8 + e][rl] = ss[e];
   }
   __syncthreads();
   reduce_lanes(red, red2, tid);
@@ -257,7 +275,7 @@ struct DenseBnBwdArgs {
 template <bool RELU>
 __global__ __launch_bounds__(512) void dense_dgrad_bn_bwd_kernel(DenseBnBwdArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t ys[DENSE_BN_MAX_ROWS][YS_LD];
-  __shared__ float red[2][128][32];
+  __shared__ float red[2][32][RED_LD];
   __shared__ float red2[2][16][32];
   __shared__ float coef[3][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -296,8 +314,8 @@ __global__ __launch_bounds__(512) void dense_dgrad_bn_bwd_kernel(DenseBnBwdArgs 
     }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    red[0][rl][vc * 8 + e] = s[e];
-    red[1][rl][vc * 8 + e] = ss[e];
+    red[0][vc * 8 + e][rl] = s[e];
+    red[1][vc * 8 + e][rl] = ss[e];
   }
   __syncthreads();
   reduce_lanes(red, red2, tid);
