@@ -48,6 +48,10 @@ struct IGemmArgs {
   const float* bn_scale;
   const float* bn_shift;
   int bn_relu;
+  // average-pool backward folded into the epilogue of a 1x1 stride-1 input gradient (asm_conv2d_dgrad_pooled): the block
+  // input of a projection bottleneck is read by conv1 and by the shortcut's average pool; dx += avgpool_bwd(pool_dy)
+  const void* pool_dy;   // bf16 [N][pool_Hp][pool_Wp][Co] or null
+  int pool_k, pool_stride, pool_pad, pool_Hp, pool_Wp, pool_cv;
 };
 
 // 16 zero bytes: the source of every masked lane of an LDS-DMA load (global_load_lds has no bounds check)
@@ -98,7 +102,7 @@ struct Cfg {
 // m_local = wm*WTM + b*32 + l31.
 // patch_base >= 0: the tile's 128 rows are an 8 x 16 pixel patch of one image (conv_halo_kernel): row r is pixel
 // patch_base + (r >> 4) * W + (r & 15) of the [N*H*W] output.
-template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS, bool PFA = false>
+template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS, bool PFA = false, bool POOL = false>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[TN][TM], unsigned char* smem,
                                                int tile_m, int tile_n, int tid, int wm, int wn, int l31, int lhi,
                                                int patch_base = -1) {
@@ -199,9 +203,43 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
       if (m < p.M && n0 < co8) {
         const size_t yoff = row_off(row, m);
-        if (p.addend || p.bn_scale) {   // workgroup-uniform
+        if (POOL || p.addend || p.bn_scale) {   // workgroup-uniform
           float fv[8];
           unpack8(v, fv);
+          if constexpr (POOL) {
+            // gather form of the average-pool backward (csrc/pool.hip): this pixel's share of every window that holds it
+            const unsigned img = fd_div((unsigned)m, p.fd_howo);
+            const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
+            const unsigned ph = fd_div(rem, p.fd_wo);
+            const unsigned pw = rem - ph * (unsigned)p.Wo;
+            const int H = p.HoWo / p.Wo, W = p.Wo;
+            const int sh = p.pool_stride >> 1, msk = p.pool_stride - 1;   // stride in {1, 2}
+            const float inv_full = 1.0f / (float)(p.pool_k * p.pool_k);
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(p.pool_dy) + (size_t)img * p.pool_Hp * p.pool_Wp * p.ldy + n0;
+            for (int r = 0; r < p.pool_k; ++r) {
+              const int th = (int)ph + p.pool_pad - r;
+              const int ho = th >> sh;
+              if (th < 0 || (th & msk) || ho >= p.pool_Hp) continue;
+              for (int q = 0; q < p.pool_k; ++q) {
+                const int tw = (int)pw + p.pool_pad - q;
+                const int wo = tw >> sh;
+                if (tw < 0 || (tw & msk) || wo >= p.pool_Wp) continue;
+                float g[8];
+                unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)(ho * p.pool_Wp + wo) * p.ldy), g);
+                float inv = inv_full;
+                if (p.pool_cv) {
+                  int ch_ = 0, cw_ = 0;
+                  for (int t = 0; t < p.pool_k; ++t) {
+                    ch_ += ((unsigned)(ho * p.pool_stride + t - p.pool_pad) < (unsigned)H);
+                    cw_ += ((unsigned)(wo * p.pool_stride + t - p.pool_pad) < (unsigned)W);
+                  }
+                  inv = 1.0f / (float)(ch_ * cw_);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fv[e] += g[e] * inv;
+              }
+            }
+          }
           if (p.bn_scale) {             // fused inference BN on the bf16-rounded conv tile (== the two-pass numerics)
             const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.bn_scale + n0), s1 = *reinterpret_cast<const f32x4*>(p.bn_scale + n0 + 4);
             const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.bn_shift + n0), h1 = *reinterpret_cast<const f32x4*>(p.bn_shift + n0 + 4);
@@ -541,7 +579,7 @@ struct Cfg2 {
   static_assert(LDS <= 160 * 1024, "lds");
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS, bool PFA = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS, bool PFA = false, bool POOL = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
   using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
   using C2 = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
@@ -711,7 +749,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
     }
   }
 
-  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS, PFA>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS, PFA, POOL>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -918,11 +956,11 @@ int try_halo(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   return 1;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2, bool PFA = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2, bool PFA = false, bool POOL = false>
 int launch2_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
   constexpr int NTHR = 64 * WGM * WGN;
-  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA>;
+  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm2_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
@@ -947,6 +985,7 @@ int launch2_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   if (a.R == 1 && a.S == 1) {
     if (out_f32) return launch2_one<BM, BN, BK, WGM, WGN, true, false, 1, 1>(a, st);
     if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 1, 1>(a, st);
+    if (a.pool_dy) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 1, 2, false, true>(a, st);
     if (pfa) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 1, 2, true>(a, st);
     return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 1>(a, st);
   }
@@ -1026,6 +1065,8 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
   a.fd_howo = make_fastdiv((unsigned)a.HoWo);
   a.fd_wo = make_fastdiv((unsigned)a.Wo);
   const int v2 = asm_env_int("ASM_IGEMM_V2", 1);
+  if (a.pool_dy && !(v2 && fmode == 0 && !out_f32 && !stats && a.R == 1 && a.S == 1 && !a.y_strided))
+    ASM_FAIL(ASM_ENOTSUP, "conv dgrad_pooled: only the 1x1 stride-1 igemm2 path folds an average-pool backward in");
   if (v2 && fmode == 0 && ftile == 0 && asm_env_int("ASM_CONV_HALO", 1)) {
     const int rc = try_halo(a, out_f32, stats, st);
     if (rc != 1) return rc;
@@ -1047,6 +1088,7 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
     else if (bigv) rc = launch2_cfg<256, 256, 64, 4, 2>(a, out_f32, stats, st);
     else rc = bk64 ? launch2_cfg<128, 128, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 128, 32, 2, 2>(a, out_f32, stats, st);
     if (rc != 1 || igemm2_only) return rc;
+    if (a.pool_dy) ASM_FAIL(ASM_ENOTSUP, "conv dgrad_pooled: no igemm2 instantiation for this shape");
   }
   if (igemm2_only) return 1;
   int mode = heavy ? 1 : 2;
@@ -1111,6 +1153,7 @@ static int fprop_impl(const asm_conv_desc* d, const void* x, const void* w, void
   a.pad_w = a.pad; a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
   a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
   a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_relu = relu;
+  a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = 0;
   a.x_img_pitch = (int)img_pitch(d); a.x_row_pitch = row_pitch(d); a.x_pix_pitch = pix_pitch(d);
   a.w_row_pitch = d->R * d->S * d->C;
   return launch(a, d->out_f32 != 0, stats_partial != nullptr, (hipStream_t)stream);
@@ -1129,8 +1172,12 @@ extern "C" int asm_conv2d_fprop_bn(const asm_conv_desc* d, const void* x, const 
   return fprop_impl(d, x, w, y, nullptr, scale, shift, residual, relu ? 1 : 0, stream);
 }
 
+struct PoolAdd {
+  const void* dy;
+  int k, stride, pad, Hp, Wp, cv;
+};
 static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
-                      const uint8_t* addend_mask, void* dx, void* stream);
+                      const uint8_t* addend_mask, void* dx, void* stream, const PoolAdd* pool = nullptr);
 
 extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
                                 void* dx, void* stream) {
@@ -1144,8 +1191,21 @@ extern "C" int asm_conv2d_dgrad_masked(const asm_conv_desc* d, const void* dy, c
   return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream);
 }
 
+extern "C" int asm_conv2d_dgrad_pooled(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                                       const uint8_t* addend_mask, const void* pool_dy, int pool_k, int pool_stride,
+                                       int pool_pad, int pool_Ho, int pool_Wo, int count_valid, void* dx, void* stream) {
+  ASM_REQUIRE(d && pool_dy, "conv dgrad_pooled: null pointer");
+  ASM_REQUIRE(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->C % 8 == 0,
+              "conv dgrad_pooled: needs a 1x1 stride-1 convolution with C %% 8 == 0");
+  ASM_REQUIRE(pool_k >= 1 && pool_k <= 7 && (pool_stride == 1 || pool_stride == 2) && pool_pad >= 0 && pool_Ho > 0 && pool_Wo > 0,
+              "conv dgrad_pooled: bad pooling geometry");
+  ASM_REQUIRE(!addend_mask || addend, "conv dgrad_pooled: a mask needs its addend");
+  const PoolAdd pa = {pool_dy, pool_k, pool_stride, pool_pad, pool_Ho, pool_Wo, count_valid ? 1 : 0};
+  return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream, &pa);
+}
+
 static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
-                      const uint8_t* addend_mask, void* dx, void* stream) {
+                      const uint8_t* addend_mask, void* dx, void* stream, const PoolAdd* pool) {
   if (int e = check_desc(d)) return e;
   ASM_REQUIRE(dy && wt && dx, "conv dgrad: null pointer");
   ASM_REQUIRE(d->K % 8 == 0, "conv dgrad: K=%d must be a multiple of 8 (pad dy)", d->K);
@@ -1167,6 +1227,11 @@ static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, co
   a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
   a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
   a.bn_scale = a.bn_shift = nullptr; a.bn_relu = 0;
+  a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = 0;
+  if (pool) {
+    a.pool_dy = pool->dy; a.pool_k = pool->k; a.pool_stride = pool->stride; a.pool_pad = pool->pad;
+    a.pool_Hp = pool->Hp; a.pool_Wp = pool->Wp; a.pool_cv = pool->cv;
+  }
   // Stride-2 3x3: three quarters of the (pixel, tap) pairs of the generic gather are parity misses (multiplied as
   // zeros).  Split dx into its four (h % 2, w % 2) classes instead: within a class every pixel uses the same
   // 1 / 2 / 2 / 4 taps, so each class is a dense stride-1 gather over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-filter

@@ -76,6 +76,7 @@ SIGNATURES = {
     'asm_conv2d_stats_blocks': (_I, [_D]),
     'asm_conv2d_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
     'asm_conv2d_dgrad_masked': (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    'asm_conv2d_dgrad_pooled': (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'asm_conv2d_wgrad_workspace_bytes': (_Z, [_D]),
     'asm_conv2d_wgrad': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
     'asm_filter_transpose': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

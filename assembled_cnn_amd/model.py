@@ -184,10 +184,12 @@ class Model(object):
     db = db_gamma_scale if (db_gamma_scale is not None and getattr(ctx, 'keep_prob', 1.0) < 1.0) else None
     kp = getattr(ctx, 'keep_prob', 1.0)
     shortcut = x
+    t0 = len(ctx.tape) if ctx.tape is not None else None
     if projection is not None:
       shortcut = projection(x)
       if db is not None:
         shortcut = nn.dropblock(ctx, shortcut, kp, db, relu=False)                      # :46-47
+    t1 = len(ctx.tape) if ctx.tape is not None else None
     c1, b1 = L(lambda: ConvKernel(ctx, 1, cin, filters)), L(lambda: BatchNorm(ctx, filters))
     if db is None:
       h = conv_bn(ctx, x, c1, b1, 1, relu=True)
@@ -206,6 +208,15 @@ class Model(object):
         h = nn.dropblock(ctx, conv_bn(ctx, h, c2, b2, s3, relu=False), kp, db, relu=True)
     if 'sconv' in aa_type and strides != 1:
       h = nn.blur_pool(ctx, h, aa_size, strides)
+    if projection is not None and t0 is not None and t1 > t0:
+      # Backward order of a projection block: block-final layer -> SHORTCUT branch -> main branch (the forward order, and
+      # with it the variable creation order, stays shortcut first).  The shortcut's average pool then leaves its gradient
+      # in pooled form and conv1's input gradient gathers it in its epilogue (nn.Var.pool_grad) instead of a scatter
+      # pass over the full-resolution block input followed by an add.  The shortcut's variables were created before the
+      # main branch's, so their gradient-ready notifications are held until the main branch is through (dp.GradSync).
+      tape, arena = ctx.tape, ctx.arena
+      t2 = len(tape)
+      tape[t0:t2] = [arena.release_grads] + tape[t1:t2] + [arena.pass_grads] + tape[t0:t1] + [arena.hold_grads]
     cout = expansion * filters
     conv3 = L(lambda: ConvKernel(ctx, 1, filters, cout))
     bn3 = L(lambda: BatchNorm(ctx, cout, zero_gamma=zero_gamma))

@@ -69,6 +69,8 @@ class ParamArena(object):
     self.w32 = self.g32 = self.m32 = self.w16 = self.state = None
     self.derived: List[Callable[[], None]] = []  # refresh hooks (CRSK copies, stem packing)
     self.on_grad: Optional[Callable[[int], None]] = None  # dp.GradSync.notify (gradient-ready watermark)
+    self._held: List[int] = []                            # notifications queued between hold_grads() and pass_grads()
+    self._holding = False
     self.wt_specs: List[dict] = []   # CRSK (dgrad operand) copies: one flat bf16 arena, one batched launch
     self.wt16 = None
     self._wt_table = None
@@ -82,7 +84,26 @@ class ParamArena(object):
     for conv kernels); backward order is the reverse of creation order, so every slot above it in its segment has
     been enqueued too."""
     if self.on_grad is not None:
-      self.on_grad(self.specs[name].offset)
+      if self._holding:
+        self._held.append(self.specs[name].offset)
+      else:
+        self.on_grad(self.specs[name].offset)
+
+  # A projection block runs its shortcut branch's backward BEFORE its main branch's (the pooled gradient then rides in
+  # conv1's input-gradient epilogue), but the shortcut's variables were created first, so the gradient-ready watermark
+  # must not see them before the main branch's: hold_grads() queues notifications (shortcut branch), pass_grads() lets
+  # them through again (main branch), release_grads() replays the queue (after the block).
+  def hold_grads(self):
+    self._holding = self.on_grad is not None
+
+  def pass_grads(self):
+    self._holding = False
+
+  def release_grads(self):
+    held, self._held, self._holding = self._held, [], False
+    if self.on_grad is not None:
+      for off in held:
+        self.on_grad(off)
 
   def enable_side_stream(self):
     if self.w32 is not None and self.w32.is_cuda and self.side_stream is None:
@@ -237,7 +258,7 @@ class Var(object):
   backward of a projection shortcut) read (dy, mask) directly, so dz is never written; anything else just reads
   ``.grad``, which materialises it."""
   __slots__ = ('_data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'fuse_dgrad', 'pending', 'bn_ctx',
-               'pre_dy', 'deferred')
+               'pre_dy', 'deferred', 'pool_grad')
 
   def __init__(self, data, shape=None, needs_grad=True):
     self._data = data
@@ -260,6 +281,10 @@ class Var(object):
     # (ops.bn_bwd_dual) and leaves this layer's dy here (pre_dy)
     self.bn_ctx = None
     self.pre_dy = None
+    # a gradient contribution still in pooled form: (dpool [N,Hp,Wp,C], k, stride, pad, count_valid) stands for
+    # avgpool_bwd(dpool); a 1x1 stride-1 convolution reading this activation gathers it in its input-gradient epilogue
+    # (asm_conv2d_dgrad_pooled), anything else reads .grad, which scatters it through asm_avgpool_bwd
+    self.pool_grad = None
 
   @property
   def data(self):
@@ -278,6 +303,16 @@ class Var(object):
       self._grad = ops.mask_apply(self._grad, self.grad_mask)
       self.grad_mask = None
       self.grad_owned = True
+    if self.pool_grad is not None:
+      dp, k, stride, pad, cv = self.pool_grad
+      self.pool_grad = None
+      if self._grad is None:
+        self._grad = ops.avgpool_bwd(dp, self.shape, k, stride, pad, cv)
+      elif self.grad_owned:
+        ops.avgpool_bwd(dp, self.shape, k, stride, pad, cv, addend=self._grad)      # in place
+      else:
+        self._grad = ops.add_bf16(self._grad, ops.avgpool_bwd(dp, self.shape, k, stride, pad, cv))
+      self.grad_owned = True
     return self._grad
 
   @grad.setter
@@ -288,6 +323,14 @@ class Var(object):
   def take_masked_grad(self):
     """-> (gradient tensor, packed mask or None) without materialising the product"""
     return self._grad, self.grad_mask
+
+  def take_pool_grad(self, d):
+    """-> the pending pooled contribution if a convolution with descriptor ``d`` can gather it in its input-gradient
+    epilogue (and clear it), else None (a later .grad read scatters it)"""
+    if self.pool_grad is None or not ops.dgrad_pool_ok(d):
+      return None
+    pg, self.pool_grad = self.pool_grad, None
+    return pg
 
 
 def accum_grad(v: Var, g: torch.Tensor, owned: bool, mask: Optional[torch.Tensor] = None):
@@ -475,7 +518,7 @@ class ConvKernel(object):
       self._wgrad(d, x, dy)
 
   def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool,
-               addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None
+               addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None, pool=None
                ) -> Optional[torch.Tensor]:
     """dW into the gradient arena; returns dx [+ addend [where addend_mask]] (or None)."""
     a = self.arena
@@ -488,8 +531,8 @@ class ConvKernel(object):
       addend, addend_mask = ops.mask_apply(addend, addend_mask), None     # the strided forms take a plain addend
     if self.kpad != self.cout:  # dy carries kpad channels (zero padded)
       dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, self.kpad, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo)
-      return ops.conv_dgrad(dd, dy, a.wt_view(self._wts), addend, addend_mask)
-    return ops.conv_dgrad(d, dy, a.wt_view(self._wts), addend, addend_mask)
+      return ops.conv_dgrad(dd, dy, a.wt_view(self._wts), addend, addend_mask, pool)
+    return ops.conv_dgrad(d, dy, a.wt_view(self._wts), addend, addend_mask, pool)
 
 
 class BatchNorm(object):
@@ -589,8 +632,11 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
       if out.pre_dy is not None:      # projection shortcut: the block-final layer already ran this batch norm's backward
         dy, out.pre_dy = out.pre_dy, None
         a.notify_grad(bn.gamma)
+        pool = x.take_pool_grad(d) if (conv.kpad == conv.cout and x.needs_grad) else None
+        if x.pool_grad is not None:
+          x.grad                                        # (not gatherable here) scatter it now
         xg, xmask = x.take_masked_grad()
-        dx = conv.backward(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask)
+        dx = conv.backward(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask, pool=pool)
         if dx is not None:
           x.grad, x.grad_owned = dx, True
         return
@@ -645,8 +691,12 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
             accum_grad(residual, ops.upsample2x_bwd(dout, mask_t) if lazy_up else ops.upsample2x_bwd(dres), True)
           else:
             accum_grad(residual, dres, relu)
+      pool = x.take_pool_grad(d) if (conv.kpad == conv.cout and x.needs_grad and not conv.stem) else None
+      if x.pool_grad is not None:
+        x.grad                                          # (not gatherable here) scatter it now
       xg, xmask = x.take_masked_grad()
-      dx = conv.backward(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask)   # fan-in add fused into the dgrad epilogue
+      # fan-in add (and a pending average-pool backward) fused into the dgrad epilogue
+      dx = conv.backward(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask, pool=pool)
       if dx is not None:
         x.grad, x.grad_owned = dx, True
       out.grad = None
@@ -844,7 +894,11 @@ def avg_pool(ctx: Ctx, x: Var, k: int, stride: int, pad: int, count_valid: bool)
   y = Var(ops.avgpool_fwd(x.data, k, stride, pad, Ho, Wo, count_valid))
   if ctx.tape is not None:
     def bwd():
-      if x.needs_grad and x.grad is not None and x.grad_owned:
+      if x.needs_grad and x.pool_grad is None and stride in (1, 2) and os.environ.get('ASM_POOL_FUSE', '1') != '0':
+        # leave the contribution in pooled form: the block's first 1x1 convolution gathers it in its input-gradient
+        # epilogue (its backward runs after this one: model._bottleneck orders the tape that way)
+        x.pool_grad = (y.grad, k, stride, pad, count_valid)
+      elif x.needs_grad and x.grad is not None and x.grad_owned:
         # gradient fan-in of the block input (main path arrived first): add inside the pool backward, in place
         ops.avgpool_bwd(y.grad, x.shape, k, stride, pad, count_valid, addend=x.grad)
       else:

@@ -223,11 +223,27 @@ def conv_fprop_bn(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, scale, shift, r
   return y
 
 
+def dgrad_pool_ok(d: ConvDesc) -> bool:
+  """can asm_conv2d_dgrad_pooled take this layer (1x1, stride 1, on the igemm2 path)?  ASM_POOL_FUSE=0: never"""
+  return (os.environ.get('ASM_POOL_FUSE', '1') != '0' and d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0
+          and d.C % 8 == 0 and d.K % 32 == 0 and not _is_dense(d) and os.environ.get('ASM_IGEMM_V2', '1') != '0'
+          and os.environ.get('ASM_IGEMM_MODE', '0') in ('', '0'))
+
+
 def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional[torch.Tensor] = None,
-               addend_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-  """dx = conv_transpose(dy, w) [+ addend [where addend_mask]]"""
+               addend_mask: Optional[torch.Tensor] = None, pool=None) -> torch.Tensor:
+  """dx = conv_transpose(dy, w) [+ addend [where addend_mask]] [+ avgpool_bwd(pool)];
+  pool = (pooled gradient [N,Hp,Wp,C], k, stride, pad, count_valid)"""
   dx = empty((d.N, d.H, d.W, d.C), BF16, dy)
   ev = _TIMER.start('dgrad', d) if _TIMER is not None else None
+  if pool is not None:
+    pdy, pk, pst, ppad, pcv = pool
+    check(L().asm_conv2d_dgrad_pooled(C.byref(d), _ptr(dy), _ptr(wt), _ptr(addend), _ptr(addend_mask), _ptr(pdy), pk, pst,
+                                      ppad, pdy.shape[1], pdy.shape[2], 1 if pcv else 0, _ptr(dx), _stream()),
+          'conv2d_dgrad_pooled')
+    if ev is not None:
+      ev.record()
+    return dx
   if addend_mask is None and _is_dense(d) and d.K % 16 == 0 and dense_small_on():
     # dy [N][K] (row stride K: a padded Cout arrives as K = kpad), wt = CRSK copy [C][K]
     check(L().asm_dense_small(_ptr(dy), d.K, _ptr(wt), d.K, d.N, d.C, d.K, _ptr(dx), d.C, 0, _ptr(addend), _stream()),

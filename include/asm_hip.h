@@ -95,6 +95,15 @@ int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, con
  * straight from (dy, mask).  Not for the 1x1 stride-2 form (ASM_ENOTSUP). */
 int asm_conv2d_dgrad_masked(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
                             const uint8_t* addend_mask, void* dx, void* stream);
+/* The same with the backward of an average pool folded in: dx = conv_transpose(dy, w) [+ addend [where mask]] +
+ * avgpool_bwd(pool_dy) -- the block input of a projection bottleneck is read by conv1 (1x1, stride 1) and by the shortcut's
+ * average pool (nets/resnet_model.py:123-141); with the shortcut branch's backward run first, its pooled gradient
+ * pool_dy [N][pool_Ho][pool_Wo][C] is gathered in conv1's epilogue instead of being scattered by asm_avgpool_bwd into
+ * a full-resolution tensor that conv1's input gradient is then added to.  1x1 / stride 1 only (ASM_ENOTSUP otherwise);
+ * pooling geometry and the count_valid divisor rule as asm_avgpool_bwd. */
+int asm_conv2d_dgrad_pooled(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                            const uint8_t* addend_mask, const void* pool_dy, int pool_k, int pool_stride, int pool_pad,
+                            int pool_Ho, int pool_Wo, int count_valid, void* dx, void* stream);
 
 /* dw[k][r][s][c] (float32) = sum_{n,ho,wo} dy(n,ho,wo,k) * x(n, ho*stride+r-pad, wo*stride+s-pad, c).
  * Split-K over output pixels; `workspace` holds the per-split slabs. */

@@ -156,6 +156,19 @@ class CpuDouble(object):
     T(dx, (d.N, d.H, d.W, d.C), 'bf16').copy_(gx)
     return 0
 
+  def asm_conv2d_dgrad_pooled(self, d, dy, wt, addend, addend_mask, pool_dy, pk, pst, ppad, pHo, pWo, cv, dx, stream):
+    dd = _desc(d)
+    if not (dd.R == 1 and dd.S == 1 and dd.stride == 1 and dd.pad == 0):
+      self._err = b'conv dgrad_pooled: needs a 1x1 stride-1 convolution'
+      return -2
+    if addend_mask:
+      rc = self.asm_conv2d_dgrad_masked(d, dy, wt, addend, addend_mask, dx, stream)
+    else:
+      rc = self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream)
+    if rc:
+      return rc
+    return self.asm_avgpool_bwd(pool_dy, dx, dd.N, dd.H, dd.W, dd.C, pk, pst, ppad, pHo, pWo, cv, dx, stream)
+
   def asm_conv2d_dgrad_masked(self, d, dy, wt, addend, addend_mask, dx, stream):
     return self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream, addend_mask)
 

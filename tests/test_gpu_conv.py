@@ -347,3 +347,45 @@ def test_dgrad_with_masked_addend(hip_lib, shape, pfa, monkeypatch):
   inplace = masked.clone()
   check(L().asm_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(inplace), _ptr(inplace), _stream()), 'dgrad in place')
   assert torch.equal(inplace, b)
+
+
+@pytest.mark.parametrize('shape,pool', [
+    ((4, 28, 28, 256, 64, 1, 1), (3, 2, 1, False)),     # BigLittle projection: 3x3 / 2, pad 1, divisor 9
+    ((2, 14, 14, 512, 128, 1, 1), (2, 2, 0, False)),    # ResNet-D: 2x2 / 2
+    ((2, 14, 14, 64, 32, 1, 1), (2, 1, 0, True)),       # ResNet-D stride 1: SAME 2x2, valid-count divisor
+    ((32, 14, 14, 1024, 256, 1, 1), (3, 2, 1, False)),  # 256 x 256 tile path
+], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('masked', [False, True], ids=['plain', 'masked-addend'])
+def test_dgrad_with_pooled_gradient_gathered_in_the_epilogue(hip_lib, shape, pool, masked):
+  """asm_conv2d_dgrad_pooled == asm_conv2d_dgrad[_masked] followed by asm_avgpool_bwd(addend = that) up to one bf16
+  rounding (the fused form rounds the sum once)."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K, k, stride = shape
+  pk, pst, ppad, cv = pool
+  g = torch.Generator(device='cuda').manual_seed(23)
+  d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
+  dy = torch.randn((N, H, W, K), generator=g, device='cuda').to(BF)
+  w = (torch.randn((K, 1, 1, Cn), generator=g, device='cuda') * Cn ** -0.5).to(BF)
+  wt = torch.empty((Cn, 1, 1, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w, wt, K, 1, 1, Cn)
+  if cv:
+    Hp, Wp = H, W
+  else:
+    Hp, Wp = (H + (pk - 1) - pk) // pst + 1, (W + (pk - 1) - pk) // pst + 1
+  dpool = torch.randn((N, Hp, Wp, Cn), generator=g, device='cuda').to(BF)
+  addend = torch.randn((N, H, W, Cn), generator=g, device='cuda').to(BF) if masked else None
+  mask = torch.randint(0, 256, (N * H * W, Cn // 8), generator=g, device='cuda', dtype=torch.uint8) if masked else None
+  assert ops.dgrad_pool_ok(d)
+  fused = ops.conv_dgrad(d, dy, wt, addend, mask, pool=(dpool, pk, pst, ppad, cv))
+  two = ops.conv_dgrad(d, dy, wt, addend, mask)
+  two = ops.avgpool_bwd(dpool, (N, H, W, Cn), pk, pst, ppad, cv, addend=two)
+  r = util.rel_l2(fused.float().cpu(), two.float().cpu())
+  assert r <= 3e-3, r
+  # fp32 reference of the sum
+  ref = dy.float().cpu().view(-1, K) @ w.float().cpu().view(K, Cn)
+  if masked:
+    bits = ((mask.cpu().to(torch.int32)[:, :, None] >> torch.arange(8, dtype=torch.int32)) & 1).reshape(-1, Cn)
+    ref = ref + addend.float().cpu().view(-1, Cn) * bits
+  pz = ops.avgpool_bwd(dpool, (N, H, W, Cn), pk, pst, ppad, cv).float().cpu().view(-1, Cn)
+  ref = ref + pz
+  assert util.rel_l2(fused.float().cpu().view(-1, Cn), ref) <= 4e-3
