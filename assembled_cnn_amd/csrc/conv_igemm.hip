@@ -51,7 +51,7 @@ struct IGemmArgs {
   // average-pool backward folded into the epilogue of a 1x1 stride-1 input gradient (asm_conv2d_dgrad_pooled): the block
   // input of a projection bottleneck is read by conv1 and by the shortcut's average pool; dx += avgpool_bwd(pool_dy)
   const void* pool_dy;   // bf16 [N][pool_Hp][pool_Wp][Co] or null
-  int pool_k, pool_stride, pool_pad, pool_Hp, pool_Wp, pool_cv;
+  int pool_k, pool_stride, pool_pad, pool_Hp, pool_Wp, pool_cv, pool_H;
 };
 
 // 16 zero bytes: the source of every masked lane of an LDS-DMA load (global_load_lds has no bounds check)
@@ -207,38 +207,61 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
           float fv[8];
           unpack8(v, fv);
           if constexpr (POOL) {
-            // gather form of the average-pool backward (csrc/pool.hip): this pixel's share of every window that holds it
+            // Gather form of the average-pool backward (csrc/pool.hip): this pixel's share of every window that holds it.
+            // Branch-free: with k <= 2 * stride at most TWO windows per dimension hold a pixel (o_hi = (p + pad) / stride and
+            // o_hi - 1), so the four candidate vectors are loaded back to back (invalid ones from a clamped address, weight 0)
+            // and waited for ONCE -- a loop over the k x k taps with early-outs issued up to nine dependent L2 round trips
+            // per pass and cost more than the scatter pass it replaced.
             const unsigned img = fd_div((unsigned)m, p.fd_howo);
             const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
             const unsigned ph = fd_div(rem, p.fd_wo);
             const unsigned pw = rem - ph * (unsigned)p.Wo;
-            const int H = p.HoWo / p.Wo, W = p.Wo;
-            const int sh = p.pool_stride >> 1, msk = p.pool_stride - 1;   // stride in {1, 2}
-            const float inv_full = 1.0f / (float)(p.pool_k * p.pool_k);
-            const bf16_t* src = reinterpret_cast<const bf16_t*>(p.pool_dy) + (size_t)img * p.pool_Hp * p.pool_Wp * p.ldy + n0;
-            for (int r = 0; r < p.pool_k; ++r) {
-              const int th = (int)ph + p.pool_pad - r;
-              const int ho = th >> sh;
-              if (th < 0 || (th & msk) || ho >= p.pool_Hp) continue;
-              for (int q = 0; q < p.pool_k; ++q) {
-                const int tw = (int)pw + p.pool_pad - q;
-                const int wo = tw >> sh;
-                if (tw < 0 || (tw & msk) || wo >= p.pool_Wp) continue;
-                float g[8];
-                unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)(ho * p.pool_Wp + wo) * p.ldy), g);
-                float inv = inv_full;
-                if (p.pool_cv) {
-                  int ch_ = 0, cw_ = 0;
-                  for (int t = 0; t < p.pool_k; ++t) {
-                    ch_ += ((unsigned)(ho * p.pool_stride + t - p.pool_pad) < (unsigned)H);
-                    cw_ += ((unsigned)(wo * p.pool_stride + t - p.pool_pad) < (unsigned)W);
-                  }
-                  inv = 1.0f / (float)(ch_ * cw_);
-                }
+            const int H = p.pool_H, W = p.Wo;
+            const int sh = p.pool_stride >> 1;                     // stride in {1, 2}
+            const int th = (int)ph + p.pool_pad, tw = (int)pw + p.pool_pad;
+            int oh[2], ow[2];
+            float wh[2], ww[2];
+            oh[0] = th >> sh; ow[0] = tw >> sh;
+            oh[1] = oh[0] - 1; ow[1] = ow[0] - 1;
+            const int rh = th - (oh[0] << sh), rw = tw - (ow[0] << sh);
+            bool vh[2], vw[2];
+            vh[0] = oh[0] < p.pool_Hp;                 vw[0] = ow[0] < p.pool_Wp;
+            vh[1] = oh[1] >= 0 && oh[1] < p.pool_Hp && rh + p.pool_stride <= p.pool_k - 1;
+            vw[1] = ow[1] >= 0 && ow[1] < p.pool_Wp && rw + p.pool_stride <= p.pool_k - 1;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fv[e] += g[e] * inv;
+            for (int i = 0; i < 2; ++i) {
+              float ch_ = (float)p.pool_k, cw_ = (float)p.pool_k;
+              if (p.pool_cv) {       // workgroup-uniform: the "count only valid taps" SAME rule
+                int a_ = 0, b_ = 0;
+                for (int t = 0; t < p.pool_k; ++t) {
+                  a_ += ((unsigned)(oh[i] * p.pool_stride + t - p.pool_pad) < (unsigned)H);
+                  b_ += ((unsigned)(ow[i] * p.pool_stride + t - p.pool_pad) < (unsigned)W);
+                }
+                ch_ = (float)(a_ > 0 ? a_ : 1);
+                cw_ = (float)(b_ > 0 ? b_ : 1);
               }
+              wh[i] = vh[i] ? 1.0f / ch_ : 0.f;
+              ww[i] = vw[i] ? 1.0f / cw_ : 0.f;
+              oh[i] = vh[i] ? oh[i] : 0;
+              ow[i] = vw[i] ? ow[i] : 0;
             }
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(p.pool_dy) + (size_t)img * p.pool_Hp * p.pool_Wp * p.ldy + n0;
+            u32x4 tv[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                tv[i * 2 + j] = *reinterpret_cast<const u32x4*>(src + (size_t)(oh[i] * p.pool_Wp + ow[j]) * p.ldy);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                float g[8];
+                unpack8(tv[i * 2 + j], g);
+                const float wgt = wh[i] * ww[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fv[e] += g[e] * wgt;
+              }
           }
           if (p.bn_scale) {             // fused inference BN on the bf16-rounded conv tile (== the two-pass numerics)
             const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.bn_scale + n0), s1 = *reinterpret_cast<const f32x4*>(p.bn_scale + n0 + 4);
@@ -1153,7 +1176,7 @@ static int fprop_impl(const asm_conv_desc* d, const void* x, const void* w, void
   a.pad_w = a.pad; a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
   a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
   a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_relu = relu;
-  a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = 0;
+  a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = a.pool_H = 0;
   a.x_img_pitch = (int)img_pitch(d); a.x_row_pitch = row_pitch(d); a.x_pix_pitch = pix_pitch(d);
   a.w_row_pitch = d->R * d->S * d->C;
   return launch(a, d->out_f32 != 0, stats_partial != nullptr, (hipStream_t)stream);
@@ -1197,8 +1220,11 @@ extern "C" int asm_conv2d_dgrad_pooled(const asm_conv_desc* d, const void* dy, c
   ASM_REQUIRE(d && pool_dy, "conv dgrad_pooled: null pointer");
   ASM_REQUIRE(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->C % 8 == 0,
               "conv dgrad_pooled: needs a 1x1 stride-1 convolution with C %% 8 == 0");
-  ASM_REQUIRE(pool_k >= 1 && pool_k <= 7 && (pool_stride == 1 || pool_stride == 2) && pool_pad >= 0 && pool_Ho > 0 && pool_Wo > 0,
+  ASM_REQUIRE(pool_k >= 1 && (pool_stride == 1 || pool_stride == 2) && pool_pad >= 0 && pool_Ho > 0 && pool_Wo > 0,
               "conv dgrad_pooled: bad pooling geometry");
+  if (pool_k > 2 * pool_stride || pool_k < pool_stride)
+    ASM_FAIL(ASM_ENOTSUP, "conv dgrad_pooled: window %d / stride %d puts a pixel in more than two windows per dimension",
+             pool_k, pool_stride);
   ASM_REQUIRE(!addend_mask || addend, "conv dgrad_pooled: a mask needs its addend");
   const PoolAdd pa = {pool_dy, pool_k, pool_stride, pool_pad, pool_Ho, pool_Wo, count_valid ? 1 : 0};
   return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream, &pa);
@@ -1227,10 +1253,10 @@ static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, co
   a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
   a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
   a.bn_scale = a.bn_shift = nullptr; a.bn_relu = 0;
-  a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = 0;
+  a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = a.pool_H = 0;
   if (pool) {
     a.pool_dy = pool->dy; a.pool_k = pool->k; a.pool_stride = pool->stride; a.pool_pad = pool->pad;
-    a.pool_Hp = pool->Hp; a.pool_Wp = pool->Wp; a.pool_cv = pool->cv;
+    a.pool_Hp = pool->Hp; a.pool_Wp = pool->Wp; a.pool_cv = pool->cv; a.pool_H = d->H;
   }
   // Stride-2 3x3: three quarters of the (pixel, tap) pairs of the generic gather are parity misses (multiplied as
   // zeros).  Split dx into its four (h % 2, w % 2) classes instead: within a class every pixel uses the same

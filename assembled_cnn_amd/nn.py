@@ -894,7 +894,8 @@ def avg_pool(ctx: Ctx, x: Var, k: int, stride: int, pad: int, count_valid: bool)
   y = Var(ops.avgpool_fwd(x.data, k, stride, pad, Ho, Wo, count_valid))
   if ctx.tape is not None:
     def bwd():
-      if x.needs_grad and x.pool_grad is None and stride in (1, 2) and os.environ.get('ASM_POOL_FUSE', '1') != '0':
+      if (x.needs_grad and x.pool_grad is None and stride in (1, 2) and stride <= k <= 2 * stride and
+          os.environ.get('ASM_POOL_FUSE', '1') != '0'):
         # leave the contribution in pooled form: the block's first 1x1 convolution gathers it in its input-gradient
         # epilogue (its backward runs after this one: model._bottleneck orders the tape that way)
         x.pool_grad = (y.grad, k, stride, pad, count_valid)
