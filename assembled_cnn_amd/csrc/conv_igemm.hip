@@ -186,6 +186,66 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         }
       }
     __syncthreads();
+    // Average-pool backward gathered in this epilogue (POOL kernels, asm_conv2d_dgrad_pooled): this pixel's share of every
+    // window that holds it.  Branch-free: with k <= 2 * stride at most TWO windows per dimension hold a pixel
+    // (o_hi = (p + pad) / stride and o_hi - 1), so the four candidate vectors are loaded back to back (invalid ones from a
+    // clamped address, weight 0) and waited for once -- a loop over the k x k taps with early-outs issued up to nine
+    // dependent L2 round trips per pass and cost more than the scatter pass it replaced -- and the taps of pass ps + 1 are
+    // issued before pass ps stores (the store would otherwise fence them: it may alias).
+    struct PoolTaps {
+      u32x4 v[4];
+      float w[4];
+    };
+    PoolTaps pcur, pnxt;
+    auto pool_issue = [&](int ps, PoolTaps& t) {
+      const int row = ps * RPO + orow;
+      const int m = tile_m * BM + row;
+      const bool ok = m < p.M && n0 < co8;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned img = fd_div(mm, p.fd_howo);
+      const unsigned rem = mm - img * (unsigned)p.HoWo;
+      const unsigned ph = fd_div(rem, p.fd_wo);
+      const unsigned pw = rem - ph * (unsigned)p.Wo;
+      const int H = p.pool_H, W = p.Wo;
+      const int sh = p.pool_stride >> 1;                     // stride in {1, 2}
+      const int th = (int)ph + p.pool_pad, tw = (int)pw + p.pool_pad;
+      int oh[2], ow[2];
+      float wh[2], ww[2];
+      oh[0] = th >> sh; ow[0] = tw >> sh;
+      oh[1] = oh[0] - 1; ow[1] = ow[0] - 1;
+      const int rh = th - (oh[0] << sh), rw = tw - (ow[0] << sh);
+      bool vh[2], vw[2];
+      vh[0] = ok && oh[0] < p.pool_Hp;           vw[0] = ow[0] < p.pool_Wp;
+      vh[1] = ok && oh[1] >= 0 && oh[1] < p.pool_Hp && rh + p.pool_stride <= p.pool_k - 1;
+      vw[1] = ow[1] >= 0 && ow[1] < p.pool_Wp && rw + p.pool_stride <= p.pool_k - 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float ch_ = (float)p.pool_k, cw_ = (float)p.pool_k;
+        if (p.pool_cv) {       // workgroup-uniform: the "count only valid taps" SAME rule
+          int a_ = 0, b_ = 0;
+          for (int q = 0; q < p.pool_k; ++q) {
+            a_ += ((unsigned)(oh[i] * p.pool_stride + q - p.pool_pad) < (unsigned)H);
+            b_ += ((unsigned)(ow[i] * p.pool_stride + q - p.pool_pad) < (unsigned)W);
+          }
+          ch_ = (float)(a_ > 0 ? a_ : 1);
+          cw_ = (float)(b_ > 0 ? b_ : 1);
+        }
+        wh[i] = vh[i] ? 1.0f / ch_ : 0.f;
+        ww[i] = vw[i] ? 1.0f / cw_ : 0.f;
+        oh[i] = vh[i] ? oh[i] : 0;
+        ow[i] = vw[i] ? ow[i] : 0;
+      }
+      const bf16_t* src = reinterpret_cast<const bf16_t*>(p.pool_dy) + (size_t)img * p.pool_Hp * p.pool_Wp * p.ldy +
+                          (n0 < co8 ? n0 : 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          t.v[i * 2 + j] = *reinterpret_cast<const u32x4*>(src + (size_t)(oh[i] * p.pool_Wp + ow[j]) * p.ldy);
+          t.w[i * 2 + j] = wh[i] * ww[j];
+        }
+    };
+    if constexpr (POOL) pool_issue(0, pcur);
     // statistics partials are per STATS_BM (=128) rows: a 256-row tile emits two of them
     constexpr int SG = STATS ? BM / STATS_BM : 1;
     float s[SG][8], ss[SG][8];
@@ -198,6 +258,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       if constexpr (PF_ON) {
         if (p.addend && ps > 0 && ps % PF == 0) prefetch(ps);
       }
+      if constexpr (POOL) {
+        if (ps + 1 < OP) pool_issue(ps + 1, pnxt);
+      }
       const int row = ps * RPO + orow;
       const int m = tile_m * BM + row;
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
@@ -207,61 +270,13 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
           float fv[8];
           unpack8(v, fv);
           if constexpr (POOL) {
-            // Gather form of the average-pool backward (csrc/pool.hip): this pixel's share of every window that holds it.
-            // Branch-free: with k <= 2 * stride at most TWO windows per dimension hold a pixel (o_hi = (p + pad) / stride and
-            // o_hi - 1), so the four candidate vectors are loaded back to back (invalid ones from a clamped address, weight 0)
-            // and waited for ONCE -- a loop over the k x k taps with early-outs issued up to nine dependent L2 round trips
-            // per pass and cost more than the scatter pass it replaced.
-            const unsigned img = fd_div((unsigned)m, p.fd_howo);
-            const unsigned rem = (unsigned)m - img * (unsigned)p.HoWo;
-            const unsigned ph = fd_div(rem, p.fd_wo);
-            const unsigned pw = rem - ph * (unsigned)p.Wo;
-            const int H = p.pool_H, W = p.Wo;
-            const int sh = p.pool_stride >> 1;                     // stride in {1, 2}
-            const int th = (int)ph + p.pool_pad, tw = (int)pw + p.pool_pad;
-            int oh[2], ow[2];
-            float wh[2], ww[2];
-            oh[0] = th >> sh; ow[0] = tw >> sh;
-            oh[1] = oh[0] - 1; ow[1] = ow[0] - 1;
-            const int rh = th - (oh[0] << sh), rw = tw - (ow[0] << sh);
-            bool vh[2], vw[2];
-            vh[0] = oh[0] < p.pool_Hp;                 vw[0] = ow[0] < p.pool_Wp;
-            vh[1] = oh[1] >= 0 && oh[1] < p.pool_Hp && rh + p.pool_stride <= p.pool_k - 1;
-            vw[1] = ow[1] >= 0 && ow[1] < p.pool_Wp && rw + p.pool_stride <= p.pool_k - 1;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              float ch_ = (float)p.pool_k, cw_ = (float)p.pool_k;
-              if (p.pool_cv) {       // workgroup-uniform: the "count only valid taps" SAME rule
-                int a_ = 0, b_ = 0;
-                for (int t = 0; t < p.pool_k; ++t) {
-                  a_ += ((unsigned)(oh[i] * p.pool_stride + t - p.pool_pad) < (unsigned)H);
-                  b_ += ((unsigned)(ow[i] * p.pool_stride + t - p.pool_pad) < (unsigned)W);
-                }
-                ch_ = (float)(a_ > 0 ? a_ : 1);
-                cw_ = (float)(b_ > 0 ? b_ : 1);
-              }
-              wh[i] = vh[i] ? 1.0f / ch_ : 0.f;
-              ww[i] = vw[i] ? 1.0f / cw_ : 0.f;
-              oh[i] = vh[i] ? oh[i] : 0;
-              ow[i] = vw[i] ? ow[i] : 0;
+            for (int t = 0; t < 4; ++t) {
+              float g[8];
+              unpack8(pcur.v[t], g);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) fv[e] += g[e] * pcur.w[t];
             }
-            const bf16_t* src = reinterpret_cast<const bf16_t*>(p.pool_dy) + (size_t)img * p.pool_Hp * p.pool_Wp * p.ldy + n0;
-            u32x4 tv[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                tv[i * 2 + j] = *reinterpret_cast<const u32x4*>(src + (size_t)(oh[i] * p.pool_Wp + ow[j]) * p.ldy);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                float g[8];
-                unpack8(tv[i * 2 + j], g);
-                const float wgt = wh[i] * ww[j];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) fv[e] += g[e] * wgt;
-              }
           }
           if (p.bn_scale) {             // fused inference BN on the bf16-rounded conv tile (== the two-pass numerics)
             const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.bn_scale + n0), s1 = *reinterpret_cast<const f32x4*>(p.bn_scale + n0 + 4);
@@ -291,6 +306,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         }
         *reinterpret_cast<u32x4*>(y + yoff) = v;
       }
+      if constexpr (POOL) pcur = pnxt;
       if constexpr (STATS) {
         constexpr int PPG = OP / SG;   // passes per statistics group (rows are pass-major)
         float f[8];
