@@ -155,7 +155,7 @@ _DENSE_BN_ROWS = None
 def dense_bn_ok(M: int, K: int, N: int) -> bool:
   """fc + training-mode batch norm (and its backward twin) in one launch: every row of 32 channels in one workgroup"""
   global _DENSE_BN_ROWS
-  if not dense_small_on():
+  if not dense_small_on() or os.environ.get('ASM_DENSE_BN', '1') == '0':
     return False
   if _DENSE_BN_ROWS is None:
     _DENSE_BN_ROWS = int(L().asm_dense_bn_max_rows())
