@@ -510,6 +510,7 @@ def test_dense_bn_fused_equals_conv_plus_bn_small(hip_lib, M, K, N, relu, monkey
   (input gradient of the next dense layer + BN backward) == asm_conv2d_dgrad + asm_bn_small_bwd."""
   from assembled_cnn_amd import ops
   monkeypatch.setenv('ASM_DENSE_SMALL', '1')
+  monkeypatch.setenv('ASM_DENSE_BN', '1')
   x = _rand((M, 1, 1, K), 1).cuda()
   w = _rand((N, 1, 1, K), 2, scale=K ** -0.5).cuda()
   gamma = (torch.rand(N, generator=torch.Generator().manual_seed(2)) + 0.5).cuda()
@@ -557,6 +558,7 @@ def test_sk_attention_path_fused_vs_unfused_whole_unit(hip_lib, monkeypatch):
   logits and every parameter gradient agree to bf16 noise."""
   from tests import model_parity as MP
   res = {}
+  monkeypatch.setenv('ASM_DENSE_BN', '1')      # the one-launch fc + batch norm forms too (opt-in)
   for knob in ('1', '0'):
     monkeypatch.setenv('ASM_DENSE_SMALL', knob)
     om, pm = MP.make_pair('a-r50', 'cuda', 8, 64)
