@@ -627,7 +627,9 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const bf16_t* __restr
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            float* moving_mean, float* moving_var, float* mean,
                                                            float* invstd, uint8_t* __restrict__ mask) {
-  __shared__ float red[2][32][64];
+  // [stat][channel][row lane], rows padded to 33 floats: a wave's 64 lanes (8 vector columns x 8 row lanes) write 32 banks
+  // two-way (channel-major rows of 64 floats put them on 4 banks: every store was a 16-way conflict)
+  __shared__ float red[2][64][33];
   __shared__ float coef[2][64];
   const int vcols = C >> 3;
   const int vcl = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -648,8 +650,8 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const bf16_t* __restr
     }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    red[0][rl][vcl * 8 + e] = s[e];
-    red[1][rl][vcl * 8 + e] = ss[e];
+    red[0][vcl * 8 + e][rl] = s[e];
+    red[1][vcl * 8 + e][rl] = ss[e];
   }
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -657,8 +659,8 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const bf16_t* __restr
     if (ch < C) {
       double a = 0.0, b = 0.0;
       for (int r = 0; r < 32; ++r) {
-        a += (double)red[0][r][threadIdx.x];
-        b += (double)red[1][r][threadIdx.x];
+        a += (double)red[0][threadIdx.x][r];
+        b += (double)red[1][threadIdx.x][r];
       }
       const double mu = a / (double)M;
       double var = b / (double)M - mu * mu;
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const bf16_t* __restr
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float* dgamma,
                                                            float* dbeta, bf16_t* __restrict__ dx) {
-  __shared__ float red[2][32][64];
+  __shared__ float red[2][64][33];   // [stat][channel][row lane] (see bn_small_fwd_kernel)
   __shared__ float coef[3][64];
   const int vcols = C >> 3;
   const int vcl = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -735,8 +737,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const bf16_t* __restr
     }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    red[0][rl][vcl * 8 + e] = s[e];
-    red[1][rl][vcl * 8 + e] = ss[e];
+    red[0][vcl * 8 + e][rl] = s[e];
+    red[1][vcl * 8 + e][rl] = ss[e];
   }
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -744,8 +746,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const bf16_t* __restr
     if (ch < C) {
       double db = 0.0, dg = 0.0;
       for (int r = 0; r < 32; ++r) {
-        db += (double)red[0][r][threadIdx.x];
-        dg += (double)red[1][r][threadIdx.x];
+        db += (double)red[0][threadIdx.x][r];
+        dg += (double)red[1][threadIdx.x][r];
       }
       dbeta[ch] = (float)db;
       dgamma[ch] = (float)dg;

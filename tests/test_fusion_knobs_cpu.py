@@ -1,0 +1,59 @@
+"""Host-side fusion plumbing (CPU test double of the C ABI): every lazy / fused path of nn.py -- lazily masked shortcut
+gradients, the deferred + dual batch norm of a projection shortcut, the pooled gradient gathered by conv1's input
+gradient, the pending input gradient of the squeeze layers, the masked block sum at a BigLittle merge, the reordered tape
+of a projection block -- must give the gradients of the plain one-kernel-per-op path.  The double computes both in fp32
+with bf16 rounding where the kernels store bf16, so the two differ by rounding only."""
+import pytest
+import torch
+
+from tests import model_parity as MP
+
+
+def _run(monkeypatch, fused: bool, name='a-r50-d', batch=2, size=64):
+  from assembled_cnn_amd import nn
+  for k in ('ASM_POOL_FUSE', 'ASM_BN_DUAL', 'ASM_DENSE_SMALL', 'ASM_SK_FUSED'):
+    monkeypatch.setenv(k, '1' if fused else '0')
+  monkeypatch.setenv('ASM_DENSE_BN', '1' if fused else '0')
+  monkeypatch.setattr(nn, 'DEFER_BN', fused)
+  monkeypatch.setattr(nn, 'LAZY_DZ', fused)
+  _, pm = MP.make_pair(name, 'cpu', batch, size)
+  _, x, _ = MP.inputs(batch, size)
+  lp = pm(x, True, use_resnet_d=MP.uses_d(name))
+  dl = torch.zeros((batch, 1, 1, pm.ldc), dtype=torch.bfloat16)
+  dl[:, 0, 0, :1001] = (torch.softmax(lp.float(), 1) / batch).to(torch.bfloat16)
+  pm.backward(dl)
+  grads = {n: pm.arena.g(n).float().clone() for n in pm.arena.specs}
+  return lp.float().clone(), grads
+
+
+@pytest.mark.parametrize('name', ['a-r50-d'])
+def test_fused_and_plain_paths_give_the_same_gradients(cpu_double, monkeypatch, name):
+  lf, gf = _run(monkeypatch, True, name)
+  lp, gp = _run(monkeypatch, False, name)
+  assert float((lf - lp).norm() / lp.norm()) <= 2e-2
+  fa = torch.cat([g.reshape(-1) for g in gf.values()])
+  fb = torch.cat([g.reshape(-1) for g in gp.values()])
+  cos = float((fa * fb).sum() / (fa.norm() * fb.norm()))
+  assert cos >= 0.97, 'global gradient cosine %.4f between the fused and the plain host paths' % cos
+  worst = min(float((gf[n] * gp[n]).sum() / (gf[n].norm() * gp[n].norm() + 1e-30)) for n in gf if float(gp[n].norm()) > 0)
+  assert worst >= 0.7, 'worst per-variable gradient cosine %.3f' % worst
+
+
+def test_projection_block_keeps_the_gradient_watermark_monotone(cpu_double):
+  """The shortcut branch of a projection block runs its backward BEFORE the main branch, yet the gradient-ready
+  notifications must still arrive in reverse creation order per segment (what dp.GradSync.notify enforces)."""
+  _, pm = MP.make_pair('a-r50-d', 'cpu', 2, 64)
+  _, x, _ = MP.inputs(2, 64)
+  a = pm.arena
+  seen = []
+  a.on_grad = seen.append
+  lp = pm(x, True, use_resnet_d=True)
+  pm.backward(torch.zeros((2, 1, 1, pm.ldc), dtype=torch.bfloat16))
+  a.on_grad = None
+  last = [1 << 62, 1 << 62]
+  for off in seen:
+    s = 0 if off < a.decay_elems else 1
+    assert off <= last[s], 'watermark moved up'
+    last[s] = off
+  kernels = [sp.offset for n, sp in a.specs.items() if n.endswith('/kernel')]
+  assert set(kernels) <= set(seen), 'every kernel gradient is announced'
