@@ -160,6 +160,7 @@ class Model(object):
     if self._ctx is None or self._ctx.tape is None:
       raise RuntimeError('no forward pass with a tape to differentiate')
     self._ctx.dlogits = dlogits
+    self.arena.release_grads()      # a previous backward that raised mid-block must not leave notifications queued
     self._ctx.backward()
     self._ctx = None
     self.arena.join_side_stream()
