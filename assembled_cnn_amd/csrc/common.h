@@ -22,8 +22,14 @@ void asm_set_error(const char* fmt, ...);
     asm_set_error(__VA_ARGS__);  \
     return (code);               \
   } while (0)
+// hipGetLastError() is STICKY per host thread across ALL HIP users of the process: an error some other component left
+// behind (PyTorch probing devices / peers, a collective library, ...) would be reported by ASM_CHECK_LAUNCH as the
+// failure of the next kernel this library launches ("cast: no ROCm-capable device is detected" on a healthy GPU).  Every
+// entry point validates its arguments first, so the argument check is where the stale state is dropped; a launch is always
+// followed directly by ASM_CHECK_LAUNCH, never by another ASM_REQUIRE, so no error of our own can be swallowed here.
 #define ASM_REQUIRE(cond, ...)                  \
   do {                                          \
+    (void)hipGetLastError();                    \
     if (!(cond)) ASM_FAIL(ASM_EINVAL, __VA_ARGS__); \
   } while (0)
 #define ASM_CHECK_LAUNCH(name)                                                       \
