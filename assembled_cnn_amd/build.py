@@ -51,10 +51,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
   with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
     objs = list(ex.map(_compile, SOURCES))
   if force or _stale(LIB_PATH, objs):
-    cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    # link beside the target and rename over it: a process that has the old library mapped (this one, after lib.load())
+    # keeps its inode; rewriting the file in place would pull the new bytes -- and the new embedded GPU code object --
+    # under the loaded image (seen as "no ROCm-capable device is detected" at the next launch)
+    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
+    cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+      if os.path.exists(tmp):
+        os.remove(tmp)
       raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    os.replace(tmp, LIB_PATH)
   if verbose:
     print('built', LIB_PATH)
   return LIB_PATH
