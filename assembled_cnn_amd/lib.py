@@ -179,6 +179,10 @@ def load(path: str = LIB_PATH) -> C.CDLL:
   if not os.path.exists(path):
     raise AsmError('%s not found -- build it with `python -m assembled_cnn_amd.build` '
                    '(there is no CPU fallback)' % path)
+  # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; whichever HIP runtime is mapped first serves the whole
+  # process.  Loaded before torch, this library would bind to the system ROCm runtime instead and the two would not share
+  # devices, streams or allocations ("no ROCm-capable device is detected" at the first launch on a healthy GPU).
+  import torch  # noqa: F401
   lib = C.CDLL(path)
   for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
     fn = getattr(lib, name, None)
