@@ -650,6 +650,8 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
         if dx is not None:
           x.grad, x.grad_owned = dx, True
         return
+      if out.pool_grad is not None:
+        out.grad                                        # a pooled contribution nobody gathered: scatter it now
       # the incoming gradient may be lazily masked by the ReLU of the block this layer's output was the shortcut of:
       # a BN without its own ReLU takes that mask as if it were its own (dz = dout * mask is exactly what it needs)
       dout, in_mask = out.take_masked_grad()

@@ -9,8 +9,10 @@ import torch
 from tests import model_parity as MP
 
 
-def _run(monkeypatch, fused: bool, name='a-r50-d', batch=2, size=64):
-  from assembled_cnn_amd import nn
+def _run(monkeypatch, fused: bool, name='a-r50-d', batch=2, size=64, gatherable=True):
+  from assembled_cnn_amd import nn, ops
+  if not gatherable:      # the pooled gradient stays pending until somebody reads .grad, which scatters it
+    monkeypatch.setattr(ops, 'dgrad_pool_ok', lambda d: False)
   for k in ('ASM_POOL_FUSE', 'ASM_BN_DUAL', 'ASM_DENSE_SMALL', 'ASM_SK_FUSED'):
     monkeypatch.setenv(k, '1' if fused else '0')
   monkeypatch.setenv('ASM_DENSE_BN', '1' if fused else '0')
@@ -37,6 +39,10 @@ def test_fused_and_plain_paths_give_the_same_gradients(cpu_double, monkeypatch, 
   assert cos >= 0.97, 'global gradient cosine %.4f between the fused and the plain host paths' % cos
   worst = min(float((gf[n] * gp[n]).sum() / (gf[n].norm() * gp[n].norm() + 1e-30)) for n in gf if float(gp[n].norm()) > 0)
   assert worst >= 0.7, 'worst per-variable gradient cosine %.3f' % worst
+  # the same with no convolution able to gather the pooled gradient: the fallback scatter must give the same sum
+  _, gn = _run(monkeypatch, True, name, gatherable=False)
+  fc = torch.cat([g.reshape(-1) for g in gn.values()])
+  assert float((fa * fc).sum() / (fa.norm() * fc.norm())) >= 0.97
 
 
 def test_projection_block_keeps_the_gradient_watermark_monotone(cpu_double):
