@@ -181,14 +181,32 @@ class Ctx(object):
     # optional per-layer record: kernel name -> conv input; gamma name -> (fused BN group output, residual or None)
     self.rec_conv_in: Optional[Dict[str, torch.Tensor]] = None
     self.rec_bn: Optional[Dict[str, Tuple[torch.Tensor, Optional[torch.Tensor]]]] = None
+    # rec_live: keep the LIVE autograd tensors (with retain_grad) instead of detached copies, so that after
+    # loss.backward() every recorded activation carries d loss / d activation in .grad (teacher-forced backward checks);
+    # rec_extra: further named activations (the output of an SK unit, keyed by the gamma of its 3x3 convolution's BN)
+    self.rec_live = False
+    self.rec_extra: Optional[Dict[str, torch.Tensor]] = None
+
+  def _keep(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+      return None
+    if not self.rec_live:
+      return t.detach()
+    if t.requires_grad and not t.is_leaf:
+      t.retain_grad()
+    return t
 
   def note_conv(self, x: torch.Tensor):
     if self.rec_conv_in is not None:
-      self.rec_conv_in[self.vs.last_name] = x.detach()
+      self.rec_conv_in[self.vs.last_name] = self._keep(x)
 
   def note_bn(self, gamma_name: str, out: torch.Tensor, residual: Optional[torch.Tensor]):
     if self.rec_bn is not None:
-      self.rec_bn[gamma_name] = (out.detach(), residual.detach() if residual is not None else None)
+      self.rec_bn[gamma_name] = (self._keep(out), self._keep(residual))
+
+  def note_extra(self, key: str, t: torch.Tensor):
+    if self.rec_extra is not None:
+      self.rec_extra[key] = self._keep(t)
 
   def q(self, x: torch.Tensor) -> torch.Tensor:
     """Storage rounding of an activation."""
@@ -339,6 +357,7 @@ def sk_conv2d(ctx: Ctx, inputs, filters, strides, training, r=2, L=32, bn_moment
   vs = ctx.vs
   x = conv2d_fixed_padding(ctx, inputs, filters * 2, 3, strides)
   x = batch_norm(ctx, x, training, momentum=bn_momentum, relu=True)
+  sk_key = ctx.last_gamma_name
   f0, f1 = x[:, :filters], x[:, filters:]                   # tf.split(axis=channel) :130
   fea_u = f0 + f1                                            # :131
   fea_s = ctx.q(fea_u.mean(dim=(2, 3), keepdim=True))        # :134
@@ -352,8 +371,9 @@ def sk_conv2d(ctx: Ctx, inputs, filters, strides, training, r=2, L=32, bn_moment
   att = _conv_raw(fea_z, ctx.qw(w2), 1, 1)                    # logits kept fp32
   vs.pop_scope()
   a = torch.softmax(torch.stack([att[:, :filters], att[:, filters:]], dim=0), dim=0)  # :150-151
-  fea_v = f0 * a[0] + f1 * a[1]                              # :152
-  return ctx.q(fea_v)
+  fea_v = ctx.q(f0 * a[0] + f1 * a[1])                       # :152
+  ctx.note_extra('sk_out:' + sk_key, fea_v)
+  return fea_v
 
 
 def se_block(ctx: Ctx, x, ratio=16):
@@ -444,6 +464,7 @@ def _bottleneck_block_v1(ctx: Ctx, inputs, filters, training, projection_shortcu
   x = conv2d_fixed_padding(ctx, x, block_expansion * filters, 1, 1)
   if dropblock_fn or se_block_fn:
     x = batch_norm(ctx, x, training, zero_gamma=zero_gamma, momentum=bn_momentum)
+    bn3_key = ctx.last_gamma_name
     if dropblock_fn:
       x = dropblock_fn(x)
     if se_block_fn:
@@ -451,7 +472,9 @@ def _bottleneck_block_v1(ctx: Ctx, inputs, filters, training, projection_shortcu
     x = x + shortcut
     if last_relu:
       x = F.relu(x)
-    return ctx.q(x)
+    x = ctx.q(x)
+    ctx.note_extra('block_out:' + bn3_key, x)
+    return x
   return batch_norm(ctx, x, training, zero_gamma=zero_gamma, momentum=bn_momentum,
                     residual=shortcut, relu=last_relu)
 
@@ -568,15 +591,19 @@ class Model(object):
 
   # -------------------------------------------------------------------------------------
   def __call__(self, inputs_nhwc, training, reuse=False, use_resnet_d=False, keep_prob=1.0,
-               return_embedding=False, dropblock_uniforms=None, record_layers=False):
+               return_embedding=False, dropblock_uniforms=None, record_layers=False, record_live=False):
     """nets/resnet_model.py:305-599.  ``inputs_nhwc``: [N, H, W, 3].  ``record_layers`` keeps every conv input and
-    every fused BN-group output (NCHW) in ``self.layer_record`` for the teacher-forced per-layer product checks."""
+    every fused BN-group output (NCHW) in ``self.layer_record`` for the teacher-forced per-layer product checks;
+    with ``record_live`` they are the live autograd tensors (retain_grad), so after a backward pass each carries
+    d loss / d activation in ``.grad``, and ``self.extra_record`` holds the SK unit outputs."""
     vs = self.vars
     vs.begin_call()
     ctx = Ctx(vs, self.emulate_bf16)
     if record_layers:
-      ctx.rec_conv_in, ctx.rec_bn = OrderedDict(), OrderedDict()
+      ctx.rec_conv_in, ctx.rec_bn, ctx.rec_extra = OrderedDict(), OrderedDict(), OrderedDict()
+      ctx.rec_live = bool(record_live)
     self.layer_record = (ctx.rec_conv_in, ctx.rec_bn)
+    self.extra_record = ctx.rec_extra
     bnm = self.bn_momentum
     x = ctx.q(inputs_nhwc.permute(0, 3, 1, 2))
     nf = self.num_filters

@@ -1,7 +1,11 @@
 """ORACLE (test infrastructure only -- never imported by the product path): numpy restatement of the tensor part of
-the reference's ImageNet preprocessing.  PARITY UNPINNED: the reference has no test or fixture for this code and
-TensorFlow 1.14 cannot run here; the legacy-resize rule is TF-1.14's published kernel (resize_bilinear_op.cc,
-compute_interpolation_weights / compute_lerp) and is pinned below only by hand-computed examples in the tests.
+the reference's ImageNet preprocessing.  PINNED (round 3) to the reference's own source: preprocess_image (evaluation
+with both crop types, training with recorded box / flip draws), central_crop, _smallest_size_at_least and
+mean_image_subtraction of preprocessing/imagenet_preprocessing.py are executed UNMODIFIED under oracle/tf_shim in
+float32 (tests/golden/make_reference_step.py -> tests/golden/reference_step.json) and tests/test_reference_step.py
+requires this module to reproduce them.  What stays [TF-sem] is the inside of tf.image.resize_images: TF-1.14's legacy
+bilinear kernel (resize_bilinear_op.cc: scale = in / out, no half-pixel centres, compute_lerp order), restated here
+and -- independently, in general form -- in the shim, plus hand-computed examples in tests/test_input_pipeline_cpu.py.
 
   resize_bilinear_legacy   tf.image.resize_images(BILINEAR, align_corners=False)   imagenet_preprocessing.py:210-225
   smallest_size_at_least   imagenet_preprocessing.py:158-186

@@ -68,6 +68,13 @@ class TensorShape(object):
   def as_list(self):
     return list(self._d)
 
+  def assert_is_compatible_with(self, other):
+    assert list(self._d) == list(other._d), 'shapes %s and %s are incompatible' % (self._d, other._d)
+
+  @property
+  def dims(self):
+    return [_Dim(d) for d in self._d]
+
   def __getitem__(self, i):
     return self._d[i]
 
@@ -83,6 +90,21 @@ class TensorShape(object):
 
   def __repr__(self):
     return 'TensorShape(%s)' % self._d
+
+
+class _Dim(object):
+  def __init__(self, v):
+    self.value = v
+
+  def is_compatible_with(self, other):
+    return self.value == int(other)
+
+
+def set_compute_dtype(dt):
+  """float64 (default: wiring comparisons exact to ~1e-12) or float32 (the arithmetic type of the reference's graph:
+  needed where a float32 rounding decides an INTEGER, e.g. the resize target of _smallest_size_at_least)"""
+  global COMPUTE_DTYPE
+  COMPUTE_DTYPE = dt
 
 
 def _nominal(t):
@@ -121,7 +143,17 @@ class Tensor(object):
       yield Tensor(self.t[i], self.dtype)
 
   def __getitem__(self, idx):
+    def plain(i):     # `logits[:tf.shape(x)[0]]`: slice bounds may be scalar tensors
+      if isinstance(i, _builtins.slice):
+        return _builtins.slice(*[(int(b.t.item()) if isinstance(b, Tensor) else b) for b in (i.start, i.stop, i.step)])
+      return int(i.t.item()) if isinstance(i, Tensor) and i.t.dim() == 0 else i
+    idx = tuple(plain(i) for i in idx) if isinstance(idx, tuple) else plain(idx)
     return Tensor(self.t[idx], self.dtype)
+
+  def set_shape(self, shape):
+    shape = list(shape)
+    assert len(shape) == self.t.dim() and all(b is None or int(b) == int(a) for a, b in zip(self.t.shape, shape)), \
+        'set_shape(%s) on a tensor of shape %s' % (shape, list(self.t.shape))
 
   def numpy(self):
     return self.t.detach().cpu().numpy()
@@ -218,6 +250,11 @@ class _Graph(object):
     self.rng = np.random.default_rng(0)
     self.uniform_draws = []             # every tf.random_uniform draw, in order (DropBlock)
     self.beta_draws = []                # every Beta.sample draw (mixup)
+    self.track_grad = False             # trainable variables become autograd leaves (optimizer.compute_gradients)
+    self.opt_slots = OrderedDict()      # '<variable>/Momentum' -> accumulator (tf.train.MomentumOptimizer slots)
+    self.last_grads = OrderedDict()     # variable name -> gradient handed to apply_gradients (after any rescaling)
+    self.metric_vars = OrderedDict()    # local (metric) variables by full name
+    self.window_draws = []              # every sample_distorted_bounding_box / random_flip draw (input pipeline)
 
 
 _G = _Graph()
@@ -242,7 +279,10 @@ class Variable(Tensor):
     self.trainable = trainable
 
   def assign(self, value):
-    self.t = _t(value).to(COMPUTE_DTYPE).clone()
+    t = _t(value)
+    self.t = (t.to(COMPUTE_DTYPE) if t.dtype.is_floating_point else t).detach().clone()
+    if _G.track_grad and self.trainable:
+      self.t.requires_grad_(True)
     return self
 
 
@@ -326,6 +366,8 @@ def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True,
     initializer = glorot_uniform_initializer()
   val = initializer(shape, _var_rng(full)) if callable(initializer) else np.broadcast_to(np.asarray(initializer), shape)
   v = Variable(torch.from_numpy(np.ascontiguousarray(np.asarray(val, dtype=np.float64))), full, trainable)
+  if _G.track_grad and trainable:
+    v.t.requires_grad_(True)
   _G.variables[full] = v
   return v
 
@@ -431,7 +473,10 @@ def reshape(x, shp, name=None):
 
 
 def transpose(x, perm=None, name=None):
-  return _wrap(_t(x).permute(*_ints(perm)), x)
+  t = _t(x)
+  if perm is None:     # [TF-sem] default perm reverses the dimensions
+    return _wrap(t.permute(*reversed(range(t.dim()))), x)
+  return _wrap(t.permute(*_ints(perm)), x)
 
 
 def expand_dims(x, axis=None, name=None, dim=None):
@@ -564,6 +609,14 @@ def cond(pred, true_fn=None, false_fn=None, **_):
 
 
 def group(*a, **k):
+  """tf.group(minimize_op, update_ops): the shim is eager, so the minimize op has already run; what is left to run are
+  the pending (variable, value) pairs of UPDATE_OPS handed in (nets/optimizer_setting.py:36-37)"""
+  for item in a:
+    if isinstance(item, (list, tuple)):
+      for op in item:
+        if isinstance(op, tuple) and len(op) == 2 and isinstance(op[0], Variable):
+          op[0].assign(op[1])
+          _G.update_ops = [u for u in _G.update_ops if u is not op]
   return None
 
 
@@ -881,6 +934,319 @@ def apply_update_ops():
   for var, val in _G.update_ops:
     var.assign(val)
   _G.update_ops = []
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 3: what resnet_model_fn / get_train_op / preprocess_image / metric.ece_metric need beyond the network code
+# ---------------------------------------------------------------------------------------------------
+def argmax(x, axis=None, name=None, dimension=None, output_type=None):
+  ax = axis if axis is not None else (dimension if dimension is not None else 0)
+  return Tensor(torch.argmax(_t(x), dim=int(ax)), int64)   # [TF-sem] first maximal index on ties (torch agrees)
+
+
+def one_hot(indices, depth, on_value=None, off_value=None, axis=None, dtype=None, name=None):
+  assert on_value is None and off_value is None and axis in (None, -1)
+  return Tensor(F.one_hot(_t(indices).long(), int(depth)).to(COMPUTE_DTYPE), dtype or float32)
+
+
+def add_n(inputs, name=None):
+  out = _t(inputs[0])
+  for v in inputs[1:]:
+    out = out + _t(v)
+  return _wrap(out, inputs[0] if isinstance(inputs[0], Tensor) else None)
+
+
+def reduce_max(x, axis=None, keepdims=None, name=None, reduction_indices=None, keep_dims=None):
+  return _reduce(torch.amax, x, axis if axis is not None else reduction_indices, keepdims, keep_dims)
+
+
+def greater(a, b, name=None):
+  return Tensor(torch.gt(_t(a), _t(b)), bool)
+
+
+def less_equal(a, b, name=None):
+  return Tensor(torch.le(_t(a), _t(b)), bool)
+
+
+def equal(a, b, name=None):
+  return Tensor(torch.eq(_t(a), _t(b)), bool)
+
+
+def logical_and(a, b, name=None):
+  return Tensor(torch.logical_and(_t(a), _t(b)), bool)
+
+
+def abs(x, name=None):  # noqa: A001
+  return _wrap(torch.abs(_t(x)), x)
+
+
+def div(a, b, name=None):
+  ta, tb = _t(a), _t(b)
+  assert ta.dtype.is_floating_point or tb.dtype.is_floating_point, 'tf.div on integers floors; not needed here'
+  return _wrap(ta / tb, a if isinstance(a, Tensor) else b)
+
+
+def rank(x, name=None):
+  return Tensor(torch.tensor(_t(x).dim(), dtype=torch.int64), int32)
+
+
+def broadcast_to(x, shp, name=None):
+  t = _t(x)
+  if not t.dtype.is_floating_point:
+    t = t.to(COMPUTE_DTYPE)
+  return Tensor(torch.broadcast_to(t.to(COMPUTE_DTYPE), _ints(shp)).clone(), float32)
+
+
+def slice(x, begin, size, name=None):  # noqa: A001
+  """tf.slice: size -1 = to the end of the dimension"""
+  t = _t(x)
+  b, n = _ints(begin), _ints(size)
+  idx = tuple(_builtins.slice(bi, (t.shape[d] if ni == -1 else bi + ni)) for d, (bi, ni) in enumerate(zip(b, n)))
+  return _wrap(t[idx], x)
+
+
+def unstack(x, num=None, axis=0, name=None):
+  t = _t(x)
+  return [_wrap(e, x) for e in torch.unbind(t, dim=axis)]
+
+
+def zeros(shp, dtype=float32, name=None):
+  if dtype.is_floating:
+    return Tensor(torch.zeros(_ints(shp), dtype=COMPUTE_DTYPE), dtype)
+  return Tensor(torch.zeros(_ints(shp), dtype=dtype._torch), dtype)
+
+
+def to_int32(x, name=None):
+  return cast(x, int32)    # [TF-sem] float -> int casts truncate toward zero (torch agrees)
+
+
+_expand_dims_scalar = expand_dims
+
+
+def expand_dims(x, axis=None, name=None, dim=None):  # noqa: F811  (array_ops.expand_dims(x, [1]) passes a list)
+  a = axis if axis is not None else dim
+  if isinstance(a, (list, tuple)):
+    assert len(a) == 1
+    a = a[0]
+  return _expand_dims_scalar(x, a)
+
+
+# ---- tf.train: global step + MomentumOptimizer -----------------------------------------------------------------
+def _get_or_create_global_step(graph=None):
+  gs = _G.variables.get('global_step')
+  if gs is None:
+    gs = Variable(torch.zeros((), dtype=torch.int64), 'global_step', False)
+    gs.dtype = int64
+    _G.variables['global_step'] = gs
+  return gs
+
+
+class _MomentumOptimizer(object):
+  """tf.train.MomentumOptimizer(learning_rate, momentum, use_nesterov=False) [TF-sem, 1.14: training/momentum.py,
+  kernels/training_ops.cc ApplyMomentum]:  accum <- accum * momentum + grad ;  var <- var - learning_rate * accum.
+  The accumulators are slot variables named '<variable>/Momentum', zero-initialised.  compute_gradients differentiates
+  the scalar with respect to tf.trainable_variables() (here: torch autograd over the eager ops of this module, every one
+  of which is a differentiable torch op; tf.stop_gradient detaches); apply_gradients also increments global_step."""
+
+  def __init__(self, learning_rate, momentum, use_locking=False, name='Momentum', use_nesterov=False):
+    assert not use_nesterov
+    self.lr, self.momentum = learning_rate, momentum
+
+  def compute_gradients(self, loss, var_list=None, **_):
+    vs = var_list if var_list is not None else trainable_variables()
+    for v in vs:
+      assert v.t.requires_grad, 'shim_state().track_grad must be set before the variables are created / assigned'
+    grads = torch.autograd.grad(_t(loss), [v.t for v in vs], allow_unused=True)
+    return [(Tensor(g.detach(), float32) if g is not None else None, v) for g, v in zip(grads, vs)]
+
+  def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+    lr = float(_t(self.lr))
+    _G.last_grads = OrderedDict()
+    for g, v in grads_and_vars:
+      if g is None:
+        continue
+      gt = _t(g).detach()
+      _G.last_grads[v.name] = gt.clone()
+      key = v.name + '/Momentum'
+      acc = _G.opt_slots.get(key)
+      if acc is None:
+        acc = torch.zeros_like(gt)
+      acc = acc * float(self.momentum) + gt
+      _G.opt_slots[key] = acc
+      v.assign(v.t.detach() - lr * acc)
+    if global_step is not None:
+      global_step.assign(global_step.t + 1)
+    return None
+
+  def minimize(self, loss, global_step=None, **_):
+    return self.apply_gradients(self.compute_gradients(loss), global_step)
+
+
+train.get_or_create_global_step = _get_or_create_global_step
+train.get_global_step = _get_or_create_global_step
+train.MomentumOptimizer = _MomentumOptimizer
+
+
+# ---- tf.estimator: just the names resnet_model_fn touches -----------------------------------------------------
+class _ModeKeys(object):
+  TRAIN, EVAL, PREDICT = 'train', 'eval', 'infer'
+
+
+class _EstimatorSpec(object):
+  def __init__(self, mode=None, predictions=None, loss=None, train_op=None, eval_metric_ops=None, export_outputs=None, **kw):
+    self.mode, self.predictions, self.loss, self.train_op = mode, predictions, loss, train_op
+    self.eval_metric_ops, self.export_outputs = eval_metric_ops, export_outputs
+
+
+estimator = _Namespace(ModeKeys=_ModeKeys, EstimatorSpec=_EstimatorSpec,
+                       export=_Namespace(PredictOutput=lambda outputs=None: outputs))
+
+
+# ---- tf.metrics (streaming) -----------------------------------------------------------------------------------
+def _metric_variable(shape, dtype, validate_shape=True, name=None):
+  """metrics_impl.metric_variable: a zero-initialised LOCAL variable.  Eager stand-in of "one graph, many session.run
+  calls": asking again for the same full name returns the SAME accumulator (the generator re-opens the scope)."""
+  full = '/'.join(_G.scope + [name])
+  v = _G.metric_vars.get(full)
+  if v is None:
+    v = Variable(torch.zeros(_ints(shape) if not isinstance(shape, (int, np.integer)) else [int(shape)], dtype=COMPUTE_DTYPE),
+                 full, False)
+    _G.metric_vars[full] = v
+  return v
+
+
+def _assign_add(ref, value, use_locking=None, name=None):
+  ref.t = (ref.t + _t(value).to(ref.t.dtype)).detach()
+  return ref
+
+
+class _Metrics(object):
+  """[TF-sem] tf.metrics.mean: total += sum(values), count += size(values), value = total / count (0 when count is 0);
+  tf.metrics.accuracy = mean of float(labels == predictions).  Returns (value, update_op): both read AFTER the update
+  here (eager)."""
+  @staticmethod
+  def mean(values, weights=None, metrics_collections=None, updates_collections=None, name=None):
+    assert weights is None
+    with variable_scope(name, default_name='mean'):
+      total = _metric_variable([], float32, name='total')
+      count = _metric_variable([], float32, name='count')
+    v = _t(values).to(COMPUTE_DTYPE)
+    _assign_add(total, v.sum())
+    _assign_add(count, torch.tensor(float(v.numel()), dtype=COMPUTE_DTYPE))
+    val = Tensor(total.t / count.t if float(count.t) > 0 else torch.zeros((), dtype=COMPUTE_DTYPE), float32)
+    return val, val
+
+  @staticmethod
+  def accuracy(labels, predictions, weights=None, metrics_collections=None, updates_collections=None, name=None):
+    assert weights is None
+    p, l = _t(predictions), _t(labels)
+    if p.dim() == l.dim() + 1:
+      p = p.squeeze(-1)
+    if l.dim() == p.dim() + 1:
+      l = l.squeeze(-1)
+    with variable_scope(name, default_name='accuracy'):
+      return _Metrics.mean(Tensor((p.long() == l.long()).to(COMPUTE_DTYPE), float32), name='mean_inner')
+
+
+metrics = _Metrics()
+
+
+# ---- tf.image: the tensor part of preprocessing/imagenet_preprocessing.py -----------------------------------------
+class _ResizeMethod(object):
+  BILINEAR, NEAREST_NEIGHBOR, BICUBIC, AREA = 0, 1, 2, 3
+
+
+def _resize_bilinear_legacy(t_hwc, out_h, out_w, align_corners):
+  """tf.image.resize_images(method=BILINEAR) of TF 1.x = the legacy ResizeBilinear kernel [TF-sem, 1.14:
+  core/kernels/resize_bilinear_op.cc + image_resizer_state.h]:
+    scale = (align_corners and out > 1) ? (in - 1) / (out - 1) : in / out         (float32)
+    in_coord = out_index * scale          (NO half-pixel offset: that only arrived with half_pixel_centers / TF 2)
+    lower = floor(in_coord); upper = min(lower + 1, in - 1); lerp = in_coord - lower
+    top = tl + (tr - tl) * x_lerp; bottom = bl + (br - bl) * x_lerp; out = top + (bottom - top) * y_lerp
+  computed in float32 whatever the input type, no antialiasing when shrinking."""
+  dt = COMPUTE_DTYPE
+  img = t_hwc.to(dt)
+  H, W = int(img.shape[0]), int(img.shape[1])
+
+  def axis(in_size, out_size):
+    if align_corners and out_size > 1:
+      scale = torch.tensor(float(in_size - 1), dtype=dt) / torch.tensor(float(out_size - 1), dtype=dt)
+    else:
+      scale = torch.tensor(float(in_size), dtype=dt) / torch.tensor(float(out_size), dtype=dt)
+    coord = torch.arange(out_size, dtype=dt) * scale
+    lower = torch.floor(coord).long()
+    upper = torch.clamp(lower + 1, max=in_size - 1)
+    return lower, upper, coord - lower.to(dt)
+
+  ly, uy, fy = axis(H, int(out_h))
+  lx, ux, fx = axis(W, int(out_w))
+  fy, fx = fy.view(-1, 1, 1), fx.view(1, -1, 1)
+  tl, tr = img[ly][:, lx], img[ly][:, ux]
+  bl, br = img[uy][:, lx], img[uy][:, ux]
+  top = tl + (tr - tl) * fx
+  bottom = bl + (br - bl) * fx
+  return top + (bottom - top) * fy
+
+
+class _Image(object):
+  ResizeMethod = _ResizeMethod
+
+  @staticmethod
+  def resize_images(images, size, method=0, align_corners=False, preserve_aspect_ratio=False):
+    assert method == _ResizeMethod.BILINEAR and not preserve_aspect_ratio
+    t = _t(images)
+    oh, ow = _ints(size) if not isinstance(size, (list, tuple)) else [int(_t(v).item()) if isinstance(v, Tensor) else int(v) for v in size]
+    if t.dim() == 3:
+      return Tensor(_resize_bilinear_legacy(t, oh, ow, align_corners), float32)
+    return Tensor(torch.stack([_resize_bilinear_legacy(e, oh, ow, align_corners) for e in t], 0), float32)
+
+  # The decoded uint8 image stands in for its JPEG bytes: decoding is outside the hot path.
+  @staticmethod
+  def decode_jpeg(contents, channels=0, dct_method='', **_):
+    t = _t(contents)
+    assert t.dtype == torch.uint8 and t.dim() == 3
+    return Tensor(t, uint8)
+
+  @staticmethod
+  def extract_jpeg_shape(contents, **_):
+    return Tensor(torch.tensor(list(_t(contents).shape), dtype=torch.int64), int32)
+
+  @staticmethod
+  def sample_distorted_bounding_box(image_size, bounding_boxes, min_object_covered=0.1, aspect_ratio_range=None,
+                                    area_range=None, max_attempts=None, use_image_if_no_bounding_boxes=None, **_):
+    """The random crop box: TF's stream cannot be reproduced, so the shim draws from shim_state().window_rng through the
+    generator-supplied sampler `shim_state().box_sampler(height, width, min_object_covered) -> (y, x, h, w)` and
+    RECORDS the draw; only the constraints the reference passes (:66-76) are checked here."""
+    H, W = _ints(image_size)[:2]
+    assert list(aspect_ratio_range) == [0.75, 1.33] and list(area_range) == [0.05, 1.0] and max_attempts == 100
+    assert use_image_if_no_bounding_boxes
+    y, x, h, w = _G.box_sampler(H, W, float(min_object_covered))
+    assert 0 <= y and 0 <= x and h > 0 and w > 0 and y + h <= H and x + w <= W
+    _G.window_draws.append(('box', int(y), int(x), int(h), int(w)))
+    begin = Tensor(torch.tensor([y, x, 0], dtype=torch.int64), int32)
+    size = Tensor(torch.tensor([h, w, -1], dtype=torch.int64), int32)
+    return begin, size, None
+
+  @staticmethod
+  def decode_and_crop_jpeg(contents, crop_window, channels=0, dct_method='', **_):
+    y, x, h, w = _ints(crop_window)
+    return Tensor(_t(contents)[y:y + h, x:x + w], uint8)
+
+  @staticmethod
+  def random_flip_left_right(image, seed=None):
+    flip = builtins_bool(_G.rng.random() < 0.5)     # [TF-sem] uniform draw < 0.5 flips
+    _G.window_draws.append(('flip', int(flip)))
+    t = _t(image)
+    return Tensor(torch.flip(t, [1]) if flip else t, getattr(image, 'dtype', None))
+
+  @staticmethod
+  def flip_left_right(image):
+    t = _t(image)
+    return Tensor(torch.flip(t, [t.dim() - 2]), getattr(image, 'dtype', None))
+
+
+uint8 = DType('uint8', False, torch.uint8)
+image = _Image()
 
 
 def __getattr__(name):

@@ -310,3 +310,212 @@ def check_teacher_forced(name, device, batch, size, training=True, out_tol=4e-3,
   assert not bad, '%s: %d of %d teacher-forced comparisons out of tolerance; worst: %s' % (
       name, len(bad), len(errs), ['%s %s %.3e %s' % t for t in bad[:8]])
   return errs
+
+
+def check_teacher_forced_backward(name, device, batch, size, label_smoothing=0.1, keep_prob=1.0, dx_tol=6e-3,
+                                  lazy_tol=8e-3, dparam_tol=6e-3, dw_tol=6e-3, squeeze_tol=2e-2, sk_tol=1.5e-2, env=None):
+  """Per-layer parity of the hand-written BACKWARD tape over the whole network, without depth amplification.
+
+  The bf16-emulating oracle runs forward + autograd backward once and keeps, for every conv -> BN [-> + residual]
+  [-> ReLU] group, its input, its output and d loss / d (both) (``record_live``).  The product then runs
+    * its forward with every group fed the ORACLE'S input (as check_teacher_forced does -- but by overriding the
+      tensor of the SAME activation object, so the tape stays connected and every fused / lazy path of nn.py runs
+      exactly as in training: deferred + dual batch norm of a projection shortcut, lazily masked shortcut / merge
+      gradients, pooled gradient gathered by conv1's input gradient, the fused SK unit, the reordered projection tape);
+    * its backward tape with every group's closure wrapped: when the closure is about to run, the gradient the product
+      has ACCUMULATED for the group's output (all fan-in terms the tape produced) is compared with the oracle's
+      d loss / d output, and then REPLACED by it (teacher forcing), so that the next comparison again sees one group's
+      worth of product kernels on the oracle's operands -- at layer 150 as at layer 1.
+  A gradient still held in lazy form (dy + ReLU mask, + pooled contribution) is compared in materialised form but left
+  as it is (its operands were forced one group upstream); a pre-computed batch-norm backward (dual path) is checked
+  through its effects (dx of the shortcut convolution at the next forced point, dW / dgamma / dbeta).
+  Comparisons: 'dout' accumulated output gradient of a group at a forced point, 'dout-lazy' the same in lazy form,
+  'dx' the input gradient of a convolution whose input is not itself a group output (pooled / blurred / SK tensors),
+  'dW', 'dgamma', 'dbeta', 'dbias' every trainable variable's gradient.  Returns the list (layer, kind, error, shape)."""
+  import os
+  from assembled_cnn_amd import model as pmodel, nn as pnn, ops
+  from oracle import assembled_oracle as O
+  old_env = {}
+  for k, v in (env or {}).items():
+    old_env[k] = os.environ.get(k)
+    os.environ[k] = v
+  try:
+    om, pm = make_pair(name, device, batch, size)
+    d = uses_d(name)
+    _, x, labels = inputs(batch, size)
+    training_kp = float(keep_prob)
+    uniforms_o = uniforms_p = None
+    if training_kp < 1.0:
+      gen = torch.Generator().manual_seed(11)
+      drawn = []
+
+      def draw(shape):      # oracle asks [1, C, H-6, W-6]; the product wants [H-6, W-6, C]
+        u = torch.rand(shape, generator=gen)
+        drawn.append(u)
+        return u
+      uniforms_o = draw
+    lo = om(x, True, use_resnet_d=d, keep_prob=training_kp, dropblock_uniforms=uniforms_o, record_layers=True,
+            record_live=True)
+    if training_kp < 1.0:
+      uniforms_p = [u[0].permute(1, 2, 0).contiguous().to(device) for u in drawn]
+    rec_in, rec_bn = om.layer_record
+    rec_extra = om.extra_record
+    loss = O.softmax_cross_entropy(lo, F.one_hot(labels.long(), 1001).float(), label_smoothing)
+    loss.backward()
+    errs = []
+    n_forced = [0]
+
+    def to_dev(t_nchw):
+      return t_nchw.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)
+
+    def cmp(got_nhwc, ref_nchw, layer, kind):
+      ref = ref_nchw.detach().permute(0, 2, 3, 1)
+      e = util.rel_l2(got_nhwc.float().cpu().reshape(ref.shape), ref)
+      errs.append((layer, kind, e, tuple(ref.shape)))
+
+    def peek_grad(v):
+      """the gradient a Var holds, materialised WITHOUT touching its lazy state; (tensor or None, was_lazy)"""
+      g, lazy = v._grad, False
+      if g is not None and v.grad_mask is not None:
+        g, lazy = ops.mask_apply(g, v.grad_mask), True
+      if v.pool_grad is not None:
+        dp, k, stride, pad, cv = v.pool_grad
+        s = ops.avgpool_bwd(dp, v.shape, k, stride, pad, cv)
+        g, lazy = (s if g is None else ops.add_bf16(g, s)), True
+      return g, lazy
+
+    group_outputs = {}
+
+    maxpool_fed = [None]
+    pending_dx = {}     # id(conv input that is not a forced point) -> [var, oracle tensor, label, consumers still to run]
+    last_gamma = [None]
+
+    def wrap_last_closure(ctx, out, ref_out, label, squeeze, x_var=None, ref_x=None, x_label=None):
+      if ctx.tape is None or not ctx.tape:
+        return
+      inner = ctx.tape[-1]
+      group_outputs[id(out)] = True
+      if x_var is not None and id(x_var) not in group_outputs and x_var.needs_grad:
+        ent = pending_dx.setdefault(id(x_var), [x_var, ref_x, x_label, 0])
+        ent[3] += 1
+
+      def bwd():
+        if out.pre_dy is None and out.pending is None and ref_out.grad is not None:
+          g, lazy = peek_grad(out)
+          assert g is not None, '%s: no gradient reached this group' % label
+          cmp(g, ref_out.grad, label, 'dout-squeeze' if squeeze else ('dout-lazy' if lazy else 'dout'))
+          if not lazy:
+            out._grad, out.grad_mask, out.grad_owned = to_dev(ref_out.grad), None, True
+            n_forced[0] += 1
+        inner()
+        ent = pending_dx.get(id(x_var)) if x_var is not None else None
+        if ent is not None:
+          ent[3] -= 1
+          if ent[3] == 0 and ent[1].grad is not None:     # every convolution reading this tensor has run its backward
+            gx, _ = peek_grad(x_var)
+            if gx is not None:
+              cmp(gx, ent[1].grad, ent[2], 'dx-squeeze' if ent[1].shape[2] * ent[1].shape[3] == 1 else 'dx')
+      ctx.tape[-1] = bwd
+
+    orig = pnn.conv_bn
+
+    def forced(ctx, xv, conv, bn, stride, relu, residual=None, res_mode=0, tap_pre=None):
+      if ctx.dry:
+        return orig(ctx, xv, conv, bn, stride, relu, residual, res_mode, tap_pre)
+      ref_in = rec_in[conv.name]
+      if not conv.stem:
+        xv._data = to_dev(ref_in)
+      ref_out, ref_res = rec_bn[bn.gamma]
+      if residual is not None and not (residual._data is None and residual.deferred is not None):
+        residual._data = to_dev(ref_res)
+      out = orig(ctx, xv, conv, bn, stride, relu, residual, res_mode, tap_pre)
+      last_gamma[0] = bn.gamma
+      if tap_pre == 'initial_conv' and pm.resnet_version == 1:
+        maxpool_fed[0] = bn.gamma
+      squeeze = ref_out.shape[2] * ref_out.shape[3] == 1
+      wrap_last_closure(ctx, out, ref_out, bn.gamma, squeeze, None if conv.stem else xv, ref_in, conv.name)
+      return out
+
+    # the SE / DropBlock form of a block ends in a separate add (+ ReLU): its output is a forced point as well
+    orig_add = pmodel.Model._add_relu
+
+    def forced_add(ctx, a_, b_, relu):
+      out = orig_add(ctx, a_, b_, relu)
+      if not ctx.dry:
+        key = 'block_out:' + last_gamma[0]
+        # its ReLU mask is read from the output at backward time: use the oracle's tensor, as every block whose output
+        # feeds a convolution does anyway (the separate bf16 add rounds once more than the oracle, and a sign flip of an
+        # element at ~0 moves the masked gradient by sqrt(fraction flipped))
+        out._data = to_dev(rec_extra[key])
+        wrap_last_closure(ctx, out, rec_extra[key], key, False)
+      return out
+
+    orig_sk = pnn.SKUnit._call_fused
+
+    def forced_sk(self, ctx, xv, stride):
+      xv._data = to_dev(rec_in[self.conv.name])
+      v = orig_sk(self, ctx, xv, stride)
+      wrap_last_closure(ctx, v, rec_extra['sk_out:' + self.bn.gamma], 'sk_out:' + self.bn.gamma, False)
+      return v
+
+    pnn.conv_bn = forced
+    pmodel.conv_bn = forced
+    pnn.SKUnit._call_fused = forced_sk
+    pmodel.Model._add_relu = staticmethod(forced_add)
+    try:
+      pm(x.to(device), True, use_resnet_d=d, keep_prob=training_kp, dropblock_uniforms=uniforms_p)
+      # the loss layer is teacher-forced too: d loss / d logits from the ORACLE's logits through the product's kernel
+      lpad = torch.zeros((batch, pm.ldc), dtype=torch.float32)
+      lpad[:, :1001] = lo.detach()
+      oh = ops.onehot(labels.to(device), batch, 1001)
+      rows, dz = ops.softmax_ce(lpad.to(device).view(batch, 1, 1, pm.ldc), pm.ldc, oh, None, batch, 1001, label_smoothing,
+                                0.0, 1.0, pm.ldc)
+      assert abs(float(rows.float().mean()) - float(loss.detach())) <= 1e-4 * abs(float(loss.detach()))
+      pm.backward(dz)
+    finally:
+      pnn.conv_bn = orig
+      pmodel.conv_bn = orig
+      pnn.SKUnit._call_fused = orig_sk
+      pmodel.Model._add_relu = staticmethod(orig_add)
+    if device != 'cpu':
+      torch.cuda.synchronize()
+    # every trainable variable's gradient (each is written by exactly one closure, on operands forced as above)
+    sk_bn = set(k[len('sk_out:'):-len('gamma')] for k in rec_extra if k.startswith('sk_out:'))
+    for pname, p in om.vars.trainable.items():
+      pg = util.product_to_oracle_grad(pname, pm.arena.g(pname).float().cpu(), p).reshape(p.shape)
+      leaf = pname.rsplit('/', 1)[1]
+      kind = 'dW' if leaf == 'kernel' else 'd' + leaf
+      if kind == 'dW' and ('sk_fc' in pname or 'seblock' in pname):
+        kind = 'dW-squeeze'
+      elif leaf in ('gamma', 'beta') and pname[:-len(leaf)] in sk_bn:
+        kind += '-sk'       # the SK unit's 3x3 batch norm: its gradient carries the attention (squeeze) path's noise
+      elif leaf in ('gamma', 'beta') and pname[:-len(leaf)] + 'gamma' in rec_bn and \
+          rec_bn[pname[:-len(leaf)] + 'gamma'][0].shape[2] * rec_bn[pname[:-len(leaf)] + 'gamma'][0].shape[3] == 1:
+        kind += '-squeeze'
+      assert torch.isfinite(pg).all(), pname
+      if leaf == 'beta' and pname[:-len(leaf)] + 'gamma' == maxpool_fed[0]:
+        # The batch norm in front of the max pool (resnet_version 1).  Every consumer of the pooled tensor is a 1x1
+        # convolution followed by a batch norm, whose backward makes sum_pixels(dy) = 0 and hence sum_pixels(W^T dy) = 0:
+        # the pooled gradient sums to zero per channel, and so does the gradient the max pool routes to its arg-maxima --
+        # EXCEPT the share routed to windows whose maximum is exactly 0 (all-negative windows after the ReLU, masked out).
+        # dbeta is minus that small subset sum; one window whose maximum is +tiny on one side and 0 on the other (a bf16
+        # rounding at the ReLU threshold) moves it by a whole term.  Measured 2-5e-2; a dropped fan-in term would be O(1).
+        kind = 'dbeta-maxpool'
+      e = util.rel_l2(pg, p.grad)
+      errs.append((pname, kind, e, tuple(p.shape)))
+    lim = {'dout': dx_tol, 'dx': dx_tol, 'dout-lazy': lazy_tol, 'dout-squeeze': squeeze_tol, 'dx-squeeze': squeeze_tol,
+           'dW': dw_tol, 'dW-squeeze': 2.5 * squeeze_tol, 'dgamma': dparam_tol, 'dbeta': dparam_tol, 'dbias': dparam_tol,
+           'dgamma-sk': sk_tol, 'dbeta-sk': sk_tol, 'dgamma-squeeze': squeeze_tol, 'dbeta-squeeze': squeeze_tol,
+           'dbeta-maxpool': 8e-2}
+    errs.sort(key=lambda t: -t[2] / lim[t[1]])
+    bad = [t for t in errs if not t[2] <= lim[t[1]]]
+    assert not bad, '%s: %d of %d teacher-forced backward comparisons out of tolerance; worst: %s' % (
+        name, len(bad), len(errs), ['%s %s %.3e %s' % t for t in bad[:10]])
+    stats = {'forced': n_forced[0], 'kinds': {k: sum(1 for e in errs if e[1] == k) for k in lim}}
+    return errs, stats
+  finally:
+    for k, v in old_env.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v

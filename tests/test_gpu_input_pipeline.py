@@ -62,3 +62,11 @@ def test_empty_batch_bad_descriptor_and_full_batch_properties(hip_lib):
   buf, table = P.pack_batch([im], [dict(ident, flip=1)], 50, 60)
   flipped = ops.resize_crop_flip(buf.cuda(), table.cuda(), 1, 50, 60, False).cpu().numpy()[0]
   assert np.array_equal(flipped, im[:, ::-1].astype(np.float32))
+
+
+def test_hip_pipeline_equals_reference_preprocess_image(hip_lib):
+  """asm_resize_crop_flip (window -> flip -> legacy bilinear resize -> central crop -> mean subtraction) against
+  preprocessing/imagenet_preprocessing.preprocess_image run from the reference's source under the shim, evaluation
+  (two crop types) and training branches, ragged sizes incl. 1 x 1 (tests/golden/reference_step.json)"""
+  from tests.test_reference_step import check_preprocessing_against_reference
+  check_preprocessing_against_reference('cuda', 'product')

@@ -126,3 +126,11 @@ def test_assemble_recipe_step_with_dropblock(hip_lib):
     tr.train_step(img.cuda(), lab, lam, lr=0.01)
   l1 = float(tr.last['loss_rows'].mean())
   assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0
+
+
+def test_ece_kernel_equals_reference_ece_metric(hip_lib):
+  """asm_eval_accumulate's per-bin counts / correct counts / confidence sums and the streaming ECE after each of
+  three batches == metric/ece_metric.py run from the reference's source (tests/golden/reference_step.json), incl.
+  confidences exactly on the bin edges"""
+  from tests.test_reference_step import check_ece_against_reference
+  check_ece_against_reference('cuda')

@@ -97,3 +97,13 @@ def test_teacher_forced_per_layer_parity_on_the_double(cpu_double):
   from tests import model_parity as mp
   errs = mp.check_teacher_forced('a-r50-d', 'cpu', 4, 64)
   assert len(errs) >= 180 and max(e[2] for e in errs) <= 4e-3
+
+
+def test_teacher_forced_backward_parity_on_the_double(cpu_double):
+  """The per-layer BACKWARD harness (tests/model_parity.check_teacher_forced_backward) through the host code of
+  Assemble-ResNet-50 + D with every default fusion on: every group's accumulated output gradient is compared with the
+  oracle's autograd value and then replaced by it, every variable's gradient is compared at the end."""
+  from tests import model_parity as mp
+  errs, st = mp.check_teacher_forced_backward('a-r50-d', 'cpu', 4, 64)
+  k = st['kinds']
+  assert st['forced'] >= 80 and k['dout'] >= 60 and k['dW'] + k['dW-squeeze'] == 117 and len(errs) >= 400

@@ -1,0 +1,281 @@
+"""The oracle (and the product's host code) against MORE OF THE REFERENCE'S OWN SOURCE (round 3).
+
+tests/golden/reference_step.json was produced by importing, UNMODIFIED, under the torch-backed `tensorflow` stand-in of
+oracle/tf_shim (tests/golden/make_reference_step.py):
+
+  nets/run_loop_classification.py:60-234   resnet_model_fn (KD label split, mixup call, CE + L2 + KD, train metrics)
+  nets/optimizer_setting.py:23-38          get_train_op (loss scaling, MomentumOptimizer, UPDATE_OPS)
+  metric/ece_metric.py:171-298             ece()
+  preprocessing/imagenet_preprocessing.py  preprocess_image, central_crop, _smallest_size_at_least, mean subtraction
+
+so SURVEY 8a rows a12 (KD + L2 + total loss) and a14 (get_train_op) and the "next" rows f2 (input pipeline tail) and f3
+(evaluation metrics) are pinned to the reference's code the way a1-a11 are.  [TF-sem] stays what it was: the rules INSIDE
+a tf op (MomentumOptimizer's update, the legacy bilinear kernel, tf.metrics) are restated in the shim in general form,
+independently of the oracle.  When /root/reference is present the fixture is regenerated and must reproduce."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+from name_seeded import tap_summary, value_for  # noqa: E402
+
+FIX = json.load(open(os.path.join(HERE, 'golden', 'reference_step.json')))
+
+ASSEMBLE = dict(resnet_size=50, resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3)
+STEP_KW = {'r50v1-ls': (dict(resnet_size=50), False), 'r50v1-ls-scale128': (dict(resnet_size=50), False),
+           'a-r50-d-mixup1-ls': (ASSEMBLE, True), 'r50v1-kd-mixup2': (dict(resnet_size=50), False)}
+
+
+def _close(a, b, what, rel):
+  a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  assert a.shape == b.shape, '%s: shape %s vs %s' % (what, a.shape, b.shape)
+  err = float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
+  assert err <= rel, '%s: max rel err %.3e' % (what, err)
+
+
+def _check_summary(arr, ref, what, rel):
+  s = tap_summary(np.asarray(arr), len(ref['idx']))
+  assert s['shape'] == ref['shape'], '%s: shape %s vs reference %s' % (what, s['shape'], ref['shape'])
+  scale = max(ref['abs_sum'] / max(int(np.prod(ref['shape'])), 1), 1e-30)       # mean magnitude of the tensor
+  assert float(np.abs(np.asarray(s['vals']) - np.asarray(ref['vals'])).max()) <= rel * max(scale, float(np.abs(ref['vals']).max())), \
+      what + ' samples'
+  assert abs(s['abs_sum'] - ref['abs_sum']) <= rel * max(ref['abs_sum'], 1e-30), what + ' sum of magnitudes'
+  assert abs(s['sum'] - ref['sum']) <= rel * max(ref['abs_sum'], 1e-30), what + ' sum'
+
+
+def _step_inputs(fx):
+  """the generator's seeded inputs (tests/golden/make_reference_step.py: rng(21) draws images, labels, teacher logits)"""
+  rng = np.random.default_rng(fx['seed'])
+  n, size = fx['images_in'], fx['input_size']
+  img = rng.integers(0, 256, size=(n, size, size, 3)).astype(np.float64)
+  labels = rng.integers(1, 1001, size=n)
+  teacher = rng.normal(0, 3, size=(n, 1001))
+  assert labels.tolist() == fx['labels']
+  return img, labels, teacher
+
+
+@pytest.mark.parametrize('name', sorted(STEP_KW))
+def test_oracle_train_step_equals_resnet_model_fn_and_get_train_op(name):
+  """Two consecutive optimisation steps: total loss, cross entropy, KD term, every gradient get_train_op applied, and
+  -- after the second step -- every variable, every moving statistic and every Momentum slot."""
+  from oracle import assembled_oracle as O
+  fx = FIX['steps'][name]
+  kw, use_d = STEP_KW[name]
+  hp = fx['hp']
+  img, labels, teacher = _step_inputs(fx)
+  m = O.Model(num_classes=1001, param_dtype=torch.float64, bn_momentum=fx['bn_momentum'], **kw)
+  x = torch.from_numpy(img - np.array(O.CHANNEL_MEANS))
+  m(x[:2], True, use_resnet_d=use_d)
+  m.vars.pending_updates = {}
+  with torch.no_grad():
+    for n, t in m.vars.trainable.items():
+      t.copy_(torch.from_numpy(value_for(n, list(t.shape))))
+    for n in list(m.vars.state.keys()):
+      m.vars.state[n] = torch.from_numpy(value_for(n, list(m.vars.state[n].shape)))
+  state = O.TrainState(m)
+  if hp['kd_temp'] > 0:
+    lab = torch.from_numpy(np.concatenate([np.eye(1001)[labels], teacher], 1))
+  else:
+    lab = torch.from_numpy(labels)
+  # float64 both sides, but batch statistics over 4..16 values amplify summation-order rounding: measured 1e-8 (loss) /
+  # 2e-7 (gradients) at the first step of the 19-block Assemble network and 3e-5 at its second step (every variable
+  # uniformly: chaos, not wiring -- a wiring difference is O(1) in the variables it touches); ResNet-50 stays at 1e-9
+  rel = 2e-6
+  grel = (1e-5, 3e-4)
+  names = list(m.vars.trainable.keys())
+  for k, ref in enumerate(fx['steps']):
+    lams = [torch.tensor(l, dtype=torch.float64) for l in ref['lams']]
+    assert len(lams) == {0: 0, 1: 1, 2: 2}[hp['mixup_type']]
+    r = O.train_step(state, x, lab, lr=ref['learning_rate'], momentum=hp['momentum'], weight_decay=hp['weight_decay'],
+                     label_smoothing=hp['label_smoothing'], kd_temp=hp['kd_temp'], mixup_type=hp['mixup_type'],
+                     lam1=lams[0] if lams else None, lam2=lams[1] if len(lams) > 1 else None, use_resnet_d=use_d,
+                     loss_scale=float(hp['loss_scale']))
+    what = '%s step %d ' % (name, k)
+    _close([float(r['loss'])], [ref['loss']], what + 'total loss', rel)
+    _close([float(r['parts']['cross_entropy'])], [ref['cross_entropy']], what + 'cross entropy', rel)
+    if hp['kd_temp'] > 0:
+      _close([float(r['parts']['cross_entropy_kd'])], [ref['cross_entropy_kd']], what + 'KD term', rel)
+    assert ref['global_step_after'] == k + 1 == state.global_step
+    grads = dict(zip(names, r['grads']))
+    assert set(ref['grads']) <= set(grads)
+    if hp['loss_scale'] == 1:
+      assert len(ref['grads']) == fx['n_grads'] == len(names), 'get_train_op differentiates every trainable variable'
+    for n, s in ref['grads'].items():
+      _check_summary(grads[n].numpy(), s, what + 'gradient of ' + n, grel[min(k, 1)])
+    if hp['mixup_type'] == 0:      # train metrics of resnet_model_fn (:208-219): accuracy, top-5, ECE of this batch
+      logits = r['logits']
+      assert logits.argmax(1).tolist() == ref['classes']
+      acc = float((logits.argmax(1) == torch.from_numpy(labels)).double().mean())
+      top5 = float(torch.tensor([int(labels[i]) in logits[i].topk(5).indices.tolist() for i in range(len(labels))]).double().mean())
+      assert abs(acc - ref['metrics']['accuracy']) <= 1e-12 and abs(top5 - ref['metrics']['accuracy_top_5']) <= 1e-12
+  last = fx['steps'][-1]
+  for n, s in last['variables_after'].items():
+    t = m.vars.trainable[n] if n in m.vars.trainable else m.vars.state[n]
+    _check_summary(t.detach().numpy(), s, name + ' variable after 2 steps ' + n, 1e-5)
+  accums = dict(zip(names, state.accums))
+  for n, s in last['momentum_after'].items():
+    assert n.endswith('/Momentum')
+    _check_summary(accums[n[:-len('/Momentum')]].numpy(), s, name + ' slot ' + n, grel[1])
+  if hp['loss_scale'] == 1:
+    assert len(last['momentum_after']) == len(names)
+
+
+def test_loss_scale_changes_nothing_but_rounding():
+  a, b = FIX['steps']['r50v1-ls'], FIX['steps']['r50v1-ls-scale128']
+  for sa, sb in zip(a['steps'], b['steps']):
+    assert abs(sa['loss'] - sb['loss']) <= 1e-9 * abs(sa['loss'])
+    for n, s in sb['grads'].items():
+      _close(s['vals'], sa['grads'][n]['vals'][:len(s['vals'])], 'gradient of ' + n, 1e-9)
+
+
+def test_product_lr_and_loss_scale_wiring_match_the_step_fixture():
+  """model_fn_cls's schedule as the step saw it (learning_rate tap) == the product's host schedule function"""
+  from assembled_cnn_amd import train
+  for name, fx in FIX['steps'].items():
+    fn = train.learning_rate_with_decay('cosine', 1024, 1024, 1281167, 2.0, 0.94, 1e-4, [30, 60, 80, 90],
+                                        [1, 0.1, 0.01, 0.001, 1e-4], fx['hp']['base_lr'], warmup_epochs=0, train_epochs=120)
+    for k, ref in enumerate(fx['steps']):
+      assert abs(fn(k) - ref['learning_rate']) <= 1e-12 * ref['learning_rate']
+
+
+def test_product_trainer_on_the_double_tracks_the_reference_step(cpu_double):
+  """The product's Trainer (host code over the CPU double of the C ABI, bf16 storage) fed the fixture's weights and
+  batch: its cross entropy follows the reference's two steps (bf16 vs float64: 1 %)."""
+  from assembled_cnn_amd import train
+  from oracle import assembled_oracle as O
+  from tests import util
+  name = 'r50v1-ls'
+  fx = FIX['steps'][name]
+  hp_ = fx['hp']
+  img, labels, _ = _step_inputs(fx)
+  om = O.Model(num_classes=1001, bn_momentum=fx['bn_momentum'], resnet_size=50)
+  om(torch.zeros(2, 64, 64, 3), True)
+  with torch.no_grad():
+    for n, t in om.vars.trainable.items():
+      t.copy_(torch.from_numpy(value_for(n, list(t.shape))).float())
+    for n in list(om.vars.state.keys()):
+      om.vars.state[n] = torch.from_numpy(value_for(n, list(om.vars.state[n].shape))).float()
+  hp = train.HParams(resnet_size=50, bn_momentum=fx['bn_momentum'], label_smoothing=hp_['label_smoothing'],
+                     weight_decay=hp_['weight_decay'], momentum=hp_['momentum'], batch_size=fx['images_in'])
+  tr = train.Trainer(hp, device='cpu')
+  tr.model.build((64, 64))
+  util.load_oracle_into_product(om, tr.model)
+  for k, ref in enumerate(fx['steps']):
+    tr.train_step(torch.from_numpy(img).float(), torch.from_numpy(labels).to(torch.int32), lr=ref['learning_rate'])
+    ce = float(tr.cross_entropy())
+    # step 0: the same weights, bf16 storage vs float64; step 1: after one lr = 0.05 update on 4 images (the loss falls
+    # from 6.9 to 4.4 in that single step, so the second value is sensitive to the first update's rounding)
+    assert abs(ce - ref['cross_entropy']) <= (1e-2, 1e-1)[k] * ref['cross_entropy'], (k, ce, ref['cross_entropy'])
+  # the L2 term of the first step: loss - CE of the fixture, against the product's own report BEFORE that update
+  # is not recoverable after the fact, so check the formula on the fixture's weights instead
+  tot = 0.0
+  for n, t in om.vars.trainable.items():
+    if 'batch_normalization' not in n:
+      tot += 0.5 * float((torch.from_numpy(value_for(n, list(t.shape))) ** 2).sum())
+  first = fx['steps'][0]
+  assert abs(hp_['weight_decay'] * tot - (first['loss'] - first['cross_entropy'])) <= 1e-9 * first['loss']
+
+
+# ---- ECE (metric/ece_metric.py) -----------------------------------------------------------------------------------
+def _ece_from_state(st):
+  correct, conf, cnt = st[3:13].double(), st[13:23].double(), st[23:33].double()
+  eps = 1e-7
+  return float(((cnt / cnt.sum()) * ((correct / (eps + cnt)) - (conf / (eps + cnt))).abs()).sum())
+
+
+def check_ece_against_reference(device):
+  """streaming accumulation over three batches through asm_eval_accumulate: per-bin sums and the ECE after every
+  batch equal the reference's accumulators / update_op values, incl. confidences exactly on bin edges"""
+  from assembled_cnn_amd import ops, train
+  state = torch.zeros(33, dtype=torch.float32, device=device)
+  for b, ref in enumerate(FIX['ece']['batches']):
+    conf = torch.tensor(ref['conf'], dtype=torch.float32, device=device)
+    top1 = torch.tensor([float(p == l) for p, l in zip(ref['pred'], ref['label'])], dtype=torch.float32, device=device)
+    ops.eval_accumulate(conf, top1, top1, state)
+    st = state.cpu()
+    acc = ref['accumulators']
+    assert st[23:33].tolist() == acc['count_per_bin'], 'batch %d: per-bin counts' % b
+    assert st[3:13].tolist() == acc['accuracy_per_bin'], 'batch %d: per-bin correct counts' % b
+    _close(st[13:23].numpy(), acc['confidence_per_bin'], 'batch %d: per-bin confidence sums' % b, 1e-6)
+    assert abs(_ece_from_state(st) - ref['ece_update']) <= 1e-6
+    assert ref['ece_update'] == ref['ece_value']
+  tr = train.Trainer.__new__(train.Trainer)      # eval_result only reads eval_state
+  tr.eval_state = state
+  assert abs(tr.eval_result(reduce=False)['ece'] - FIX['ece']['batches'][-1]['ece_update']) <= 1e-6
+
+
+def test_ece_accumulators_equal_the_reference_on_the_double(cpu_double):
+  check_ece_against_reference('cpu')
+
+
+# ---- preprocessing (preprocessing/imagenet_preprocessing.py) ---------------------------------------------------------
+def _eval_images():
+  rng = np.random.default_rng(FIX['preprocessing']['seed'])
+  return [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for (h, w) in [(75, 100), (100, 67), (64, 64), (58, 160), (49, 49), (1, 1)]]
+
+
+def test_resize_targets_equal_smallest_size_at_least_in_float32():
+  from assembled_cnn_amd import input_pipeline as P
+  from oracle import input_oracle as IO
+  for h, w, m, nh, nw in FIX['preprocessing']['sizes']:
+    assert IO.smallest_size_at_least(h, w, m) == (nh, nw), (h, w, m)
+    assert P.smallest_size_at_least(h, w, m) == (nh, nw), (h, w, m)
+  assert FIX['preprocessing']['channel_means'] == [float(v) for v in np.float64(IO.CHANNEL_MEANS.astype(np.float64))] or \
+      np.allclose(FIX['preprocessing']['channel_means'], IO.CHANNEL_MEANS)
+
+
+def check_preprocessing_against_reference(device, which):
+  """`which`: 'oracle' (oracle/input_oracle.py) or 'product' (input_pipeline.preprocess_batch through the C ABI)"""
+  from assembled_cnn_amd import input_pipeline as P
+  from oracle import input_oracle as IO
+  fx = FIX['preprocessing']
+  imgs = _eval_images()
+  for ref in fx['eval']:
+    im, side, ct = imgs[ref['image']], ref['side'], ref['crop_type']
+    if which == 'oracle':
+      out = IO.preprocess_eval(im, side, side, crop_type=ct)
+    else:
+      win = P.eval_window(im.shape[0], im.shape[1], side, side, ct)
+      out = P.preprocess_batch([im], False, device, windows=[win], image_size=side,
+                               preprocessing_type='imagenet_%03d%s' % (side, 'a' if ct else ''))[0].cpu().numpy()
+    _check_summary(out, ref['out'], '%s eval image %d side %d crop_type %d' % (which, ref['image'], side, ct), 1e-6)
+  for ref in fx['train']:
+    im = np.random.default_rng(ref['image_seed']).integers(0, 256, size=(ref['h'], ref['w'], 3), dtype=np.uint8)
+    y, x, h, w, flip = ref['window']
+    if which == 'oracle':
+      out = IO.preprocess_train_window(im, (y, x, h, w, flip), ref['side'], ref['side'])
+    else:
+      win = dict(crop_y=y, crop_x=x, crop_h=h, crop_w=w, resize_h=ref['side'], resize_w=ref['side'], out_y=0, out_x=0, flip=flip)
+      out = P.preprocess_batch([im], True, device, windows=[win], image_size=ref['side'])[0].cpu().numpy()
+    if not ref['use_random_crop']:
+      assert (y, x, h, w) == (0, 0, ref['h'], ref['w'])     # min_object_covered = 1.0: the whole image
+    _check_summary(out, ref['out'], '%s train image %d' % (which, ref['image_seed']), 1e-6)
+
+
+def test_input_oracle_equals_reference_preprocess_image():
+  check_preprocessing_against_reference('cpu', 'oracle')
+  from oracle import input_oracle as IO
+  cc = FIX['preprocessing']['central_crop']
+  a = np.random.default_rng(FIX['preprocessing']['seed'])
+  assert np.asarray(cc['out']).shape == (6, 9, 3)
+  with pytest.raises(ValueError) as ei:
+    IO.mean_image_subtraction(np.zeros((1, 4, 4, 3), np.float32))
+  assert str(ei.value) == FIX['preprocessing']['mean_sub_rank_error']
+
+
+def test_product_pipeline_equals_reference_preprocess_image_on_the_double(cpu_double):
+  check_preprocessing_against_reference('cpu', 'product')
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference tree is only in the build container')
+def test_step_fixture_reproduces_from_the_reference_source():
+  r = subprocess.run([sys.executable, os.path.join(HERE, 'golden', 'make_reference_step.py'), '--check'],
+                     capture_output=True, text=True, timeout=1500)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
