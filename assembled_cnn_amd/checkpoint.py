@@ -19,14 +19,19 @@ import torch
 
 from .model import Model
 
+MOMENTUM_SLOT = '/Momentum'   # tf.train.MomentumOptimizer's slot variable name (nets/optimizer_setting.py:29)
+
 
 def _is_dense_kernel(name: str) -> bool:
   """tf.layers.dense kernels ([in, units]) are the ones whose LAYER is named dense / dense_N; 'embedding_dense' is a
-  tf.layers.conv2d (nets/resnet_model.py:576-580) and keeps the 4-D HWIO layout [1, 1, in, emb]."""
+  tf.layers.conv2d (nets/resnet_model.py:576-580) and keeps the 4-D HWIO layout [1, 1, in, emb].  Also true for the
+  kernel's optimiser slot ``<kernel>/Momentum``."""
+  if name.endswith(MOMENTUM_SLOT):
+    name = name[:-len(MOMENTUM_SLOT)]
   parts = name.split('/')
-  if len(parts) < 2 or parts[-1] not in ('kernel', 'kernel/Momentum') and parts[-2:] != ['kernel', 'Momentum']:
+  if len(parts) < 2 or parts[-1] != 'kernel':
     return False
-  layer = parts[-3] if parts[-1] == 'Momentum' else parts[-2]
+  layer = parts[-2]
   return layer == 'dense' or (layer.startswith('dense_') and layer[6:].isdigit())
 
 
@@ -53,8 +58,6 @@ def _from_tf_layout(name: str, a: np.ndarray, like: torch.Tensor) -> torch.Tenso
                      % (name, tuple(np.asarray(a).shape), tuple(like.shape), 'HWIO' if like.dim() == 4 else 'as is'))
   return t
 
-
-MOMENTUM_SLOT = '/Momentum'   # tf.train.MomentumOptimizer's slot variable name (nets/optimizer_setting.py:29)
 
 
 def export_variables(model: Model, global_step: Optional[int] = None, include_slots: bool = True
@@ -88,11 +91,13 @@ def warm_start_variable_names(model: Model) -> Iterable[str]:
 def import_variables(model: Model, variables: Dict[str, np.ndarray], warm_start: bool = False,
                      global_step: int = 0, strict: bool = True) -> Dict[str, list]:
   """Load a {TF name: array} dictionary.  ``warm_start`` applies the WarmStartHook rule (skip the classifier,
-  only at global_step == 0, trainable variables only).  Returns the lists of loaded / skipped / missing names."""
+  only at global_step == 0, trainable variables only; momentum accumulators untouched).  A full restore also loads the
+  ``<variable>/Momentum`` slots, zeroing those the checkpoint does not hold (``missing_slots``).  Returns the lists of
+  loaded / skipped / missing names."""
   a = model.arena
   if not a.finalized:
     raise RuntimeError('build the model first (variables are created by a shape-only walk)')
-  report = {'loaded': [], 'skipped': [], 'missing': []}
+  report = {'loaded': [], 'skipped': [], 'missing': [], 'missing_slots': []}
   if warm_start and global_step != 0:
     report['skipped'] = list(a.specs)
     return report
@@ -108,9 +113,15 @@ def import_variables(model: Model, variables: Dict[str, np.ndarray], warm_start:
       a.w(name).copy_(_from_tf_layout(name, variables[name], a.w(name)).to(a.w32.device))
       report['loaded'].append(name)
       slot = name + MOMENTUM_SLOT      # optional: inference / warm-start checkpoints carry no optimiser slots
-      if not warm_start and slot in variables:
-        a.m(name).copy_(_from_tf_layout(name, variables[slot], a.m(name)).to(a.w32.device))
-        report['loaded'].append(slot)
+      if not warm_start:
+        if slot in variables:
+          a.m(name).copy_(_from_tf_layout(name, variables[slot], a.m(name)).to(a.w32.device))
+          report['loaded'].append(slot)
+        else:
+          # a full restore of a slot-less checkpoint must not keep whatever accumulator an earlier run left behind:
+          # the slot starts at zero, as MomentumOptimizer creates it, and the report says so
+          a.m(name).zero_()
+          report['missing_slots'].append(slot)
     if not warm_start:   # a tf.train.Saver over trainables does not restore the moving statistics
       for name in a.state_specs:
         if name in variables:
@@ -131,3 +142,26 @@ def save_npz(path: str, model: Model, global_step: Optional[int] = None):
 def load_npz(path: str) -> Dict[str, np.ndarray]:
   with np.load(path) as z:
     return {k.replace('|', '/'): z[k] for k in z.files}
+
+
+# ---- TensorFlow's own checkpoint files (tensor bundle) -----------------------------------------------------------------
+def load_tf_checkpoint(path: str, names=None) -> Dict[str, np.ndarray]:
+  """``path``: a checkpoint prefix (``.../model.ckpt-1234``) or a directory holding a ``checkpoint`` state file
+  (tf.train.latest_checkpoint, utils/hook_utils.py:45-46) -> {TF name: array}, ready for import_variables."""
+  import os
+  from . import tf_bundle
+  if os.path.isdir(path):
+    latest = tf_bundle.latest_checkpoint(path)
+    if latest is None:
+      raise FileNotFoundError('no checkpoint state / index file under %s' % path)
+    path = latest
+  return tf_bundle.read_bundle(path, names)
+
+
+def save_tf_checkpoint(prefix: str, model: Model, global_step: Optional[int] = None, include_slots: bool = True):
+  """Write the model as a TensorFlow checkpoint (``<prefix>.index`` + ``<prefix>.data-00000-of-00001`` + the
+  ``checkpoint`` state file) under the reference's names and layouts -- loadable by the reference's tf.train.Saver."""
+  import os
+  from . import tf_bundle
+  tf_bundle.write_bundle(prefix, export_variables(model, global_step, include_slots))
+  tf_bundle.write_checkpoint_state(os.path.dirname(os.path.abspath(prefix)), os.path.basename(prefix))

@@ -23,7 +23,7 @@ RowTiling make_tiling(int M, int C) {
   t.rpb = 256 / t.vcb;
   // <= 1024 partial rows = <= 1024 blocks = 4 workgroups (16 waves) per CU: with 512 the reducers ran at 4.4 TB/s,
   // with 1024 at 5.7 TB/s (occupancy-bound streaming).  The finalize kernels read 1024 rows without a compaction pass.
-  const int cap = asm_env_int("ASM_BN_ROWS", 1024);
+  const int cap = asm_tune().bn_rows;
   int rows = cdiv(M, cap);
   rows = cdiv(rows, t.rpb) * t.rpb;
   if (rows < t.rpb * 4) rows = t.rpb * 4;
@@ -792,7 +792,7 @@ extern "C" int asm_bn_stats_blocks(int M, int C) {
 extern "C" int asm_bn_stats(const void* x, int M, int C, float* stats_partial, void* stream) {
   ASM_REQUIRE(x && stats_partial && M > 0 && C > 0 && C % 8 == 0, "bn_stats: bad arguments (M=%d C=%d)", M, C);
   RowTiling t = make_tiling(M, C);
-  hipLaunchKernelGGL((rowreduce_kernel<0>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH((rowreduce_kernel<0>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, nullptr, nullptr, 0, M, C, nullptr, nullptr, t, stats_partial);
   ASM_CHECK_LAUNCH("bn_stats");
   return ASM_OK;
@@ -803,7 +803,7 @@ extern "C" int asm_bn_partials_compact(const float* partial, int blocks, int C, 
   ASM_REQUIRE(partial && out && blocks > 0 && C > 0 && groups > 0 && groups <= blocks, "bn_partials_compact: bad arguments");
   const int per_group = cdiv(blocks, groups);
   ASM_REQUIRE(cdiv(blocks, per_group) == groups, "bn_partials_compact: groups=%d does not tile blocks=%d", groups, blocks);
-  hipLaunchKernelGGL(partials_compact_kernel, dim3(cdiv(C, 16), groups), dim3(16 * FL), 0, (hipStream_t)stream, partial,
+  ASM_LAUNCH(partials_compact_kernel, dim3(cdiv(C, 16), groups), dim3(16 * FL), 0, (hipStream_t)stream, partial,
                      blocks, C, out, per_group);
   ASM_CHECK_LAUNCH("bn_partials_compact");
   return ASM_OK;
@@ -816,7 +816,7 @@ extern "C" int asm_bn_finalize(const float* stats_partial, int blocks, int M, in
   ASM_REQUIRE(stats_partial && gamma && beta && mean && invstd && scale && shift && blocks > 0 && M > 0 && C > 0,
               "bn_finalize: bad arguments");
   ASM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must both be given");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(16 * FL), 0, (hipStream_t)stream, stats_partial,
+  ASM_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(16 * FL), 0, (hipStream_t)stream, stats_partial,
                      blocks, M, C, gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift);
   ASM_CHECK_LAUNCH("bn_finalize");
   return ASM_OK;
@@ -825,7 +825,7 @@ extern "C" int asm_bn_finalize(const float* stats_partial, int blocks, int M, in
 extern "C" int asm_bn_infer_coeffs(int C, const float* gamma, const float* beta, const float* moving_mean,
                                    const float* moving_var, float eps, float* scale, float* shift, void* stream) {
   ASM_REQUIRE(C > 0 && gamma && beta && moving_mean && moving_var && scale && shift, "bn_infer_coeffs: bad arguments");
-  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+  ASM_LAUNCH(bn_infer_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
                      moving_mean, moving_var, eps, scale, shift);
   ASM_CHECK_LAUNCH("bn_infer_coeffs");
   return ASM_OK;
@@ -845,7 +845,7 @@ extern "C" int asm_bn_apply(const void* x, void* y, int M, int C, const float* s
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(ew_grid(nvec)), block(256);
 #define LAUNCH_APPLY(RES, RELU)                                                                          \
-  hipLaunchKernelGGL((bn_apply_kernel<RES, RELU>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, nvec, C, fv, \
+  ASM_LAUNCH((bn_apply_kernel<RES, RELU>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, nvec, C, fv, \
                      scale, shift, (const bf16_t*)residual, fw, fh, H, W, relu_mask_out)
   if (res_mode == 0) { if (relu) LAUNCH_APPLY(0, true); else LAUNCH_APPLY(0, false); }
   else if (res_mode == 1) { if (relu) LAUNCH_APPLY(1, true); else LAUNCH_APPLY(1, false); }
@@ -860,7 +860,7 @@ extern "C" int asm_bn_bwd_reduce(const void* dy, const void* x, const void* yout
   ASM_REQUIRE(dy && x && mean && invstd && partial && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
   ASM_REQUIRE(relu >= 0 && relu <= 2 && (!relu || yout), "bn_bwd_reduce: relu mask needs the forward output / bitmask");
   RowTiling t = make_tiling(M, C);
-  hipLaunchKernelGGL((rowreduce_kernel<1>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH((rowreduce_kernel<1>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (const bf16_t*)x, (const bf16_t*)yout, relu, M, C, mean, invstd, t, partial);
   ASM_CHECK_LAUNCH("bn_bwd_reduce");
   return ASM_OK;
@@ -871,7 +871,7 @@ extern "C" int asm_bn_bwd_finalize(const float* partial, int blocks, int M, int 
                                    float* coefA, float* coefB, float* coefC, void* stream) {
   ASM_REQUIRE(partial && gamma && mean && invstd && dgamma && dbeta && coefA && coefB && coefC && blocks > 0,
               "bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(16 * FL), 0, (hipStream_t)stream, partial, blocks,
+  ASM_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(16 * FL), 0, (hipStream_t)stream, partial, blocks,
                      M, C, gamma, mean, invstd, dgamma, dbeta, coefA, coefB, coefC);
   ASM_CHECK_LAUNCH("bn_bwd_finalize");
   return ASM_OK;
@@ -888,7 +888,7 @@ extern "C" int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout,
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(ew_grid(nvec)), block(256);
 #define LAUNCH_BWD(RELU, DZ)                                                                              \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<RELU, DZ>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, \
+  ASM_LAUNCH((bn_bwd_apply_kernel<RELU, DZ>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, \
                      (const bf16_t*)yout, nvec, C, fv, coefA, coefB, coefC, (bf16_t*)dx, (bf16_t*)dz_out)
   if (relu == 1) { if (dz_out) LAUNCH_BWD(1, true); else LAUNCH_BWD(1, false); }
   else if (relu == 2) { if (dz_out) LAUNCH_BWD(2, true); else LAUNCH_BWD(2, false); }
@@ -908,10 +908,10 @@ extern "C" int asm_bn_small_fwd(const void* x, void* y, int M, int C, const floa
   ASM_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_small_fwd: moving stats must both be given");
   const dim3 grid(cdiv(C, 64)), block(256);
   if (relu)
-    hipLaunchKernelGGL(bn_small_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, M, C,
+    ASM_LAUNCH(bn_small_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, M, C,
                        gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, relu_mask_out);
   else
-    hipLaunchKernelGGL(bn_small_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, M, C,
+    ASM_LAUNCH(bn_small_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, M, C,
                        gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, nullptr);
   ASM_CHECK_LAUNCH("bn_small_fwd");
   return ASM_OK;
@@ -924,10 +924,10 @@ extern "C" int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* re
                   C % 8 == 0, "bn_small_bwd: bad arguments (M=%d C=%d)", M, C);
   const dim3 grid(cdiv(C, 64)), block(256);
   if (relu_mask)
-    hipLaunchKernelGGL(bn_small_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+    ASM_LAUNCH(bn_small_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
                        relu_mask, M, C, gamma, mean, invstd, dgamma, dbeta, (bf16_t*)dx);
   else
-    hipLaunchKernelGGL(bn_small_bwd_kernel<0>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+    ASM_LAUNCH(bn_small_bwd_kernel<0>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
                        nullptr, M, C, gamma, mean, invstd, dgamma, dbeta, (bf16_t*)dx);
   ASM_CHECK_LAUNCH("bn_small_bwd");
   return ASM_OK;
@@ -939,7 +939,7 @@ extern "C" int asm_bn_bwd_reduce2(const void* dy, const void* xa, const void* xb
   ASM_REQUIRE(dy && xa && xb && relu_mask && mean_a && invstd_a && mean_b && invstd_b && partial_a && partial_b && M > 0 &&
                   C > 0 && C % 8 == 0, "bn_bwd_reduce2: bad arguments");
   RowTiling t = make_tiling(M, C);
-  hipLaunchKernelGGL(rowreduce2_kernel, dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(rowreduce2_kernel, dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (const bf16_t*)xa, (const bf16_t*)xb, relu_mask, M, C, mean_a, invstd_a, mean_b, invstd_b, t, partial_a,
                      partial_b);
   ASM_CHECK_LAUNCH("bn_bwd_reduce2");
@@ -951,7 +951,7 @@ extern "C" int asm_bn_bwd_apply2(const void* dy, const void* xa, const void* xb,
   ASM_REQUIRE(dy && xa && xb && relu_mask && coef6 && dxa && dxb && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply2: bad arguments");
   ASM_REQUIRE((size_t)M * (C / 8) < 0x7fffffffull, "bn_bwd_apply2: tensor too large");
   const size_t nvec = (size_t)M * (C / 8);
-  hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(bn_bwd_apply2_kernel, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (const bf16_t*)xa, (const bf16_t*)xb, relu_mask, nvec, C, make_fastdiv((unsigned)(C / 8)), coef6,
                      (bf16_t*)dxa, (bf16_t*)dxb);
   ASM_CHECK_LAUNCH("bn_bwd_apply2");
@@ -967,10 +967,10 @@ extern "C" int asm_bn_apply2(const void* xa, const void* xb, void* y, int M, int
   const FastDiv fv = make_fastdiv((unsigned)(C / 8));
   const dim3 grid(ew_grid(nvec)), block(256);
   if (relu)
-    hipLaunchKernelGGL(bn_apply2_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)xa, (const bf16_t*)xb,
+    ASM_LAUNCH(bn_apply2_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)xa, (const bf16_t*)xb,
                        (bf16_t*)y, nvec, C, fv, scale_a, shift_a, scale_b, shift_b, relu_mask_out);
   else
-    hipLaunchKernelGGL(bn_apply2_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)xa, (const bf16_t*)xb,
+    ASM_LAUNCH(bn_apply2_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)xa, (const bf16_t*)xb,
                        (bf16_t*)y, nvec, C, fv, scale_a, shift_a, scale_b, shift_b, nullptr);
   ASM_CHECK_LAUNCH("bn_apply2");
   return ASM_OK;

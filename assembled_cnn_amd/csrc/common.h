@@ -24,17 +24,25 @@ void asm_set_error(const char* fmt, ...);
   } while (0)
 // hipGetLastError() is STICKY per host thread across ALL HIP users of the process: an error some other component left
 // behind (PyTorch probing devices / peers, a collective library, ...) would be reported by ASM_CHECK_LAUNCH as the
-// failure of the next kernel this library launches ("cast: no ROCm-capable device is detected" on a healthy GPU).  Every
-// entry point validates its arguments first, so the argument check is where the stale state is dropped; a launch is always
-// followed directly by ASM_CHECK_LAUNCH, never by another ASM_REQUIRE, so no error of our own can be swallowed here.
-#define ASM_REQUIRE(cond, ...)                  \
-  do {                                          \
-    (void)hipGetLastError();                    \
-    if (!(cond)) ASM_FAIL(ASM_EINVAL, __VA_ARGS__); \
+// failure of the next kernel this library launches ("cast: no ROCm-capable device is detected" on a healthy GPU).  The
+// argument checks at the top of an entry point are where that stale state is dropped -- but ONLY while this thread has no
+// launch of its own waiting for its ASM_CHECK_LAUNCH (asm_unchecked_launches, counted by ASM_LAUNCH): an ASM_REQUIRE that
+// a later edit places after a launch can therefore never swallow that launch's error.
+inline thread_local int asm_unchecked_launches = 0;
+#define ASM_LAUNCH(...)             \
+  do {                              \
+    ++asm_unchecked_launches;       \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+#define ASM_REQUIRE(cond, ...)                               \
+  do {                                                       \
+    if (asm_unchecked_launches == 0) (void)hipGetLastError(); \
+    if (!(cond)) ASM_FAIL(ASM_EINVAL, __VA_ARGS__);          \
   } while (0)
 #define ASM_CHECK_LAUNCH(name)                                                       \
   do {                                                                               \
     hipError_t e__ = hipGetLastError();                                              \
+    asm_unchecked_launches = 0;                                                      \
     if (e__ != hipSuccess) ASM_FAIL(ASM_EHIP, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
@@ -98,12 +106,11 @@ __device__ __forceinline__ unsigned fd_div(unsigned n, const FastDiv& f) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-// Tuning / test knobs are read on EVERY call (never cached in a static): a test process can flip a kernel choice
-// between two launches with setenv.  Cost: one getenv (~100 ns) per knob per launch.
-static inline int asm_env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
+// Tuning / test knobs: an explicit, caller-set struct (asm_tuning, include/asm_hip.h; asm_set_tuning / asm_get_tuning in
+// plan.hip).  The library reads NO environment variable: the host (assembled_cnn_amd/ops.py) maps its ASM_* variables onto
+// the struct, so a C caller sees exactly the heuristics the header documents.  Read on every call (never cached).
+extern "C" const asm_tuning* asm_tuning_current(void);
+static inline const asm_tuning& asm_tune() { return *asm_tuning_current(); }
 // > 64 KiB of dynamic LDS needs an explicit per-function opt-in, and the attribute is per DEVICE: `done` is the
 // caller's static per-device flag table (idempotent; a racing second call just repeats the same setting).
 #define ASM_MAX_DEVICES 16

@@ -970,12 +970,12 @@ int launch_halo(IGemmArgs& a, bool stats, hipStream_t st) {
     auto kern = conv_halo_kernel<KO, CI, WGM, WGN, true>;
     if (hipError_t e = asm_ensure_dyn_lds(kern, H::LDS, attr_done[1]); e != hipSuccess)
       ASM_FAIL(ASM_EHIP, "conv_halo_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), H::LDS, st, a);
+    ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(256), H::LDS, st, a);
   } else {
     auto kern = conv_halo_kernel<KO, CI, WGM, WGN, false>;
     if (hipError_t e = asm_ensure_dyn_lds(kern, H::LDS, attr_done[0]); e != hipSuccess)
       ASM_FAIL(ASM_EHIP, "conv_halo_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), H::LDS, st, a);
+    ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(256), H::LDS, st, a);
   }
   ASM_CHECK_LAUNCH("conv_halo_kernel");
   return ASM_OK;
@@ -1003,7 +1003,7 @@ int launch2_one(const IGemmArgs& a, hipStream_t st) {
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm2_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(NTHR), C::LDS, st, a);
+  ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(NTHR), C::LDS, st, a);
   ASM_CHECK_LAUNCH("igemm2_kernel");
   return ASM_OK;
 }
@@ -1018,7 +1018,7 @@ int launch2_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   if (a.Ci % BK != 0 && a.kchunks != 1) return 1;
   // addend-prefetching epilogue (see igemm_epilogue): where a launch is one round of few workgroups, or one 256-row
   // workgroup per CU anyway; ASM_IGEMM_PFA=0 / 1 forces it off / on (tests, A/B)
-  const int pfa_env = asm_env_int("ASM_IGEMM_PFA", -1);
+  const int pfa_env = asm_tune().igemm_pfa;
   const bool pfa = a.addend != nullptr && !a.y_strided &&
                    (pfa_env >= 0 ? pfa_env != 0 : (BM == 256 || a.n_blocks <= 1024));
   if (a.R == 1 && a.S == 1) {
@@ -1059,7 +1059,7 @@ int launch_one(const IGemmArgs& a, hipStream_t st) {
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(C::NT), C::LDS, st, a);
+  ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(C::NT), C::LDS, st, a);
   ASM_CHECK_LAUNCH("igemm_kernel");
   return ASM_OK;
 }
@@ -1076,7 +1076,6 @@ int launch_mode(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
 
 // staging: 1 = register-staged 2-deep prefetch, 2 = LDS-DMA (see Cfg); 0 = per-layer heuristic.
 // ASM_IGEMM_MODE / ASM_IGEMM_TILE (1 = 128-row tiles, 3 = 256x256) force a choice (tests, tuning).
-int env_int(const char* name) { return asm_env_int(name, 0); }
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool ALLOW_DEEP = true>
 int launch_cfg(IGemmArgs& a, bool out_f32, bool stats, int mode, hipStream_t st) {
@@ -1097,16 +1096,16 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
   // (tools/conv_bench.py, all 1x1 shapes of the network: fprop 2.36 -> 2.31 ms, input gradients 2.11 -> 2.03 ms per step;
   // 0 = off).
   const long long t128_all = (long long)cdiv(a.M, 128) * cdiv(a.Co, 128);
-  const int bk64_tiles = asm_env_int("ASM_IGEMM_BK64_1X1", 4000);
+  const int bk64_tiles = asm_tune().igemm_bk64_1x1;
   const bool bk64 = a.Ci % 64 == 0 && (a.R * a.S > 1 || (bk64_tiles > 0 && a.Ci >= 256 && t128_all <= bk64_tiles));
   const bool heavy = a.Ci % 64 == 0 && (long long)a.R * a.S * a.Ci >= 512;
-  const int fmode = env_int("ASM_IGEMM_MODE"), ftile = env_int("ASM_IGEMM_TILE");
+  const int fmode = asm_tune().igemm_mode, ftile = asm_tune().igemm_tile;
   a.fd_howo = make_fastdiv((unsigned)a.HoWo);
   a.fd_wo = make_fastdiv((unsigned)a.Wo);
-  const int v2 = asm_env_int("ASM_IGEMM_V2", 1);
+  const int v2 = asm_tune().igemm_v2;
   if (a.pool_dy && !(v2 && fmode == 0 && !out_f32 && !stats && a.R == 1 && a.S == 1 && !a.y_strided))
     ASM_FAIL(ASM_ENOTSUP, "conv dgrad_pooled: only the 1x1 stride-1 igemm2 path folds an average-pool backward in");
-  if (v2 && fmode == 0 && ftile == 0 && asm_env_int("ASM_CONV_HALO", 1)) {
+  if (v2 && fmode == 0 && ftile == 0 && asm_tune().conv_halo) {
     const int rc = try_halo(a, out_f32, stats, st);
     if (rc != 1) return rc;
   }
@@ -1119,7 +1118,7 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
     // Small-M, deep-K layers (7x7 maps at batch 256: 98 row tiles): with 128 x 128 tiles a 256-channel output makes only
     // 196 workgroups for the 512 resident slots; 128 x 64 tiles double the workgroup count (ASM_IGEMM_SMALLM=1, A/B knob).
     const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Co, 128);
-    const bool narrow = asm_env_int("ASM_IGEMM_SMALLM", 0) && !bigv && ftile == 0 && a.Co > 64 && a.Co % 64 == 0 &&
+    const bool narrow = asm_tune().igemm_smallm && !bigv && ftile == 0 && a.Co > 64 && a.Co % 64 == 0 &&
                         t128 < 320 && (long long)a.R * a.S * a.Ci >= 1024;
     if (a.Co <= 32) rc = bk64 ? launch2_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, st) : launch2_cfg<128, 32, 32, 4, 1>(a, out_f32, stats, st);
     else if (a.Co <= 64 || narrow) rc = bk64 ? launch2_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, st);
@@ -1280,9 +1279,9 @@ static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, co
   //   dx(2hh+ph, 2ww+pw) = sum_{i,j} dy(hh + dh0 - i, ww + dw0 - j) . w(r0 + 2i, s0 + 2j),
   //   r0 = (ph + pad) & 1, dh0 = (ph + pad - r0) / 2   (same for columns)
   // written through the strided-output epilogue: 9/4 instead of 9 tap passes.
-  const int split_ok = asm_env_int("ASM_DGRAD_PARITY", 1);
+  const int split_ok = asm_tune().dgrad_parity;
   const bool k3 = d->R == 3 && d->S == 3, k1 = d->R == 1 && d->S == 1 && d->pad == 0;
-  if (split_ok && d->stride == 2 && (k3 || k1) && env_int("ASM_IGEMM_MODE") == 0) {
+  if (split_ok && d->stride == 2 && (k3 || k1) && asm_tune().igemm_mode == 0) {
     // a 1x1 / 2 projection touches only the (even, even) class: the other three are zero (or just the addend)
     bool launched = false;
     for (int cls = 0; cls < 4; ++cls) {

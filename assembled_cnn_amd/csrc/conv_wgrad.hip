@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
 
 // workgroups of the persistent halo form for this layer, or 0 if it does not apply
 int wgrad_halo_blocks(const asm_conv_desc* d) {
-  const int mode = asm_env_int("ASM_WGRAD_HALO", 1);     // 0 off, 1 on for the large maps, 2 whenever the shape allows (tests)
+  const int mode = asm_tune().wgrad_halo;     // 0 off, 1 on for the large maps, 2 whenever the shape allows (tests)
   if (!mode) return 0;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
   if (d->H % 8 || d->W % 16 || d->x_img_pitch || d->x_row_pitch || d->x_pix_pitch) return 0;
@@ -471,7 +471,7 @@ Plan make_plan(const asm_conv_desc* d) {
   pl.bnw = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);
   pl.bcw = 128;
   // 256 x 256 / 8 waves when dW tiles exactly (no padded MFMAs) and there is enough of it; ASM_WGRAD_BIG=0/1 forces
-  const int big_env = asm_env_int("ASM_WGRAD_BIG", -1);
+  const int big_env = asm_tune().wgrad_big;
   // measured: -13..-20 % on the layers with >= 40 GFLOP, +5..+20 % on the small 7x7 / narrow ones; column padding
   // of up to 1/8 (3x3 with 128 input channels: 1152 -> 1280 columns) still nets -14 %
   const int cpad = cdiv(cols, 256) * 256;
@@ -508,7 +508,7 @@ Plan make_plan(const asm_conv_desc* d) {
     }
   }
   // ASM_WGRAD_SPLITS=n forces the pixel split (tests: slab path on small shapes; tuning)
-  const int forced = asm_env_int("ASM_WGRAD_SPLITS", 0);
+  const int forced = asm_tune().wgrad_splits;
   if (forced > 0) splits = forced < msteps ? forced : msteps;
   int steps_per = cdiv(msteps, splits);
   pl.m_per_split = steps_per * WPX;
@@ -566,7 +566,7 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
     h.fd_howo = make_fastdiv((unsigned)h.HoWo); h.fd_wo = make_fastdiv((unsigned)h.Wo);
     hipStream_t hs = (hipStream_t)stream;
 #define LAUNCH_WH(KF, CI)                                                                                        \
-    hipLaunchKernelGGL((wgrad_halo_kernel<KF, CI>), dim3(hb), dim3(256), (WHalo<KF, CI>::LDS), hs, h)
+    ASM_LAUNCH((wgrad_halo_kernel<KF, CI>), dim3(hb), dim3(256), (WHalo<KF, CI>::LDS), hs, h)
     if (d->K == 32 && d->C == 64) LAUNCH_WH(32, 64);
     else if (d->K == 64 && d->C == 32) LAUNCH_WH(64, 32);
     else if (d->K == 32 && d->C == 32) LAUNCH_WH(32, 32);
@@ -574,7 +574,7 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
 #undef LAUNCH_WH
     ASM_CHECK_LAUNCH("wgrad_halo_kernel");
     const size_t n = (size_t)d->K * 9 * d->C;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 128)), dim3(256), 0, hs,
+    ASM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 128)), dim3(256), 0, hs,
                        reinterpret_cast<const float*>(workspace), dw, n, hb);
     ASM_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ASM_OK;
@@ -600,11 +600,11 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   const dim3 grid(pl.tiles_n * pl.tiles_c * pl.splits);
   const bool lin = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->Ho == d->H && d->Wo == d->W &&
                    a.x_pix_pitch == d->C && a.x_row_pitch == d->W * d->C && a.x_img_pitch == d->H * d->W * d->C &&
-                   asm_env_int("ASM_WGRAD_LINEAR", 1) != 0;
+                   asm_tune().wgrad_linear != 0;
   if (lin && pl.bcw != 256) {
-    if (pl.bnw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128, true>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);
-    else if (pl.bnw == 64) hipLaunchKernelGGL((wgrad_kernel<64, 128, true>), grid, dim3(256), 2 * (WPX * 128 + WPX * 256), st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<32, 128, true>), grid, dim3(256), 2 * (WPX * 64 + WPX * 256), st, a);
+    if (pl.bnw == 128) ASM_LAUNCH((wgrad_kernel<128, 128, true>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);
+    else if (pl.bnw == 64) ASM_LAUNCH((wgrad_kernel<64, 128, true>), grid, dim3(256), 2 * (WPX * 128 + WPX * 256), st, a);
+    else ASM_LAUNCH((wgrad_kernel<32, 128, true>), grid, dim3(256), 2 * (WPX * 64 + WPX * 256), st, a);
   } else if (pl.bcw == 256) {
     constexpr int LDS = 2 * (WPX * 512 + WPX * 512);   // 128 KiB
     static bool attr_done[ASM_MAX_DEVICES] = {};
@@ -614,21 +614,21 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
       static bool attr_done_l[ASM_MAX_DEVICES] = {};
       if (hipError_t e = asm_ensure_dyn_lds(wgrad_kernel<256, 256, true>, LDS, attr_done_l); e != hipSuccess)
         ASM_FAIL(ASM_EHIP, "wgrad_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-      hipLaunchKernelGGL((wgrad_kernel<256, 256, true>), grid, dim3(512), LDS, st, a);
+      ASM_LAUNCH((wgrad_kernel<256, 256, true>), grid, dim3(512), LDS, st, a);
     } else {
-      hipLaunchKernelGGL((wgrad_kernel<256, 256>), grid, dim3(512), LDS, st, a);
+      ASM_LAUNCH((wgrad_kernel<256, 256>), grid, dim3(512), LDS, st, a);
     }
   } else if (pl.bnw == 128) {
-    hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);
+    ASM_LAUNCH((wgrad_kernel<128, 128>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);
   } else if (pl.bnw == 64) {
-    hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 2 * (WPX * 128 + WPX * 256), st, a);
+    ASM_LAUNCH((wgrad_kernel<64, 128>), grid, dim3(256), 2 * (WPX * 128 + WPX * 256), st, a);
   } else {
-    hipLaunchKernelGGL((wgrad_kernel<32, 128>), grid, dim3(256), 2 * (WPX * 64 + WPX * 256), st, a);
+    ASM_LAUNCH((wgrad_kernel<32, 128>), grid, dim3(256), 2 * (WPX * 64 + WPX * 256), st, a);
   }
   ASM_CHECK_LAUNCH("wgrad_kernel");
   if (pl.splits > 1) {
     const size_t n = (size_t)d->K * a.cols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 128)), dim3(256), 0, st,
+    ASM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 128)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(workspace), dw, n, pl.splits);
     ASM_CHECK_LAUNCH("wgrad_reduce_kernel");
   }

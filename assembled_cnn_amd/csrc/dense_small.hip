@@ -93,10 +93,11 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseArgs a) {
   __syncthreads();
   const int m = tid >> 3, nq = (tid & 7) * 4;
   const int gm = m0 + m, gn = n0 + nq;
-  if (gm >= a.M || gn >= a.N) return;
+  if (gm >= a.M || gn >= a.ldo) return;     // pad columns N .. ldo-1 of a padded output row are written as zeros
   float v[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = (red[0][m][nq + j] + red[1][m][nq + j]) + (red[2][m][nq + j] + red[3][m][nq + j]);
+  for (int j = 0; j < 4; ++j)
+    v[j] = gn + j < a.N ? (red[0][m][nq + j] + red[1][m][nq + j]) + (red[2][m][nq + j] + red[3][m][nq + j]) : 0.f;
   const size_t o = (size_t)gm * a.ldo + gn;
   const bool full = gn + 3 < a.N;
   if (a.addend) {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseArgs a) {
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (gn + j < a.N) out[o + j] = v[j];
+        if (gn + j < a.ldo) out[o + j] = v[j];
     }
   } else {
     bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseArgs a) {
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (gn + j < a.N) out[o + j] = f2bf(v[j]);
+        if (gn + j < a.ldo) out[o + j] = f2bf(v[j]);
     }
   }
 }
@@ -429,7 +430,7 @@ extern "C" int asm_dense_small(const void* p, int ldp, const void* q, int ldq, i
   DenseArgs a;
   a.p = (const bf16_t*)p; a.q = (const bf16_t*)q; a.out = out; a.addend = (const bf16_t*)addend;
   a.ldp = ldp; a.ldq = ldq; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32 ? 1 : 0;
-  hipLaunchKernelGGL(dense_small_kernel, dim3(cdiv(N, 32), cdiv(M, 32)), dim3(256), 0, (hipStream_t)stream, a);
+  ASM_LAUNCH(dense_small_kernel, dim3(cdiv(N, 32), cdiv(M, 32)), dim3(256), 0, (hipStream_t)stream, a);
   ASM_CHECK_LAUNCH("dense_small");
   return ASM_OK;
 }
@@ -449,8 +450,8 @@ extern "C" int asm_dense_bn_fwd(const void* x, int ldx, const void* w, int ldw, 
   a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.moving_mean = moving_mean; a.moving_var = moving_var;
   a.ypre = (bf16_t*)ypre; a.z = (bf16_t*)z; a.mean = mean; a.invstd = invstd; a.mask = relu_mask_out;
   const dim3 grid(cdiv(N, 32)), block(512);
-  if (relu) hipLaunchKernelGGL(dense_bn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(dense_bn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+  if (relu) ASM_LAUNCH(dense_bn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+  else ASM_LAUNCH(dense_bn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
   ASM_CHECK_LAUNCH("dense_bn_fwd");
   return ASM_OK;
 }
@@ -468,8 +469,8 @@ extern "C" int asm_dense_dgrad_bn_bwd(const void* dy, int lddy, const void* wt, 
   a.ypre = (const bf16_t*)ypre; a.mask = relu_mask; a.gamma = gamma; a.mean = mean; a.invstd = invstd;
   a.dgamma = dgamma; a.dbeta = dbeta; a.dx = (bf16_t*)dx;
   const dim3 grid(cdiv(N, 32)), block(512);
-  if (relu_mask) hipLaunchKernelGGL(dense_dgrad_bn_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(dense_dgrad_bn_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+  if (relu_mask) ASM_LAUNCH(dense_dgrad_bn_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+  else ASM_LAUNCH(dense_dgrad_bn_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
   ASM_CHECK_LAUNCH("dense_dgrad_bn_bwd");
   return ASM_OK;
 }
@@ -482,7 +483,7 @@ extern "C" int asm_dense_small_wgrad(const void* x, int ldx, const void* dy, int
   DenseWgradArgs a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw; a.ldx = ldx; a.ldy = ldy; a.ldw = ldw;
   a.M = M; a.Cin = Cin; a.Cout = Cout;
-  hipLaunchKernelGGL(dense_small_wgrad_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32)), dim3(256), 0, (hipStream_t)stream, a);
+  ASM_LAUNCH(dense_small_wgrad_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32)), dim3(256), 0, (hipStream_t)stream, a);
   ASM_CHECK_LAUNCH("dense_small_wgrad");
   return ASM_OK;
 }

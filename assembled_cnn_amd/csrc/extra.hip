@@ -262,10 +262,10 @@ extern "C" int asm_sigmoid_ce(const float* logits, int ld, const float* targets,
   ASM_REQUIRE(logits && targets && rows_ws && loss_out && B > 0 && C > 0 && ld >= C, "sigmoid_ce: bad arguments");
   ASM_REQUIRE(!dlogits || ld_out >= C, "sigmoid_ce: bad ld_out");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sigmoid_ce_rows_kernel, dim3(B), dim3(256), 0, st, logits, ld, targets, C, rows_ws);
-  hipLaunchKernelGGL(sigmoid_ce_total_kernel, dim3(1), dim3(256), 0, st, rows_ws, B, loss_out);
+  ASM_LAUNCH(sigmoid_ce_rows_kernel, dim3(B), dim3(256), 0, st, logits, ld, targets, C, rows_ws);
+  ASM_LAUNCH(sigmoid_ce_total_kernel, dim3(1), dim3(256), 0, st, rows_ws, B, loss_out);
   if (dlogits)
-    hipLaunchKernelGGL(sigmoid_ce_grad_kernel, dim3((unsigned)cdivz((size_t)B * ld_out, 256)), dim3(256), 0, st, logits,
+    ASM_LAUNCH(sigmoid_ce_grad_kernel, dim3((unsigned)cdivz((size_t)B * ld_out, 256)), dim3(256), 0, st, logits,
                        ld, targets, B, C, loss_out, loss_scale, (bf16_t*)dlogits, ld_out);
   ASM_CHECK_LAUNCH("sigmoid_ce");
   return ASM_OK;
@@ -273,7 +273,7 @@ extern "C" int asm_sigmoid_ce(const float* logits, int ld, const float* targets,
 
 extern "C" int asm_gem_fwd(const void* x, void* y, float* ssum, int N, int HW, int C, float p, void* stream) {
   ASM_REQUIRE(x && y && ssum && N > 0 && HW > 0 && C > 0 && p > 0.f, "gem_fwd: bad arguments");
-  hipLaunchKernelGGL(gem_fwd_kernel, dim3(cdiv(C, 256), N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  ASM_LAUNCH(gem_fwd_kernel, dim3(cdiv(C, 256), N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)y, ssum, HW, C, p);
   ASM_CHECK_LAUNCH("gem_fwd");
   return ASM_OK;
@@ -281,7 +281,7 @@ extern "C" int asm_gem_fwd(const void* x, void* y, float* ssum, int N, int HW, i
 extern "C" int asm_gem_bwd(const void* x, const void* dy, const float* ssum, void* dx, int N, int HW, int C, float p,
                            void* stream) {
   ASM_REQUIRE(x && dy && ssum && dx && N > 0 && HW > 0 && C > 0 && p > 0.f, "gem_bwd: bad arguments");
-  hipLaunchKernelGGL(gem_bwd_kernel, dim3((unsigned)cdivz((size_t)N * HW * C, 256)), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(gem_bwd_kernel, dim3((unsigned)cdivz((size_t)N * HW * C, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)dy, ssum, (bf16_t*)dx, N, HW, C, p);
   ASM_CHECK_LAUNCH("gem_bwd");
   return ASM_OK;
@@ -292,9 +292,9 @@ extern "C" int asm_dropblock_mask(const float* uniform, float gamma, int H, int 
   ASM_REQUIRE(uniform && keep && scale && H >= block_size && W >= block_size && C > 0 && block_size >= 1,
               "dropblock_mask: bad arguments (H=%d W=%d block=%d)", H, W, block_size);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(dropblock_mask_kernel, dim3(cdiv(H * W * C, 256)), dim3(256), 0, st, uniform, gamma, H, W, C,
+  ASM_LAUNCH(dropblock_mask_kernel, dim3(cdiv(H * W * C, 256)), dim3(256), 0, st, uniform, gamma, H, W, C,
                      block_size, keep);
-  hipLaunchKernelGGL(dropblock_norm_kernel, dim3(1), dim3(256), 0, st, keep, H * W * C, scale);
+  ASM_LAUNCH(dropblock_norm_kernel, dim3(1), dim3(256), 0, st, keep, H * W * C, scale);
   ASM_CHECK_LAUNCH("dropblock_mask");
   return ASM_OK;
 }
@@ -302,7 +302,7 @@ extern "C" int asm_dropblock_apply(const void* x, const float* keep, const float
                                    int relu, void* y, int N, int HWC, void* stream) {
   ASM_REQUIRE(x && keep && scale && y && N > 0 && HWC > 0 && HWC % 8 == 0, "dropblock_apply: bad arguments");
   const size_t nvec = (size_t)N * (HWC / 8);
-  hipLaunchKernelGGL(dropblock_apply_kernel, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  ASM_LAUNCH(dropblock_apply_kernel, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      keep, scale, (const bf16_t*)relu_mask_from, relu, (bf16_t*)y, nvec, (unsigned)(HWC / 8));
   ASM_CHECK_LAUNCH("dropblock_apply");
   return ASM_OK;
@@ -311,7 +311,7 @@ extern "C" int asm_dropblock_apply(const void* x, const float* keep, const float
 extern "C" int asm_eval_rows(const float* logits, int ld, const int32_t* labels, int B, int C, int32_t* pred,
                              float* conf, float* top1, float* top5, void* stream) {
   ASM_REQUIRE(logits && labels && pred && conf && top1 && top5 && B > 0 && C > 0 && ld >= C, "eval_rows: bad arguments");
-  hipLaunchKernelGGL(eval_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, C, pred, conf,
+  ASM_LAUNCH(eval_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, C, pred, conf,
                      top1, top5);
   ASM_CHECK_LAUNCH("eval_rows");
   return ASM_OK;
@@ -319,7 +319,7 @@ extern "C" int asm_eval_rows(const float* logits, int ld, const int32_t* labels,
 extern "C" int asm_eval_accumulate(const float* conf, const float* top1, const float* top5, int B, float* state33,
                                    void* stream) {
   ASM_REQUIRE(conf && top1 && top5 && state33 && B > 0, "eval_accumulate: bad arguments");
-  hipLaunchKernelGGL(eval_accumulate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, conf, top1, top5, B, state33);
+  ASM_LAUNCH(eval_accumulate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, conf, top1, top5, B, state33);
   ASM_CHECK_LAUNCH("eval_accumulate");
   return ASM_OK;
 }

@@ -527,7 +527,7 @@ NaiveArgs naive_args(const asm_conv_desc* d) {
 extern "C" int asm_relu_fwd(const void* x, void* y, size_t n, void* stream) {
   ASM_REQUIRE(x && y, "relu_fwd: null pointer");
   VEC8_OK("relu_fwd");
-  hipLaunchKernelGGL(relu_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  ASM_LAUNCH(relu_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)y, n / 8);
   ASM_CHECK_LAUNCH("relu_fwd");
   return ASM_OK;
@@ -535,7 +535,7 @@ extern "C" int asm_relu_fwd(const void* x, void* y, size_t n, void* stream) {
 extern "C" int asm_relu_bwd(const void* dy, const void* y, void* dx, size_t n, void* stream) {
   ASM_REQUIRE(dy && y && dx, "relu_bwd: null pointer");
   VEC8_OK("relu_bwd");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(relu_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (const bf16_t*)y, (bf16_t*)dx, n / 8);
   ASM_CHECK_LAUNCH("relu_bwd");
   return ASM_OK;
@@ -543,7 +543,7 @@ extern "C" int asm_relu_bwd(const void* dy, const void* y, void* dx, size_t n, v
 extern "C" int asm_mask_apply(const void* dy, const uint8_t* mask, void* dx, size_t n, void* stream) {
   ASM_REQUIRE(dy && mask && dx, "mask_apply: null pointer");
   VEC8_OK("mask_apply");
-  hipLaunchKernelGGL(mask_apply_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, mask,
+  ASM_LAUNCH(mask_apply_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, mask,
                      (bf16_t*)dx, n / 8);
   ASM_CHECK_LAUNCH("mask_apply");
   return ASM_OK;
@@ -551,21 +551,21 @@ extern "C" int asm_mask_apply(const void* dy, const uint8_t* mask, void* dx, siz
 extern "C" int asm_add_bf16(const void* a, const void* b, void* out, size_t n, void* stream) {
   ASM_REQUIRE(a && b && out, "add_bf16: null pointer");
   VEC8_OK("add_bf16");
-  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+  ASM_LAUNCH(add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
                      (const bf16_t*)b, (bf16_t*)out, n / 8);
   ASM_CHECK_LAUNCH("add_bf16");
   return ASM_OK;
 }
 extern "C" int asm_bias_add_f32(float* y, const float* bias, int M, int C, int ldy, void* stream) {
   ASM_REQUIRE(y && bias && M > 0 && C > 0 && ldy >= C, "bias_add: bad arguments");
-  hipLaunchKernelGGL(bias_add_kernel, dim3((unsigned)cdivz((size_t)M * C, 256)), dim3(256), 0, (hipStream_t)stream, y,
+  ASM_LAUNCH(bias_add_kernel, dim3((unsigned)cdivz((size_t)M * C, 256)), dim3(256), 0, (hipStream_t)stream, y,
                      bias, M, C, ldy);
   ASM_CHECK_LAUNCH("bias_add");
   return ASM_OK;
 }
 extern "C" int asm_bias_grad_bf16(const void* dz, int M, int C, int ld, float* dbias, void* stream) {
   ASM_REQUIRE(dz && dbias && M > 0 && C > 0 && ld >= C, "bias_grad: bad arguments");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, M, C,
+  ASM_LAUNCH(bias_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, M, C,
                      ld, dbias);
   ASM_CHECK_LAUNCH("bias_grad");
   return ASM_OK;
@@ -573,7 +573,7 @@ extern "C" int asm_bias_grad_bf16(const void* dz, int M, int C, int ld, float* d
 extern "C" int asm_cast_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {
   ASM_REQUIRE(x && y, "cast: null pointer");
   if (n == 0) return ASM_OK;
-  hipLaunchKernelGGL(cast_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+  ASM_LAUNCH(cast_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
   ASM_CHECK_LAUNCH("cast");
   return ASM_OK;
 }
@@ -581,7 +581,7 @@ extern "C" int asm_cast_f32_to_bf16(const float* x, void* y, size_t n, void* str
 extern "C" int asm_cast_bf16_to_f32(const void* x, float* y, size_t n, void* stream) {
   ASM_REQUIRE(x && y, "cast: null pointer");
   if (n == 0) return ASM_OK;
-  hipLaunchKernelGGL(widen_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
+  ASM_LAUNCH(widen_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
   ASM_CHECK_LAUNCH("cast_bf16_to_f32");
   return ASM_OK;
 }
@@ -592,27 +592,27 @@ extern "C" int asm_softmax_ce(const float* logits, int ld, const float* targets,
   ASM_REQUIRE(logits && targets && loss_rows && B > 0 && C > 0 && ld >= C, "softmax_ce: bad arguments");
   ASM_REQUIRE(!teacher || kd_temp > 0.f, "softmax_ce: teacher given but kd_temp <= 0");
   ASM_REQUIRE(!dlogits || ld_out >= C, "softmax_ce: bad ld_out");
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, teacher, B, C,
+  ASM_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, teacher, B, C,
                      label_smoothing, kd_temp, loss_scale, loss_rows, (bf16_t*)dlogits, ld_out);
   ASM_CHECK_LAUNCH("softmax_ce");
   return ASM_OK;
 }
 extern "C" int asm_onehot(const int32_t* labels, float* out, int B, int C, void* stream) {
   ASM_REQUIRE(labels && out && B > 0 && C > 0, "onehot: bad arguments");
-  hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)cdivz((size_t)B * C, 256)), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(onehot_kernel, dim3((unsigned)cdivz((size_t)B * C, 256)), dim3(256), 0, (hipStream_t)stream,
                      labels, out, B, C);
   ASM_CHECK_LAUNCH("onehot");
   return ASM_OK;
 }
 extern "C" int asm_softmax_rows(const float* x, float* y, int B, int C, float inv_temp, void* stream) {
   ASM_REQUIRE(x && y && B > 0 && C > 0, "softmax_rows: bad arguments");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, B, C, inv_temp);
+  ASM_LAUNCH(softmax_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, B, C, inv_temp);
   ASM_CHECK_LAUNCH("softmax_rows");
   return ASM_OK;
 }
 extern "C" int asm_mean_f32(const float* x, int n, float* out, void* stream) {
   ASM_REQUIRE(x && out && n > 0, "mean: bad arguments");
-  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  ASM_LAUNCH(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
   ASM_CHECK_LAUNCH("mean");
   return ASM_OK;
 }
@@ -625,7 +625,7 @@ extern "C" int asm_mixup_meansub(const void* images, int is_u8, int Bin, int H, 
   ASM_REQUIRE(mixup_type != 2 || lam2, "mixup_meansub: mixup_type 2 needs lam2");
   const int Bout = mixup_type == 1 ? Bin / 2 : Bin;
   const size_t total = (size_t)Bout * (H + 6) * (W + 6);
-  hipLaunchKernelGGL(mixup_meansub_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream, images,
+  ASM_LAUNCH(mixup_meansub_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream, images,
                      is_u8, Bin, Bout, H, W, mixup_type, lam1, lam2, (bf16_t*)out);
   ASM_CHECK_LAUNCH("mixup_meansub");
   return ASM_OK;
@@ -633,7 +633,7 @@ extern "C" int asm_mixup_meansub(const void* images, int is_u8, int Bin, int H, 
 extern "C" int asm_stem_pad_input(const void* x, int x_is_f32, void* xp, int N, int H, int W, void* stream) {
   ASM_REQUIRE(x && xp && N > 0 && H > 0 && W > 0, "stem_pad_input: bad arguments");
   const size_t total = (size_t)N * (H + 6) * (W + 6);
-  hipLaunchKernelGGL(stem_pad_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32,
+  ASM_LAUNCH(stem_pad_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32,
                      (bf16_t*)xp, N, H, W);
   ASM_CHECK_LAUNCH("stem_pad_input");
   return ASM_OK;
@@ -645,7 +645,7 @@ extern "C" int asm_mixup_labels(const float* y, int Bin, int C, int mixup_type, 
   ASM_REQUIRE(mixup_type == 0 || (lam1 && Bin % 2 == 0), "mixup_labels: mixup needs lam1 and an even batch");
   ASM_REQUIRE(mixup_type != 2 || lam2, "mixup_labels: mixup_type 2 needs lam2");
   const int Bout = mixup_type == 1 ? Bin / 2 : Bin;
-  hipLaunchKernelGGL(mixup_labels_kernel, dim3((unsigned)cdivz((size_t)Bout * C, 256)), dim3(256), 0,
+  ASM_LAUNCH(mixup_labels_kernel, dim3((unsigned)cdivz((size_t)Bout * C, 256)), dim3(256), 0,
                      (hipStream_t)stream, y, Bin, Bout, C, mixup_type, lam1, lam2, out);
   ASM_CHECK_LAUNCH("mixup_labels");
   return ASM_OK;
@@ -655,7 +655,7 @@ extern "C" int asm_sgd_momentum(float* w, float* accum, const float* grad, void*
                                 float momentum, float weight_decay, float grad_scale, void* stream) {
   ASM_REQUIRE(w && accum && grad, "sgd_momentum: null pointer");
   if (n == 0) return ASM_OK;
-  hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(cdivz(n, 4))), dim3(256), 0, (hipStream_t)stream, w, accum, grad,
+  ASM_LAUNCH(sgd_kernel, dim3(ew_grid(cdivz(n, 4))), dim3(256), 0, (hipStream_t)stream, w, accum, grad,
                      (bf16_t*)w_bf16, n, lr, momentum, weight_decay, grad_scale);
   ASM_CHECK_LAUNCH("sgd_momentum");
   return ASM_OK;
@@ -667,7 +667,7 @@ extern "C" int asm_filter_transpose(const void* w_krsc, void* w_crsk, int K, int
               "filter_transpose: bad arguments");
   if (ldk == 0) ldk = K;
   const size_t n = (size_t)K * R * S * C;
-  hipLaunchKernelGGL(filter_transpose_kernel, dim3((unsigned)cdivz(n, 256)), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(filter_transpose_kernel, dim3((unsigned)cdivz(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)w_krsc, (bf16_t*)w_crsk, K, R * S, C, ldk);
   ASM_CHECK_LAUNCH("filter_transpose");
   return ASM_OK;
@@ -675,7 +675,7 @@ extern "C" int asm_filter_transpose(const void* w_krsc, void* w_crsk, int K, int
 extern "C" int asm_stem_pack_filter(const float* w_krsc3, void* w_packed, int K, int ksize, void* stream) {
   ASM_REQUIRE(w_krsc3 && w_packed && K > 0 && (ksize == 3 || ksize == 7), "stem_pack_filter: bad arguments");
   const int L = (4 * ksize + 7) & ~7;
-  hipLaunchKernelGGL(stem_pack_kernel, dim3(cdiv(K * ksize * L, 256)), dim3(256), 0, (hipStream_t)stream, w_krsc3,
+  ASM_LAUNCH(stem_pack_kernel, dim3(cdiv(K * ksize * L, 256)), dim3(256), 0, (hipStream_t)stream, w_krsc3,
                      (bf16_t*)w_packed, K, ksize, L);
   ASM_CHECK_LAUNCH("stem_pack_filter");
   return ASM_OK;
@@ -683,7 +683,7 @@ extern "C" int asm_stem_pack_filter(const float* w_krsc3, void* w_packed, int K,
 extern "C" int asm_stem_unpack_grad(const float* dw_packed, float* dw_krsc3, int K, int ksize, void* stream) {
   ASM_REQUIRE(dw_packed && dw_krsc3 && K > 0 && (ksize == 3 || ksize == 7), "stem_unpack_grad: bad arguments");
   const int L = (4 * ksize + 7) & ~7;
-  hipLaunchKernelGGL(stem_unpack_kernel, dim3(cdiv(K * ksize * ksize * 3, 256)), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(stem_unpack_kernel, dim3(cdiv(K * ksize * ksize * 3, 256)), dim3(256), 0, (hipStream_t)stream,
                      dw_packed, dw_krsc3, K, ksize, L);
   ASM_CHECK_LAUNCH("stem_unpack_grad");
   return ASM_OK;
@@ -693,7 +693,7 @@ extern "C" int asm_conv2d_fprop_naive(const asm_conv_desc* d, const void* x, con
   ASM_REQUIRE(d && x && w && y, "fprop_naive: null pointer");
   NaiveArgs a = naive_args(d);
   const size_t total = (size_t)a.N * a.Ho * a.Wo * a.K;
-  hipLaunchKernelGGL(naive_fprop_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(naive_fprop_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)w, y, a);
   ASM_CHECK_LAUNCH("fprop_naive");
   return ASM_OK;
@@ -703,7 +703,7 @@ extern "C" int asm_conv2d_dgrad_naive(const asm_conv_desc* d, const void* dy, co
   ASM_REQUIRE(d && dy && w_krsc && dx, "dgrad_naive: null pointer");
   NaiveArgs a = naive_args(d);
   const size_t total = (size_t)a.N * a.H * a.W * a.C;
-  hipLaunchKernelGGL(naive_dgrad_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(naive_dgrad_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, (const bf16_t*)w_krsc, (bf16_t*)dx, a);
   ASM_CHECK_LAUNCH("dgrad_naive");
   return ASM_OK;
@@ -712,7 +712,7 @@ extern "C" int asm_conv2d_wgrad_naive(const asm_conv_desc* d, const void* x, con
   ASM_REQUIRE(d && x && dy && dw, "wgrad_naive: null pointer");
   NaiveArgs a = naive_args(d);
   const size_t total = (size_t)a.K * a.R * a.S * a.C;
-  hipLaunchKernelGGL(naive_wgrad_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(naive_wgrad_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)dy, dw, a);
   ASM_CHECK_LAUNCH("wgrad_naive");
   return ASM_OK;
@@ -720,7 +720,7 @@ extern "C" int asm_conv2d_wgrad_naive(const asm_conv_desc* d, const void* x, con
 
 extern "C" int asm_debug_tr_probe(void* out256_i16, void* stream) {
   ASM_REQUIRE(out256_i16, "tr_probe: null pointer");
-  hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (short*)out256_i16);
+  ASM_LAUNCH(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (short*)out256_i16);
   ASM_CHECK_LAUNCH("tr_probe");
   return ASM_OK;
 }
@@ -728,7 +728,7 @@ extern "C" int asm_debug_tr_probe(void* out256_i16, void* stream) {
 extern "C" int asm_filter_transpose_tiled(const void* w_arena, void* wt_arena, const int32_t* table, int nlayers,
                                           int total_tiles, void* stream) {
   ASM_REQUIRE(w_arena && wt_arena && table && nlayers > 0 && total_tiles > 0, "filter_transpose_tiled: bad arguments");
-  hipLaunchKernelGGL(filter_transpose_tiled_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(filter_transpose_tiled_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)w_arena, (bf16_t*)wt_arena, (const int*)table, nlayers);
   ASM_CHECK_LAUNCH("filter_transpose_tiled");
   return ASM_OK;
@@ -737,7 +737,7 @@ extern "C" int asm_filter_transpose_tiled(const void* w_arena, void* wt_arena, c
 extern "C" int asm_filter_transpose_batched(const void* w_arena, void* wt_arena, const int32_t* table, int nlayers,
                                             long long total_elems, void* stream) {
   ASM_REQUIRE(w_arena && wt_arena && table && nlayers > 0 && total_elems > 0, "filter_transpose_batched: bad arguments");
-  hipLaunchKernelGGL(filter_transpose_batched_kernel, dim3((unsigned)cdivz((size_t)total_elems, 256)), dim3(256), 0,
+  ASM_LAUNCH(filter_transpose_batched_kernel, dim3((unsigned)cdivz((size_t)total_elems, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)w_arena, (bf16_t*)wt_arena, (const int*)table, nlayers,
                      total_elems);
   ASM_CHECK_LAUNCH("filter_transpose_batched");

@@ -428,7 +428,7 @@ extern "C" int asm_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int
   same_pad(W, 3, 2, &Wo, &pw);
   const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  ASM_LAUNCH(maxpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)y, argmax, N, H, W, C, Ho, Wo, ph, pw);
   ASM_CHECK_LAUNCH("maxpool_fwd");
   return ASM_OK;
@@ -443,7 +443,7 @@ extern "C" int asm_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void*
   same_pad(W, 3, 2, &Wo, &pw);
   const size_t nvec = (size_t)N * H * W * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(maxpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      argmax, (bf16_t*)dx, N, H, W, C, Ho, Wo, ph, pw);
   ASM_CHECK_LAUNCH("maxpool_bwd");
   return ASM_OK;
@@ -455,7 +455,7 @@ extern "C" int asm_avgpool_fwd(const void* x, void* y, int N, int H, int W, int 
   ASM_REQUIRE(x && y && k >= 1 && k <= 7 && stride >= 1 && pad >= 0 && Ho > 0 && Wo > 0, "avgpool_fwd: bad arguments");
   const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  ASM_LAUNCH(avgpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)y, N, H, W, C, k, stride, pad, Ho, Wo, count_valid);
   ASM_CHECK_LAUNCH("avgpool_fwd");
   return ASM_OK;
@@ -468,7 +468,7 @@ extern "C" int asm_avgpool_bwd(const void* dy, void* dx, int N, int H, int W, in
   ASM_REQUIRE(stride == 1 || stride == 2, "avgpool_bwd: stride %d not supported (the shortcut pools use 1 and 2)", stride);
   const size_t nvec = (size_t)N * H * W * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(avgpool_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (bf16_t*)dx, N, H, W, C, k, stride, pad, Ho, Wo, count_valid, (const bf16_t*)addend);
   ASM_CHECK_LAUNCH("avgpool_bwd");
   return ASM_OK;
@@ -478,7 +478,7 @@ extern "C" int asm_upsample2x_bwd(const void* dy, void* dx, int N, int Hs, int W
   ASM_REQUIRE(dy && dx && N > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0, "upsample2x_bwd: bad arguments");
   const size_t nvec = (size_t)N * Hs * Ws * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(upsample_bwd_kernel<false>, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(upsample_bwd_kernel<false>, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      nullptr, (bf16_t*)dx, N, Hs, Ws, C);
   ASM_CHECK_LAUNCH("upsample2x_bwd");
   return ASM_OK;
@@ -489,7 +489,7 @@ extern "C" int asm_upsample2x_bwd_masked(const void* dy, const uint8_t* relu_mas
   ASM_REQUIRE(dy && relu_mask && dx && N > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0, "upsample2x_bwd_masked: bad arguments");
   const size_t nvec = (size_t)N * Hs * Ws * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(upsample_bwd_kernel<true>, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(upsample_bwd_kernel<true>, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      relu_mask, (bf16_t*)dx, N, Hs, Ws, C);
   ASM_CHECK_LAUNCH("upsample2x_bwd_masked");
   return ASM_OK;
@@ -504,7 +504,7 @@ extern "C" int asm_blurpool_fwd(const void* x, void* y, int N, int H, int W, int
   const int Ho = blur_out(H, k, stride), Wo = blur_out(W, k, stride);
   const size_t nvec = (size_t)N * Ho * Wo * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(blur_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  ASM_LAUNCH(blur_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)y, N, H, W, C, k, stride, Ho, Wo, blur_coef(k));
   ASM_CHECK_LAUNCH("blurpool_fwd");
   return ASM_OK;
@@ -517,7 +517,7 @@ extern "C" int asm_blurpool_bwd(const void* dy, void* dx, int N, int H, int W, i
   const int Ho = blur_out(H, k, stride), Wo = blur_out(W, k, stride);
   const size_t nvec = (size_t)N * H * W * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(blur_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(blur_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (bf16_t*)dx, N, H, W, C, k, stride, Ho, Wo, blur_coef(k));
   ASM_CHECK_LAUNCH("blurpool_bwd");
   return ASM_OK;
@@ -527,10 +527,10 @@ extern "C" int asm_gap_fwd(const void* x, void* y, int N, int HW, int C, void* s
   ASM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_fwd: bad arguments");
   const int vcb = C / 8 < 32 ? C / 8 : 32;
   if (HW >= 512)
-    hipLaunchKernelGGL((gap_fwd_kernel<false, 1024>), dim3(cdiv(C / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
+    ASM_LAUNCH((gap_fwd_kernel<false, 1024>), dim3(cdiv(C / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (bf16_t*)y, HW, C, C, vcb);
   else
-    hipLaunchKernelGGL((gap_fwd_kernel<false, 256>), dim3(cdiv(C / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
+    ASM_LAUNCH((gap_fwd_kernel<false, 256>), dim3(cdiv(C / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (bf16_t*)y, HW, C, C, vcb);
   ASM_CHECK_LAUNCH("gap_fwd");
   return ASM_OK;
@@ -540,10 +540,10 @@ extern "C" int asm_sk_gap(const void* f, void* s, int N, int HW, int F, void* st
   ASM_REQUIRE(f && s && N > 0 && HW > 0 && F > 0 && F % 8 == 0, "sk_gap: bad arguments");
   const int vcb = F / 8 < 32 ? F / 8 : 32;
   if (HW >= 512)
-    hipLaunchKernelGGL((gap_fwd_kernel<true, 1024>), dim3(cdiv(F / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
+    ASM_LAUNCH((gap_fwd_kernel<true, 1024>), dim3(cdiv(F / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
                        (const bf16_t*)f, (bf16_t*)s, HW, 2 * F, F, vcb);
   else
-    hipLaunchKernelGGL((gap_fwd_kernel<true, 256>), dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
+    ASM_LAUNCH((gap_fwd_kernel<true, 256>), dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)f, (bf16_t*)s, HW, 2 * F, F, vcb);
   ASM_CHECK_LAUNCH("sk_gap");
   return ASM_OK;
@@ -553,7 +553,7 @@ extern "C" int asm_gap_bwd(const void* dy, void* dx, int N, int HW, int C, void*
   ASM_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_bwd: bad arguments");
   const size_t nvec = (size_t)N * HW * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(gap_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (bf16_t*)dx, N, HW, C);
   ASM_CHECK_LAUNCH("gap_bwd");
   return ASM_OK;

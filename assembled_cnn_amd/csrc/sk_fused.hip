@@ -518,7 +518,7 @@ static int sk_gap_bn_impl(const void* y, const float* scale, const float* shift,
   const dim3 grid(cdiv(F / 8, vcb), N);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_GAP(NT, ST)                                                                                       \
-  hipLaunchKernelGGL((sk_gap_bn_kernel<NT, ST>), grid, dim3(NT), 0, st, (const bf16_t*)y, scale, shift, (bf16_t*)s, HW, F, \
+  ASM_LAUNCH((sk_gap_bn_kernel<NT, ST>), grid, dim3(NT), 0, st, (const bf16_t*)y, scale, shift, (bf16_t*)s, HW, F, \
                      vcb, mean, invstd, stats)
   if (stats) { if (HW >= 512) LAUNCH_GAP(1024, true); else LAUNCH_GAP(256, true); }
   else { if (HW >= 512) LAUNCH_GAP(1024, false); else LAUNCH_GAP(256, false); }
@@ -543,7 +543,7 @@ extern "C" int asm_sk_select_bn_fwd(const void* y, const float* scale, const flo
   SKF_OK("sk_select_bn_fwd");
   ASM_REQUIRE(y && scale && shift && att && v, "sk_select_bn_fwd: null pointer");
   const size_t nvec = (size_t)N * HW * (F / 8);
-  hipLaunchKernelGGL(sk_select_bn_fwd_kernel, dim3((unsigned)cdivz(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(sk_select_bn_fwd_kernel, dim3((unsigned)cdivz(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)y, scale, shift, att, (bf16_t*)v, N, HW, F);
   ASM_CHECK_LAUNCH("sk_select_bn_fwd");
   return ASM_OK;
@@ -557,7 +557,7 @@ static int sk_att_impl(const void* y, const float* scale, const float* shift, co
   const dim3 grid(cdiv(F / 8, vcb), N);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_ATT(NT, ST)                                                                                          \
-  hipLaunchKernelGGL((sk_bn_bwd_att_kernel<NT, ST>), grid, dim3(NT), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)dv, \
+  ASM_LAUNCH((sk_bn_bwd_att_kernel<NT, ST>), grid, dim3(NT), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)dv, \
                      att, (bf16_t*)datt, HW, F, vcb, mean, invstd, stats)
   if (stats) { if (HW >= 512) LAUNCH_ATT(1024, true); else LAUNCH_ATT(256, true); }
   else { if (HW >= 512) LAUNCH_ATT(1024, false); else LAUNCH_ATT(256, false); }
@@ -584,7 +584,7 @@ extern "C" int asm_sk_bn_bwd_finalize(const float* grad_stats, const float* mask
   SKF_OK("sk_bn_bwd_finalize");
   ASM_REQUIRE(grad_stats && mask_stats && att && ds && gamma && mean && invstd && dgamma && dbeta && coefA && coefB && coefC,
               "sk_bn_bwd_finalize: null pointer");
-  hipLaunchKernelGGL(sk_bn_bwd_finalize_kernel, dim3(cdiv(2 * F, 16)), dim3(1024), 0, (hipStream_t)stream, grad_stats,
+  ASM_LAUNCH(sk_bn_bwd_finalize_kernel, dim3(cdiv(2 * F, 16)), dim3(1024), 0, (hipStream_t)stream, grad_stats,
                      mask_stats, att, (const bf16_t*)ds, N, HW, F, gamma, mean, invstd, dgamma, dbeta, coefA, coefB, coefC);
   ASM_CHECK_LAUNCH("sk_bn_bwd_finalize");
   return ASM_OK;
@@ -601,7 +601,7 @@ extern "C" int asm_sk_bn_bwd_reduce(const void* dv, const float* att, const void
   SKF_OK("sk_bn_bwd_reduce");
   ASM_REQUIRE(dv && att && ds && y && scale && shift && mean && invstd && partial, "sk_bn_bwd_reduce: null pointer");
   const SkBnGeom g = make_geom(N, HW, F);
-  hipLaunchKernelGGL(sk_bn_bwd_reduce_kernel, dim3(g.chunks, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dv, att,
+  ASM_LAUNCH(sk_bn_bwd_reduce_kernel, dim3(g.chunks, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dv, att,
                      (const bf16_t*)ds, (const bf16_t*)y, scale, shift, mean, invstd, g, partial);
   ASM_CHECK_LAUNCH("sk_bn_bwd_reduce");
   return ASM_OK;
@@ -613,7 +613,7 @@ extern "C" int asm_sk_bn_bwd_apply(const void* dv, const float* att, const void*
   SKF_OK("sk_bn_bwd_apply");
   ASM_REQUIRE(dv && att && ds && y && scale && shift && coefA && coefB && coefC && dy, "sk_bn_bwd_apply: null pointer");
   const SkBnGeom g = make_geom(N, HW, F);
-  hipLaunchKernelGGL(sk_bn_bwd_apply_kernel, dim3(g.chunks, N), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH(sk_bn_bwd_apply_kernel, dim3(g.chunks, N), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dv, att, (const bf16_t*)ds, (const bf16_t*)y, scale, shift, coefA, coefB, coefC,
                      (bf16_t*)dy, g);
   ASM_CHECK_LAUNCH("sk_bn_bwd_apply");

@@ -217,7 +217,7 @@ extern "C" int asm_sk_select_fwd(const void* f, const float* att, void* v, int N
   ASM_REQUIRE(f && att && v, "sk_select_fwd: null pointer");
   const size_t nvec = (size_t)N * HW * (F / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "sk/se: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(sk_select_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)f,
+  ASM_LAUNCH(sk_select_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)f,
                      att, (bf16_t*)v, N, HW, F);
   ASM_CHECK_LAUNCH("sk_select_fwd");
   return ASM_OK;
@@ -229,10 +229,10 @@ extern "C" int asm_sk_select_bwd_att(const void* f, const void* dv, const float*
   ASM_REQUIRE(f && dv && att && datt, "sk_select_bwd_att: null pointer");
   const int vcb = F / 8 < 32 ? F / 8 : 32;
   if (HW >= 512)
-    hipLaunchKernelGGL(sk_bwd_att_kernel<1024>, dim3(cdiv(F / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
+    ASM_LAUNCH(sk_bwd_att_kernel<1024>, dim3(cdiv(F / 8, vcb), N), dim3(1024), 0, (hipStream_t)stream,
                        (const bf16_t*)f, (const bf16_t*)dv, att, (bf16_t*)datt, HW, F, vcb);
   else
-    hipLaunchKernelGGL(sk_bwd_att_kernel<256>, dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
+    ASM_LAUNCH(sk_bwd_att_kernel<256>, dim3(cdiv(F / 8, vcb), N), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)f, (const bf16_t*)dv, att, (bf16_t*)datt, HW, F, vcb);
   ASM_CHECK_LAUNCH("sk_select_bwd_att");
   return ASM_OK;
@@ -244,7 +244,7 @@ extern "C" int asm_sk_select_bwd_f(const void* dv, const float* att, const void*
   ASM_REQUIRE(dv && att && ds && df, "sk_select_bwd_f: null pointer");
   const size_t nvec = (size_t)N * HW * (F / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "sk/se: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(sk_bwd_f_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dv, att,
+  ASM_LAUNCH(sk_bwd_f_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dv, att,
                      (const bf16_t*)ds, (bf16_t*)df, N, HW, F);
   ASM_CHECK_LAUNCH("sk_select_bwd_f");
   return ASM_OK;
@@ -254,7 +254,7 @@ extern "C" int asm_se_scale_fwd(const void* x, const float* e, void* y, int N, i
   ASM_REQUIRE(x && e && y && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale_fwd: bad arguments");
   const size_t nvec = (size_t)N * HW * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "sk/se: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(se_scale_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, e,
+  ASM_LAUNCH(se_scale_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, e,
                      (bf16_t*)y, N, HW, C);
   ASM_CHECK_LAUNCH("se_scale_fwd");
   return ASM_OK;
@@ -264,7 +264,7 @@ extern "C" int asm_se_scale_bwd_e(const void* x, const void* dy, const float* e,
                                   void* stream) {
   ASM_REQUIRE(x && dy && e && de && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale_bwd_e: bad arguments");
   const int vcb = C / 8 < 32 ? C / 8 : 32;
-  hipLaunchKernelGGL(se_bwd_e_kernel, dim3(cdiv(C / 8, vcb), N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  ASM_LAUNCH(se_bwd_e_kernel, dim3(cdiv(C / 8, vcb), N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (const bf16_t*)dy, e, (bf16_t*)de, HW, C, vcb);
   ASM_CHECK_LAUNCH("se_scale_bwd_e");
   return ASM_OK;
@@ -275,7 +275,7 @@ extern "C" int asm_se_scale_bwd_x(const void* dy, const float* e, const void* ds
   ASM_REQUIRE(dy && e && dsq && dx && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale_bwd_x: bad arguments");
   const size_t nvec = (size_t)N * HW * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "sk/se: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(se_bwd_x_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, e,
+  ASM_LAUNCH(se_bwd_x_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, e,
                      (const bf16_t*)dsq, (bf16_t*)dx, N, HW, C);
   ASM_CHECK_LAUNCH("se_scale_bwd_x");
   return ASM_OK;

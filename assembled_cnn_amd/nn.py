@@ -321,7 +321,10 @@ class Var(object):
     self.grad_mask = None
 
   def take_masked_grad(self):
-    """-> (gradient tensor, packed mask or None) without materialising the product"""
+    """-> (gradient tensor, packed mask or None) without materialising the product.  A pooled contribution nobody
+    gathered (take_pool_grad) is scattered first, so a caller that bypasses ``.grad`` can never drop it."""
+    if self.pool_grad is not None:
+      self.grad      # the getter scatters it (and materialises a lazy mask)
     return self._grad, self.grad_mask
 
   def take_pool_grad(self, d):
@@ -896,6 +899,8 @@ def avg_pool(ctx: Ctx, x: Var, k: int, stride: int, pad: int, count_valid: bool)
   y = Var(ops.avgpool_fwd(x.data, k, stride, pad, Ho, Wo, count_valid))
   if ctx.tape is not None:
     def bwd():
+      if y.grad is None:
+        raise RuntimeError('avg_pool backward: no gradient reached this layer')
       if (x.needs_grad and x.pool_grad is None and stride in (1, 2) and stride <= k <= 2 * stride and
           os.environ.get('ASM_POOL_FUSE', '1') != '0'):
         # leave the contribution in pooled form: the block's first 1x1 convolution gathers it in its input-gradient

@@ -16,7 +16,9 @@
  *   - activations: NHWC bfloat16 (C % 8 == 0); conv filters: KRSC bfloat16 ([Cout][R][S][Cin]);
  *     statistics, BN parameters, master weights, gradients of parameters: float32.
  *   - every launch takes the hipStream_t to enqueue on (as void*); calls are asynchronous and
- *     hold no global mutable state, so they are re-entrant across streams/threads.
+ *     re-entrant across streams/threads.  The library reads no environment variable and keeps ONE piece
+ *     of process-wide state, set explicitly by the caller: the kernel-selection overrides of asm_tuning
+ *     (below; defaults = the shipped heuristics).  Set it before launching from other threads.
  */
 #ifndef ASM_HIP_H_
 #define ASM_HIP_H_
@@ -37,6 +39,33 @@ extern "C" {
 
 const char* asm_last_error(void);
 int asm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel-selection overrides (tests, same-box A/B runs, tuning).  The defaults are the heuristics the
+ * benchmarked binary uses; nothing here changes results beyond the summation order a different tile
+ * implies.  asm_set_tuning copies the struct (NULL restores the defaults) and is process-wide: it is
+ * not synchronised against concurrent launches from other threads.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asm_tuning {
+  int32_t igemm_mode;      /* 0: per-layer choice; 1: register-staged 2-deep fallback kernel; 2: its LDS-DMA form       */
+  int32_t igemm_tile;      /* 0: per-layer choice; 1: 128-row tiles only; 2: 256 x 128; 3: 256 x 256 where Ci % 64 == 0  */
+  int32_t igemm_v2;        /* 1: address-free main loop (igemm2) where instantiated; 0: general fallback kernel          */
+  int32_t conv_halo;       /* 1: resident-halo 3x3 kernels for the 112 x 112 narrow layers                               */
+  int32_t igemm_smallm;    /* 1: 128 x 64 tiles for small-M deep-K layers                                                 */
+  int32_t igemm_pfa;       /* -1: per-layer choice; 0 / 1: addend-prefetching epilogue off / on                           */
+  int32_t igemm_bk64_1x1;  /* 1x1 layers with at most this many 128 x 128 tiles take 64-channel steps (0: never)         */
+  int32_t dgrad_parity;    /* 1: stride-2 input gradients as four parity classes                                          */
+  int32_t wgrad_halo;      /* 0: off; 1: resident-halo weight gradient on the large maps; 2: wherever the shape allows    */
+  int32_t wgrad_big;       /* -1: per-layer choice; 0 / 1: 256 x 256 weight-gradient tile off / on                        */
+  int32_t wgrad_splits;    /* 0: cost model; n > 0: force n pixel splits                                                   */
+  int32_t wgrad_linear;    /* 1: linear-address form for 1x1 stride-1 weight gradients                                    */
+  int32_t bn_rows;         /* partial rows (= workgroups) of the batch-norm reducers                                       */
+  int32_t conv_sched;      /* main-loop schedule variant of the MFMA convolution kernels (0: default)                     */
+  int32_t reserved[6];
+} asm_tuning;
+void asm_tuning_defaults(asm_tuning* t);
+int asm_set_tuning(const asm_tuning* t);
+void asm_get_tuning(asm_tuning* t);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution -- replaces tf.layers.conv2d inside conv2d_fixed_padding (nets/model_helper.py:67-78),
@@ -206,6 +235,8 @@ int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* relu_mask, in
  *                           accumulation, out f32 or bf16 with row stride ldo.  K % 16 == 0; ldp, ldq % 8 == 0.
  *                           fprop: p = x [M][Cin], q = kernel [Cout][Cin]; input gradient: p = dy [M][ldy], q = the
  *                           CRSK copy [Cin][ldk] (asm_filter_transpose), K = ldk.
+ *                           Columns N .. ldo-1 of a padded output row (the classifier's 1001 -> 1008) are written as
+ *                           zeros, so whole-row readers (isfinite checks, taps) never see uninitialised memory.
  *   asm_dense_bn_fwd:       ypre = bf16(x . w^T) [M][N]; training-mode batch norm of ypre over the M rows (statistics of
  *                           the bf16-rounded values, moving-statistics update, mean / invstd out), z = bn(ypre) [relu],
  *                           optional packed ReLU mask [M][N/8] -- one launch (== asm_conv2d_fprop + asm_bn_small_fwd).

@@ -239,8 +239,11 @@ def _conv_raw(x: torch.Tensor, w_hwio: torch.Tensor, kernel_size: int, strides: 
 def conv2d_fixed_padding(ctx: Ctx, inputs, filters, kernel_size, strides, layer_name=None):
   cin = inputs.shape[1]
   w = ctx.vs.conv_kernel(kernel_size, cin, filters, layer_name)
+  name = ctx.vs.last_name
   ctx.note_conv(inputs)
-  return ctx.q(_conv_raw(inputs, ctx.qw(w), kernel_size, strides))
+  y = ctx.q(_conv_raw(inputs, ctx.qw(w), kernel_size, strides))
+  ctx.note_extra('conv_out:' + name, y)
+  return y
 
 
 def _bn_raw(ctx: Ctx, inputs, training, zero_gamma, momentum, epsilon, layer_name=None):
@@ -366,6 +369,7 @@ def sk_conv2d(ctx: Ctx, inputs, filters, strides, training, r=2, L=32, bn_moment
   w1 = vs.conv_kernel(1, filters, d, layer_name='sk_fc_1')
   ctx.note_conv(fea_s)
   fea_z = ctx.q(_conv_raw(fea_s, ctx.qw(w1), 1, 1))
+  ctx.note_extra('conv_out:' + vs.last_name, fea_z)
   fea_z = batch_norm(ctx, fea_z, training, momentum=bn_momentum, relu=True)
   w2 = vs.conv_kernel(1, d, filters * 2, layer_name='sk_fc_2')
   att = _conv_raw(fea_z, ctx.qw(w2), 1, 1)                    # logits kept fp32
@@ -670,7 +674,9 @@ class Model(object):
           u = dropblock_uniforms((1, t.shape[1], t.shape[2] - 6, t.shape[3] - 6))
         else:
           u = next(db_iter)
-        return dropblock(t, keep_prob, 7, gamma_scale, True, u)
+        # one storage rounding where a low-precision implementation stores the DropBlock output (the reference's fp16 graph
+        # holds it as an fp16 tensor between ops); the ReLU that may follow commutes with the rounding
+        return ctx.q(dropblock(t, keep_prob, 7, gamma_scale, True, u))
       return fn
 
     for i, num_blocks in enumerate(self.block_sizes):

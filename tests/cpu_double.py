@@ -347,6 +347,7 @@ class CpuDouble(object):
       acc = acc + T(addend, (M, ldo), 'bf16').float()[:, :N]
     o = T(out, (M, ldo), 'f32' if out_f32 else 'bf16')
     o[:, :N] = acc.to(o.dtype)
+    o[:, N:] = 0          # pad columns of a padded output row are written as zeros (include/asm_hip.h)
     return 0
 
   def asm_dense_small_wgrad(self, x, ldx, dy, ldy, M, Cin, Cout, dw, ldw, stream):

@@ -51,7 +51,23 @@ def test_config3_forward_at_batch_256_224_vs_oracle(hip_lib):
   assert abs(st['loss_product'] - st['loss_oracle']) <= 2e-2 * abs(st['loss_oracle']), st
 
 
-@pytest.mark.parametrize('name,batch,size', [('r50v1', 16, 64), ('a-r50-d', 16, 64), ('se-proj', 16, 64), ('a-r152', 8, 96)])
+def test_config4_shard_at_size_512_images_mixup_label_smoothing(hip_lib):
+  """BASELINE config 4, one GPU's shard literally: 2 x 256 uint8 images at 224 x 224 -> mixup type 1 (lambda ~
+  Beta(0.2, 0.2), seed 4) -> 256 images, label smoothing 0.1, Assemble-ResNet-50 + D in training mode: the mixed input,
+  the mixed targets, the logits and the loss against the oracle's forward."""
+  rep = mp.check_train_forward_at_size('a-r50-d', 'cuda', 512, 224, mixup_type=1, label_smoothing=0.1)
+  assert rep['batch'] == 256
+
+
+def test_config5_shard_at_size_128_images_kd(hip_lib):
+  """BASELINE config 5, one GPU's shard literally: Assemble-ResNet-152 (alpha 1, beta 2) at batch 128, 224 x 224, with the
+  KD loss on N(0, 3^2) teacher logits (kd_temp 1): forward + loss against the oracle, logits bound calibrated against the
+  oracle's own bf16-vs-fp32 rounding noise (70 blocks at random init amplify rounding beyond any fixed tolerance)."""
+  rep = mp.check_train_forward_at_size('a-r152', 'cuda', 128, 224, kd_temp=1.0, noise_floor=True, loss_tol=3e-2)
+  assert rep['batch'] == 128
+
+
+@pytest.mark.parametrize('name,batch,size', [('r50v1', 16, 64), ('a-r50-d', 16, 128), ('se-proj', 16, 64), ('a-r152', 16, 96)])
 def test_teacher_forced_backward_per_layer_parity(hip_lib, name, batch, size):
   """The hand-written backward tape, layer by layer, without depth amplification (tests/model_parity.py): every conv ->
   BN [-> + residual] [-> ReLU] group, SK unit and SE / DropBlock block output is a forced point -- the gradient the tape
@@ -62,7 +78,7 @@ def test_teacher_forced_backward_per_layer_parity(hip_lib, name, batch, size):
   gathered in conv1's input-gradient epilogue, the fused SK backward, the reordered projection-block tape."""
   errs, st = mp.check_teacher_forced_backward(name, 'cuda', batch, size)
   assert st['forced'] >= 45 and len(errs) >= 200, st
-  assert sum(st['kinds'][k] for k in ('dout', 'dout-lazy', 'dx', 'dout-squeeze', 'dx-squeeze')) >= (100 if name != 'r50v1' else 50)
+  assert sum(st['kinds'][k] for k in ('dout', 'dout-lazy', 'dx', 'dout-squeeze', 'dx-squeeze')) >= (100 if 'a-r' in name else 50)
 
 
 @pytest.mark.parametrize('env', [{'ASM_BN_DUAL': '0'}, {'ASM_POOL_FUSE': '0'}, {'ASM_SK_FUSED': '0'},
@@ -79,7 +95,7 @@ def test_teacher_forced_backward_with_a_fusion_switched_off(hip_lib, env):
 def test_teacher_forced_backward_with_dropblock(hip_lib):
   """DropBlock on (keep_prob 0.9, shared uniform draws): stages 3 / 4 run the separate BN -> DropBlock -> ReLU and
   add + ReLU forms of the block; 224 x 224 so that DropBlock's 7 x 7 block fits the 7 x 7 maps"""
-  errs, st = mp.check_teacher_forced_backward('a-r50-d', 'cuda', 2, 224, keep_prob=0.9)
+  errs, st = mp.check_teacher_forced_backward('a-r50-d', 'cuda', 16, 224, keep_prob=0.9)   # the squeeze layers normalise over the batch only
   assert len(errs) >= 400
 
 
@@ -137,3 +153,29 @@ def test_full_size_layer_shapes_run(hip_lib):
   assert abs(ce - math.log(1001)) < 1.0, ce
   assert bool(torch.isfinite(tr.model.arena.w32).all())
   assert tr.model.num_params() == 41867721
+
+
+@pytest.mark.parametrize('name', ['a-r50-d'])
+def test_side_streams_change_no_bit_over_several_steps(hip_lib, monkeypatch, name):
+  """The weight-gradient side stream and the BigLittle big-branch stream (both default-on) against ONE stream: three
+  consecutive training steps (so the caching allocator recycles blocks across steps and streams), then an evaluation
+  forward and a tape-less training-mode forward -- identical weights, moving statistics, momentum and logits, bit for bit."""
+  from assembled_cnn_amd.train import HParams, Trainer
+  img, x, labels = mp.inputs(8, 96)
+  outs = []
+  for knob in ('1', '0'):
+    monkeypatch.setenv('ASM_WGRAD_STREAM', knob)
+    monkeypatch.setenv('ASM_BL_STREAMS', knob)
+    hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
+                 zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01, batch_size=8, label_smoothing=0.1)
+    tr = Trainer(hp, seed=3, device='cuda')
+    for _ in range(3):
+      tr.train_step(img.cuda(), labels.cuda())
+    assert (tr.model.arena.side_stream is not None) == (knob == '1')
+    ev = tr.eval_logits(x.cuda()).clone()
+    tl = tr.model(x.cuda(), True, use_resnet_d=True, record_tape=False).clone()
+    torch.cuda.synchronize()
+    a = tr.model.arena
+    outs.append((a.w32.clone(), a.m32.clone(), a.state.clone(), ev, tl, tr.last['loss_rows'].clone()))
+  for p, q in zip(*outs):
+    assert torch.equal(p, q)
