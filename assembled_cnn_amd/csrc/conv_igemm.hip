@@ -618,7 +618,12 @@ struct Cfg2 {
   static_assert(LDS <= 160 * 1024, "lds");
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS, bool PFA = false, bool POOL = false>
+// SCHED 1 (asm_tuning.conv_sched = 1): the LDS-DMA pieces of step k+1 are issued IN BETWEEN the MFMA groups of step k
+// instead of all at once right after the barrier.  Every wave comes out of the barrier at the same moment, and one piece
+// costs its wave 60-180 issue cycles (v_readfirstlane + M0 write + the buffer_load itself): with 8 pieces up front both waves
+// of a SIMD sit in their issue phase together and the matrix pipe idles for that long at the head of every step.
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS, bool PFA = false, bool POOL = false,
+          int SCHED = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
   using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
   using C2 = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
@@ -702,6 +707,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
   }
 
   const int wrow0 = wave * (64 / CPR);
+  // pieces [lo, hi) of a step's XP + WP LDS-DMA pieces (activation rows first)
+  auto issue_part = [&](int stage, const int t, unsigned xso, unsigned wso, const int lo, const int hi) {
+    unsigned char* xs = smem + stage * STAGE;
+    unsigned char* ws = xs + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < XP; ++j)
+      if (j >= lo && j < hi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (j * RPP + wrow0) * ROWB), 16,
+                                                 (int)vx[j][t], (int)xso, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WP; ++j)
+      if (XP + j >= lo && XP + j < hi && j * RPP + wrow0 < BN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(ws + (j * RPP + wrow0) * ROWB), 16,
+                                                 (int)vw[j], (int)wso, 0, 0);
+  };
   auto issue = [&](int stage, const int t, unsigned xso, unsigned wso) {
     unsigned char* xs = smem + stage * STAGE;
     unsigned char* ws = xs + BM * ROWB;
@@ -768,6 +788,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) {
         const bool more = (t + 1 < NTAP) || (kc + 1 < p.kchunks);
+        if constexpr (SCHED == 1 && KK >= 2) {
+          constexpr int NP = XP + WP, G = KK - 1;            // pieces, MFMA groups in front of the barrier
+          constexpr int PPG = (NP + G - 1) / G;
+          const int tn = (t + 1 < NTAP) ? t + 1 : 0;         // compile-time after unrolling
+          const unsigned xso = (t + 1 < NTAP) ? kcb : kcb + BK * 2;
+          const unsigned wso = xso + (unsigned)(p.wt0 + (tn / S) * p.wtr + (tn % S) * p.wts) * tapw;
+#pragma unroll
+          for (int kk = 0; kk + 1 < KK; ++kk) {
+            if (more) issue_part(cur ^ 1, tn, xso, wso, kk * PPG, (kk + 1) * PPG < NP ? (kk + 1) * PPG : NP);
+            load_frags(cur, kk + 1, (kk + 1) & 1);
+            mma(kk & 1);
+          }
+        } else {
         if (t + 1 < NTAP) {
           issue(cur ^ 1, t + 1, kcb, kcb + (unsigned)(p.wt0 + ((t + 1) / S) * p.wtr + ((t + 1) % S) * p.wts) * tapw);
         } else if (kc + 1 < p.kchunks) {
@@ -777,6 +810,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
         for (int kk = 0; kk + 1 < KK; ++kk) {
           load_frags(cur, kk + 1, (kk + 1) & 1);
           mma(kk & 1);
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // next tile visible; everyone's reads of this stage are in registers
@@ -995,11 +1029,19 @@ int try_halo(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   return 1;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2, bool PFA = false, bool POOL = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2, bool PFA = false, bool POOL = false,
+          int SCHED = 0>
 int launch2_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
   constexpr int NTHR = 64 * WGM * WGN;
-  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL>;
+  // measured (tools/conv_bench.py, same box, round 3): spreading the DMA issue is +2..4 % on the 3x3 layers (7 of 8 shapes,
+  // fprop and dgrad) and -3..6 % on the deep 1x1 layers (their steps are short: the last pieces land too late), hence the
+  // per-layer default; asm_tuning.conv_sched = 1 / 2 forces it on / off for every instantiated shape
+  if constexpr (SCHED == 0 && BK == 64 && BN >= 128 && !OUT_F32 && !POOL && ((R == 3 && S == 3) || (R == 1 && S == 1))) {
+    const int cs = asm_tune().conv_sched;
+    if (cs == 1 || (cs == 0 && R == 3)) return launch2_one<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL, 1>(a, st);
+  }
+  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL, SCHED>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm2_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));

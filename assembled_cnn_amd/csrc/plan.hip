@@ -317,7 +317,8 @@ extern "C" void asm_tuning_defaults(asm_tuning* t) {
 }
 extern "C" int asm_set_tuning(const asm_tuning* t) {
   if (t && (t->bn_rows <= 0 || t->igemm_mode < 0 || t->igemm_mode > 2 || t->igemm_tile < 0 || t->igemm_tile > 3 ||
-            t->wgrad_halo < 0 || t->wgrad_halo > 2 || t->wgrad_splits < 0 || t->igemm_bk64_1x1 < 0))
+            t->wgrad_halo < 0 || t->wgrad_halo > 2 || t->wgrad_splits < 0 || t->igemm_bk64_1x1 < 0 || t->conv_sched < 0 ||
+            t->conv_sched > 2))
     ASM_FAIL(ASM_EINVAL, "asm_set_tuning: field out of range");
   g_tuning = t ? *t : make_default_tuning();
   return ASM_OK;

@@ -59,6 +59,35 @@ class PlanSummary(C.Structure):
               ('forward_macs_per_image', C.c_int64), ('wgrad_workspace_bytes', C.c_int64)]
 
 
+class Tuning(C.Structure):
+  """struct asm_tuning: the kernel-selection overrides (the library itself reads no environment variable)"""
+  _fields_ = [(n, C.c_int32) for n in (
+      'igemm_mode', 'igemm_tile', 'igemm_v2', 'conv_halo', 'igemm_smallm', 'igemm_pfa', 'igemm_bk64_1x1', 'dgrad_parity',
+      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched')] + [('reserved', C.c_int32 * 6)]
+
+
+# environment variable of the HOST -> asm_tuning field (same-box A/B runs, tests); unset = the library's default
+TUNING_ENV = {'ASM_IGEMM_MODE': 'igemm_mode', 'ASM_IGEMM_TILE': 'igemm_tile', 'ASM_IGEMM_V2': 'igemm_v2',
+              'ASM_CONV_HALO': 'conv_halo', 'ASM_IGEMM_SMALLM': 'igemm_smallm', 'ASM_IGEMM_PFA': 'igemm_pfa',
+              'ASM_IGEMM_BK64_1X1': 'igemm_bk64_1x1', 'ASM_DGRAD_PARITY': 'dgrad_parity', 'ASM_WGRAD_HALO': 'wgrad_halo',
+              'ASM_WGRAD_BIG': 'wgrad_big', 'ASM_WGRAD_SPLITS': 'wgrad_splits', 'ASM_WGRAD_LINEAR': 'wgrad_linear',
+              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched'}
+
+
+def apply_env_tuning(lib) -> 'Tuning':
+  """asm_set_tuning(defaults overridden by whichever ASM_* variables are set in this process's environment)"""
+  t = Tuning()
+  lib.asm_tuning_defaults(C.byref(t))
+  for env, field in TUNING_ENV.items():
+    v = os.environ.get(env)
+    if v not in (None, ''):
+      setattr(t, field, int(v))
+  check_code = lib.asm_set_tuning(C.byref(t))
+  if check_code != ASM_OK:
+    raise ValueError('asm_set_tuning rejected the ASM_* overrides: %s' % (lib.asm_last_error() or b'').decode())
+  return t
+
+
 ASM_F32, ASM_BF16, ASM_F16 = 0, 1, 2
 ASM_AA_SCONV, ASM_AA_PROJ = 1, 2
 POOL_TYPES = {'gap': 0, 'gem': 1, 'flatten': 2}
@@ -72,6 +101,9 @@ _D = C.POINTER(ConvDesc)
 SIGNATURES = {
     'asm_last_error': (C.c_char_p, []),
     'asm_abi_version': (_I, []),
+    'asm_tuning_defaults': (None, [C.POINTER(Tuning)]),
+    'asm_set_tuning': (_I, [C.POINTER(Tuning)]),
+    'asm_get_tuning': (None, [C.POINTER(Tuning)]),
     'asm_conv2d_fprop': (_I, [_D, _P, _P, _P, _P, _P]),
     'asm_conv2d_stats_blocks': (_I, [_D]),
     'asm_conv2d_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
@@ -111,9 +143,6 @@ SIGNATURES = {
     'asm_sk_gap_bn': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'asm_sk_select_bn_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'asm_sk_select_bn_bwd_att': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'asm_sk_gap_bn_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'asm_sk_select_bn_bwd_att_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'asm_sk_bn_bwd_finalize': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_sk_bn_bwd_blocks': (_I, [_I, _I, _I]),
     'asm_sk_bn_bwd_reduce': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'asm_sk_bn_bwd_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -149,11 +178,8 @@ SIGNATURES = {
     'asm_bn_small_max_rows': (_I, []),
     'asm_bn_small_fwd': (_I, [_P, _P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _P]),
     'asm_bn_small_bwd': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    'asm_dense_bn_max_rows': (_I, []),
     'asm_dense_small': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
     'asm_dense_small_wgrad': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P]),
-    'asm_dense_bn_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
-    'asm_dense_dgrad_bn_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_resize_crop_flip': (_I, [_P, C.c_int64, _P, _I, _I, _I, _I, _P, _P]),
     'asm_model_plan': (_I, [C.POINTER(ModelCfg), _I, _I, _I, C.POINTER(PlanEntry), _I, C.POINTER(PlanSummary)]),
 }
@@ -166,6 +192,13 @@ DEBUG_SIGNATURES = {
     'asm_conv2d_wgrad_naive': (_I, [_D, _P, _P, _P, _P]),
     'asm_debug_tr_probe': (_I, [_P, _P]),
     'asm_conv2d_wgrad_plan': (_I, [_D, C.POINTER(C.c_int32 * 6)]),
+    # measured-slower variants (opt-in: ASM_DENSE_BN=1, ASM_SK_FACTOR=1)
+    'asm_dense_bn_max_rows': (_I, []),
+    'asm_dense_bn_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'asm_dense_dgrad_bn_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asm_sk_gap_bn_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_select_bn_bwd_att_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_bn_bwd_finalize': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -192,11 +225,16 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     fn.argtypes = args
   if lib.asm_abi_version() != ABI_VERSION:
     raise AsmError('libasm_hip.so ABI version %d != %d' % (lib.asm_abi_version(), ABI_VERSION))
+  apply_env_tuning(lib)
   _lib = lib
   return lib
 
 
+CALLS = [0]   # C-ABI calls checked so far (bench.py reports launches per step from it)
+
+
 def check(code: int, what: str = ''):
+  CALLS[0] += 1
   if code != ASM_OK:
     msg = load().asm_last_error()
     msg = msg.decode() if msg else ''

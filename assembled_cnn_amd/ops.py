@@ -34,6 +34,19 @@ def L():
   return _L
 
 
+def abi_calls() -> int:
+  """number of C-ABI calls made through this module so far"""
+  return _lib.CALLS[0]
+
+
+def refresh_tuning():
+  """Re-read the ASM_* kernel-selection variables of THIS process and hand them to the library (asm_set_tuning).  The
+  library reads no environment itself; lib.load() does this once, tests / A/B tools call it after changing a knob."""
+  if _IS_DOUBLE:
+    return None
+  return _lib.apply_env_tuning(L())
+
+
 def _ptr(t: Optional[torch.Tensor]) -> int:
   if t is None:
     return 0

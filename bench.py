@@ -15,10 +15,15 @@ the product's side streams on (weight gradients beside the dgrad chain, the big 
 little one), where kernels share the CUs and individual durations depend on their neighbours.
 
 Extra objects on the line:
-  roofline      the dominant convolution kernel class (picked from HIP-event timings of every conv
-                launch in a warm-up step), timed with HIP events on the launch stream during the timed
-                region; achieved = algorithmic FLOPs of that launch / its mean duration, against the
-                gfx950 dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  roofline      what BASELINE.json's north_star names: the 3x3-convolution CLASS (every 3x3 fprop, input-gradient and
+                weight-gradient launch of a step, time-weighted) against the gfx950 dense bf16 MFMA peak (2.5 PFLOP/s,
+                MI355X_MICROARCH.md): achieved = the class's algorithmic FLOPs / its HIP-event time.  `dominant_layer` keeps
+                the single heaviest conv launch (picked in a warm-up step, timed with HIP events on the launch stream over
+                the timed region), `hbm` the batch-norm family against the HBM peak; `traffic` = HBM bytes per step of the
+                class from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes OF THIS COMMAND (profiles/, tools/profile_round.sh).
+  dp            N = 1: the step with the gradient exchange attached to an RCCL group of ONE (real bucket launches, stream
+                waits, casts; no link traffic) and `exchange_ms_exposed` = that step - the plain step.  N > 1: the bucket
+                plan of the run.  No N > 1 number exists in this repository until the driver's SCALE run.
   step          the whole step against its per-layer bound sum_l max(flops_l / 2.5 PFLOP/s, bytes_l / 8 TB/s)
                 (every conv as fprop + dgrad + wgrad with un-fused algorithmic bytes, every batch norm
                 as 3 + 5 tensor passes), plus two class figures from HIP events of ONE instrumented step run after
@@ -41,7 +46,8 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
-PMC_FILE = 'round2_pmc_traffic.json'
+PMC_FILE = 'round2_pmc_traffic.json'          # dominant layer, tools/conv_bench.py in isolation (round 2)
+CLASS_TRAFFIC_FILE = 'round3_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
 HBM_PEAK_GBS = 8000.0            # spec; MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {
@@ -202,6 +208,62 @@ def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=200.0):
             'sample': 'CPU oracle did not finish a batch-4 step sample within %.0f s on this host' % hard_timeout_s}
 
 
+def _flush_c_stdio():
+  try:
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+  except Exception:
+    pass
+
+
+def _dp_plan(gs, world):
+  nb = sum(len(seg) for seg in gs.segments)
+  width = 2 if gs.comm_dtype == 'bf16' else 4
+  return {'world': world, 'buckets': nb, 'bucket_bytes_max': max((hi - lo) for seg in gs.segments for lo, hi in seg) * width,
+          'bytes_per_step': gs.arena.total_elems * width, 'comm_dtype': gs.comm_dtype, 'backend': 'RCCL (torch.distributed nccl)',
+          'overlap': 'buckets are launched as the backward watermark passes them; the optimiser waits for the last one'}
+
+
+def _gradsync_leg(tr, step, sync, args, plain_ms):
+  """N = 1: the same steps with dp.GradSync attached to an RCCL group of ONE rank: every bucket launch, stream wait and
+  (bf16) cast is real, only the link traffic is missing.  exchange_ms_exposed = step with the exchange - step without."""
+  import socket
+  import torch.distributed as dist
+  from assembled_cnn_amd import dp
+  try:
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    if os.environ.get('NCCL_DEBUG', '').upper() in ('', 'VERSION'):
+      os.environ['NCCL_DEBUG'] = 'WARN'     # no version banner on stdout next to the one JSON line
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    os.environ['ASM_BL_STREAMS'] = '0'      # compared with the single-stream step (GradSync hands the weight-gradient stream back)
+    gs = dp.GradSync(tr.model.arena, comm_dtype=args.comm_dtype)
+    tr.grad_sync = gs
+    for _ in range(2):
+      step()
+    sync()
+    t1 = time.time()
+    for _ in range(args.steps):
+      step()
+    sync()
+    ms = 1000.0 * (time.time() - t1) / args.steps
+    info = _dp_plan(gs, 1)
+    info.update({'ms_per_step_with_exchange': round(ms, 3), 'exchange_ms_exposed': round(ms - plain_ms, 3),
+                 'what': 'RCCL group of ONE rank on this GPU (bucket launches, waits and casts are real, xGMI traffic is '
+                         'not); NO N > 1 number exists in this repository until the driver\'s SCALE run'})
+    tr.grad_sync = None
+    tr.model.arena.on_grad = None
+    dist.destroy_process_group()
+    return info
+  except Exception as e:   # a reported extra must never lose the measured number
+    tr.grad_sync = None
+    tr.model.arena.on_grad = None
+    return {'world': 1, 'error': repr(e)}
+
+
 def main():
   if len(sys.argv) >= 3 and sys.argv[1] == '--cpu-baseline-only':
     print(json.dumps(_cpu_baseline_worker(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 20.0)), flush=True)
@@ -218,6 +280,12 @@ def main():
                   help='time the step with the weight-gradient / BigLittle side streams on (the product default); '
                        'without it the timed region is single-stream and the overlapped rate is reported as an extra')
   ap.add_argument('--dump-convs', default='', help='write the per-conv-shape HIP-event times of the instrumented step here (markdown)')
+  ap.add_argument('--no-gradsync', action='store_true', help='N = 1: skip the extra leg with the gradient exchange attached')
+  ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='precision of the exchanged gradient buckets')
+  ap.add_argument('--dry-run-cpu', action='store_true',
+                  help='TEST ONLY (tests/test_bench_dryrun_cpu.py): run the control flow of this script -- rank-0 build, '
+                       'rendezvous, GradSync, barriers, MAX-reduce of the elapsed time, the JSON line -- on CPU over gloo with '
+                       'the test double of the C ABI and a tiny batch; the number it prints means nothing')
   args = ap.parse_args()
 
   import torch
@@ -230,15 +298,22 @@ def main():
     if world == 1 and args.gpus > 1:
       raise SystemExit('--gpus %d needs a torch.distributed.run launch with %d ranks' % (args.gpus, args.gpus))
     raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-  if not torch.cuda.is_available():
-    raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
-  torch.cuda.set_device(local_rank)
+  dry = args.dry_run_cpu
+  if not dry:
+    if not torch.cuda.is_available():
+      raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
   if rank == 0:
     __graft_entry__.build()
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world)
+    dist.init_process_group('gloo' if dry else 'nccl', rank=rank, world_size=world)
     dist.barrier()
+  if dry:
+    args.no_roofline = args.no_cpu_baseline = args.no_gradsync = True
+    from assembled_cnn_amd import ops as _ops
+    from tests.cpu_double import CpuDouble      # test infrastructure, only under --dry-run-cpu
+    _ops.set_library(CpuDouble(), is_double=True)
 
   # The timed region runs every kernel on ONE stream: per-kernel HIP-event durations (the `roofline` and `step` objects)
   # and the rocprofv3 summaries under profiles/ are then properties of the kernels.  With the side streams on (weight
@@ -256,14 +331,17 @@ def main():
   hp = HParams(**dict(dict(resnet_size=50, zero_gamma=True, weight_decay=1e-4, momentum=0.9,
                            base_learning_rate=0.1 * B * world / 256, learning_rate_decay_type='fixed',
                            batch_size=B * world, dtype='bf16'), **wl['hp']))
-  dev = torch.device('cuda', local_rank)
+  dev = torch.device('cpu') if dry else torch.device('cuda', local_rank)
+  side = 64 if dry else 224
   tr = Trainer(hp, seed=0, device=dev, world_size=world)
-  tr.model.build((224, 224), use_resnet_d=hp.use_resnet_d)
+  tr.model.build((side, side), use_resnet_d=hp.use_resnet_d)
+  dp_info = None
   if world > 1:
-    tr.grad_sync = dp.GradSync(tr.model.arena)
+    tr.grad_sync = dp.GradSync(tr.model.arena, comm_dtype=args.comm_dtype)
+    dp_info = _dp_plan(tr.grad_sync, world)
   g = torch.Generator(device=dev).manual_seed(1 + rank)
   nin = B * 2 if hp.mixup_type == 1 else B
-  images = torch.randint(0, 256, (nin, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8)
+  images = torch.randint(0, 256, (nin, side, side, 3), generator=g, device=dev, dtype=torch.uint8)
   labels = torch.randint(1, 1001, (nin,), generator=g, device=dev, dtype=torch.int32)
   if hp.kd_temp > 0:   # labels = concat(one-hot, teacher logits) (nets/run_loop_classification.py:90-96)
     onehot = torch.nn.functional.one_hot(labels.long(), 1001).float()
@@ -275,10 +353,12 @@ def main():
     return tr.train_step(images, labels, lam1)
 
   def sync():
-    torch.cuda.synchronize()
+    if not dry:
+      torch.cuda.synchronize()
     if world > 1:
       dist.barrier()
-      torch.cuda.synchronize()
+      if not dry:
+        torch.cuda.synchronize()
 
   dominant = None
   for i in range(args.warmup):
@@ -298,25 +378,30 @@ def main():
     ops.set_conv_timer(timer)
 
   sync()
+  calls0 = ops.abi_calls()
   t0 = time.time()
   for _ in range(args.steps):
     rows = step()
   sync()
   el = time.time() - t0
+  abi_calls = (ops.abi_calls() - calls0) / max(args.steps, 1)
   ops.set_conv_timer(None)
   if world > 1:
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
   class_sum = None
-  if not args.no_roofline:   # ONE instrumented step after the timed region: HIP events around every conv and BN-family call
+  INSTR = 3
+  if not args.no_roofline:   # instrumented steps after the timed region: HIP events around every conv and BN-family call
     step()
     ct = ops.ConvTimer(classes=True)
     ops.set_conv_timer(ct)
-    step()
+    for _ in range(INSTR):
+      step()
     torch.cuda.synchronize()
     ops.set_conv_timer(None)
-    class_sum = (ct.summary(), ct.class_summary())
+    class_sum = ({k: (v[0] / INSTR, v[1] / INSTR) for k, v in ct.summary().items()},
+                 {k: (v[0] / INSTR, v[1] / INSTR, v[2] / INSTR) for k, v in ct.class_summary().items()})
     if args.dump_convs and rank == 0:
       rows = sorted(((v[1], k, v[0]) for k, v in class_sum[0].items()), reverse=True)
       with open(args.dump_convs, 'w') as f:
@@ -342,10 +427,15 @@ def main():
     overlap = {'value': round(B * world * args.steps / el2, 2), 'ms_per_step': round(1000.0 * el2 / args.steps, 3),
                'what': 'the same %d steps with weight gradients and the big branch of each BigLittle stage on a second '
                        'HIP stream (the product default; per-kernel durations are then contention-dependent)' % args.steps}
+  if world == 1 and not args.no_gradsync and not args.overlap:
+    dp_info = _gradsync_leg(tr, step, sync, args, 1000.0 * el / args.steps)
   loss = float(tr.cross_entropy())
   if not (loss == loss) or loss > 50:
     raise SystemExit('training diverged (loss=%r): the number would be invalid' % loss)
 
+  if world > 1:       # whatever a native library buffered on stdout (an RCCL banner) goes out BEFORE rank 0's JSON line
+    _flush_c_stdio()
+    dist.barrier()
   if rank == 0:
     out = {
         'metric': 'images/sec %s 224^2 bf16 train' % wl.get('model', 'Assemble-ResNet-50'),
@@ -358,6 +448,7 @@ def main():
         'config': {'workload': wl['desc'], 'per_gpu_batch': B, 'global_batch': B * world, 'image': '224x224x3',
                    'num_classes': 1001, 'parallelism': 'dp%d' % world, 'final_cross_entropy': round(loss, 4)},
     }
+    dominant_obj = None
     if timer is not None:
       n, ms = timer.summary()[dominant]
       fl = conv_flops(dominant)
@@ -369,12 +460,10 @@ def main():
         traffic = pmc.get(kname, {}).get('traffic_bytes')
       except (OSError, ValueError):
         pass
-      out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
-                         'traffic_source': 'profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
-                                           'this command; not measured in this run)' % PMC_FILE,
-                         'kernel': kname,
-                         'launches_timed': n, 'avg_launch_ms': round(ms / n, 4), 'flops_per_launch': fl}
+      dominant_obj = {'kernel': kname, 'achieved': round(ach, 2), 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                      'launches_timed': n, 'avg_launch_ms': round(ms / n, 4), 'flops_per_launch': fl, 'traffic': traffic,
+                      'traffic_source': 'profiles/%s (rocprofv3 --pmc passes over tools/conv_bench.py of this layer)' % PMC_FILE,
+                      'timed': 'HIP events on the launch stream around every launch of this layer over the timed region'}
     try:
       sb = step_bound(args.workload, B)
       ms_step = 1000.0 * el / args.steps
@@ -396,11 +485,42 @@ def main():
           st_obj['bn_class'] = {'ms_per_step': round(tb, 3), 'algorithmic_gb': round(wb / 1e9, 2),
                                 'gbs': round(wb / (tb * 1e-3) / 1e9, 1),
                                 'frac_of_hbm_peak': round(wb / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'calls': nb}
-        st_obj['class_source'] = 'HIP events around every conv / batch-norm-family call of one instrumented step after the timed region'
+        st_obj['class_source'] = 'HIP events around every conv / batch-norm-family call of %d instrumented steps after the timed region' % INSTR
+        cls_traffic = {}
+        try:
+          cls_traffic = json.load(open(os.path.join(ROOT, 'profiles', CLASS_TRAFFIC_FILE)))
+        except (OSError, ValueError):
+          pass
+        c33 = st_obj['conv3x3_class']
+        out['roofline'] = {
+            'bound': 'mfma', 'achieved': c33['tflops'], 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': c33['frac_of_mfma_peak'], 'traffic': cls_traffic.get('conv3x3_class_bytes_per_step'),
+            'kernel': '3x3 convolution class: every 3x3 fprop / input-gradient / weight-gradient launch of a step (%d launches, '
+                      '%.3f ms, %.1f algorithmic GFLOP), time-weighted' % (c33['launches'], c33['ms_per_step'], f33 / 1e9),
+            'traffic_source': 'profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command, '
+                              'tools/profile_round.sh; not measured in this run)' % CLASS_TRAFFIC_FILE,
+            'dominant_layer': dominant_obj}
+        if 'bn_class' in st_obj:
+          bc = st_obj['bn_class']
+          out['roofline']['hbm'] = {'bound': 'hbm', 'achieved': bc['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                    'frac': bc['frac_of_hbm_peak'], 'traffic': cls_traffic.get('bn_class_bytes_per_step'),
+                                    'kernel': 'batch-norm family (statistics finalize, apply, backward reduce / apply, the SK '
+                                              'unit\'s on-the-fly forms): %.2f algorithmic GB in %.3f ms per step' % (
+                                                  bc['algorithmic_gb'], bc['ms_per_step'])}
+      elif dominant_obj is not None:
+        out['roofline'] = dict({'bound': 'mfma', 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s'}, **dominant_obj)
       out['step'] = st_obj
     except Exception as e:   # reporting extras must never lose the measured number
       out['step'] = {'error': repr(e)}
     out['streams'] = 'overlapped (weight-gradient + BigLittle side streams)' if args.overlap else 'single'
+    out['launches'] = {'abi_calls_per_step': round(abi_calls, 1),
+                       'note': 'C-ABI calls of one step in the timed region (one kernel launch each, except: strided input '
+                               'gradients = one per parity class, weight gradients = kernel + slab reduce); the rocprofv3 '
+                               'kernel count per step is in profiles/'}
+    if dp_info is not None:
+      out['dp'] = dp_info
+    if dry:
+      out['data'] = 'DRY RUN on CPU (test double of the C ABI, gloo): control flow only, the value means nothing'
     if overlap is not None:
       out['overlap'] = overlap
     if world == 1 and not args.no_cpu_baseline:
@@ -409,6 +529,7 @@ def main():
       except Exception as e:  # the baseline is a reported extra; never lose the GPU number over it
         out['cpu_baseline'] = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port',
                                'sample': 'failed: %r' % (e,)}
+    _flush_c_stdio()
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.barrier()

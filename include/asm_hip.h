@@ -60,7 +60,8 @@ typedef struct asm_tuning {
   int32_t wgrad_splits;    /* 0: cost model; n > 0: force n pixel splits                                                   */
   int32_t wgrad_linear;    /* 1: linear-address form for 1x1 stride-1 weight gradients                                    */
   int32_t bn_rows;         /* partial rows (= workgroups) of the batch-norm reducers                                       */
-  int32_t conv_sched;      /* main-loop schedule variant of the MFMA convolution kernels (0: default)                     */
+  int32_t conv_sched;      /* LDS-DMA issue of the MFMA conv kernels: 0 per layer (3x3: spread between the MFMA groups,
+                              1x1: all at the head of the step); 1: always spread; 2: never                              */
   int32_t reserved[6];
 } asm_tuning;
 void asm_tuning_defaults(asm_tuning* t);
@@ -237,26 +238,12 @@ int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* relu_mask, in
  *                           CRSK copy [Cin][ldk] (asm_filter_transpose), K = ldk.
  *                           Columns N .. ldo-1 of a padded output row (the classifier's 1001 -> 1008) are written as
  *                           zeros, so whole-row readers (isfinite checks, taps) never see uninitialised memory.
- *   asm_dense_bn_fwd:       ypre = bf16(x . w^T) [M][N]; training-mode batch norm of ypre over the M rows (statistics of
- *                           the bf16-rounded values, moving-statistics update, mean / invstd out), z = bn(ypre) [relu],
- *                           optional packed ReLU mask [M][N/8] -- one launch (== asm_conv2d_fprop + asm_bn_small_fwd).
- *   asm_dense_dgrad_bn_bwd: g = bf16(dy . wt^T) [M][N] (the input gradient of the NEXT dense layer: dy [M][lddy],
- *                           wt = its CRSK copy [N][ldwt], reduction K), then the backward of the batch norm that produced
- *                           that layer's input: dgamma, dbeta, dx [M][N] from g, ypre and the mask (NULL = no ReLU)
- *                           (== asm_conv2d_dgrad + asm_bn_small_bwd).
  *   asm_dense_small_wgrad:  dw[n][k] = sum_m dy[m][n] * x[m][k]  (fp32 [Cout][ldw]; x [M][ldx], dy [M][ldy]).
- * The two batch-norm forms need M <= asm_dense_bn_max_rows() (one workgroup owns every row of 32 channels). */
-int asm_dense_bn_max_rows(void);
+ * (The one-launch dense + batch-norm forms, measured slower than these + asm_bn_small_*, are in asm_hip_debug.h.) */
 int asm_dense_small(const void* p, int ldp, const void* q, int ldq, int M, int N, int K, void* out, int ldo,
                     int out_f32, const void* addend, void* stream);
 int asm_dense_small_wgrad(const void* x, int ldx, const void* dy, int ldy, int M, int Cin, int Cout, float* dw, int ldw,
                           void* stream);
-int asm_dense_bn_fwd(const void* x, int ldx, const void* w, int ldw, int M, int K, int N, const float* gamma,
-                     const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
-                     void* ypre, void* z, float* mean, float* invstd, int relu, uint8_t* relu_mask_out, void* stream);
-int asm_dense_dgrad_bn_bwd(const void* dy, int lddy, const void* wt, int ldwt, int M, int K, int N, const void* ypre,
-                           const uint8_t* relu_mask, const float* gamma, const float* mean, const float* invstd,
-                           float* dgamma, float* dbeta, void* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling / resampling (NHWC bf16)
@@ -319,20 +306,6 @@ int asm_sk_bn_bwd_reduce(const void* dv, const float* att, const void* ds, const
 int asm_sk_bn_bwd_apply(const void* dv, const float* att, const void* ds, const void* y, const float* scale,
                         const float* shift, const float* coefA, const float* coefB, const float* coefC, void* dy,
                         int N, int HW, int F, void* stream);
-/* Factorised form of that reduce: a_b and ds are constant over an image, so
- *   sum dz = sum_n a_b[n] G0[n] + (ds[n]/HW) M0[n],  sum dz*y = sum_n a_b[n] G1[n] + (ds[n]/HW) M1[n]
- * with per-image statistics [N][2][2F] (fp32): mask_stats = (sum_hw [f>0], sum_hw [f>0] y) out of the pooled-sum pass
- * (asm_sk_gap_bn_stats) and grad_stats = (sum_hw [f>0] dV, sum_hw [f>0] dV y) out of the gate-gradient pass
- * (asm_sk_select_bn_bwd_att_stats), both of which read y (and dV) anyway.  asm_sk_bn_bwd_finalize turns them into
- * dgamma, dbeta and the apply coefficients (xhat is affine in y): the reduce pass over the whole tensor disappears. */
-int asm_sk_gap_bn_stats(const void* y, const float* scale, const float* shift, const float* mean, const float* invstd,
-                        void* s, float* mask_stats, int N, int HW, int F, void* stream);
-int asm_sk_select_bn_bwd_att_stats(const void* y, const float* scale, const float* shift, const float* mean,
-                                   const float* invstd, const void* dv, const float* att, void* datt, float* grad_stats,
-                                   int N, int HW, int F, void* stream);
-int asm_sk_bn_bwd_finalize(const float* grad_stats, const float* mask_stats, const float* att, const void* ds, int N,
-                           int HW, int F, const float* gamma, const float* mean, const float* invstd, float* dgamma,
-                           float* dbeta, float* coefA, float* coefB, float* coefC, void* stream);
 /* SE: y = x * sigmoid(e[n][c]);  e float32 [N, C] (pre-sigmoid) */
 int asm_se_scale_fwd(const void* x, const float* e, void* y, int N, int HW, int C, void* stream);
 /* de[n][c] = sigmoid'(e) * sum_hw x*dy (bf16 out) */

@@ -26,6 +26,40 @@ int asm_debug_tr_probe(void* out256_i16, void* stream);
  * plan = {dy-tile rows (32/64/128/256), column-tile width (128/256), tiles_n, tiles_c, pixel splits, pixels per split}. */
 int asm_conv2d_wgrad_plan(const asm_conv_desc* d, int32_t plan[6]);
 
+
+/* ---- measured-slower variants, kept for A/B runs (opt-in on the host: ASM_DENSE_BN=1, ASM_SK_FACTOR=1) ------------------
+ * Not part of the drop-in boundary; DESIGN.md section 5.1 has the numbers (dense + BN in one launch: 27.61 vs 27.40 ms per
+ * step; factorised SK batch-norm reduction: +0.6 ms per step).
+ *   asm_dense_bn_fwd:       ypre = bf16(x . w^T) [M][N]; training-mode batch norm of ypre over the M rows (statistics of
+ *                           the bf16-rounded values, moving-statistics update, mean / invstd out), z = bn(ypre) [relu],
+ *                           optional packed ReLU mask [M][N/8] -- one launch (== asm_dense_small + asm_bn_small_fwd).
+ *   asm_dense_dgrad_bn_bwd: g = bf16(dy . wt^T) [M][N] (the input gradient of the NEXT dense layer: dy [M][lddy],
+ *                           wt = its CRSK copy [N][ldwt], reduction K), then the backward of the batch norm that produced
+ *                           that layer's input: dgamma, dbeta, dx [M][N] from g, ypre and the mask (NULL = no ReLU)
+ *                           (== asm_dense_small + asm_bn_small_bwd).
+ * Both need M <= asm_dense_bn_max_rows() (one workgroup owns every row of 32 channels). */
+int asm_dense_bn_max_rows(void);
+int asm_dense_bn_fwd(const void* x, int ldx, const void* w, int ldw, int M, int K, int N, const float* gamma,
+                     const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                     void* ypre, void* z, float* mean, float* invstd, int relu, uint8_t* relu_mask_out, void* stream);
+int asm_dense_dgrad_bn_bwd(const void* dy, int lddy, const void* wt, int ldwt, int M, int K, int N, const void* ypre,
+                           const uint8_t* relu_mask, const float* gamma, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, void* dx, void* stream);
+/* Factorised form of that reduce: a_b and ds are constant over an image, so
+ *   sum dz = sum_n a_b[n] G0[n] + (ds[n]/HW) M0[n],  sum dz*y = sum_n a_b[n] G1[n] + (ds[n]/HW) M1[n]
+ * with per-image statistics [N][2][2F] (fp32): mask_stats = (sum_hw [f>0], sum_hw [f>0] y) out of the pooled-sum pass
+ * (asm_sk_gap_bn_stats) and grad_stats = (sum_hw [f>0] dV, sum_hw [f>0] dV y) out of the gate-gradient pass
+ * (asm_sk_select_bn_bwd_att_stats), both of which read y (and dV) anyway.  asm_sk_bn_bwd_finalize turns them into
+ * dgamma, dbeta and the apply coefficients (xhat is affine in y): the reduce pass over the whole tensor disappears. */
+int asm_sk_gap_bn_stats(const void* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                        void* s, float* mask_stats, int N, int HW, int F, void* stream);
+int asm_sk_select_bn_bwd_att_stats(const void* y, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const void* dv, const float* att, void* datt, float* grad_stats,
+                                   int N, int HW, int F, void* stream);
+int asm_sk_bn_bwd_finalize(const float* grad_stats, const float* mask_stats, const float* att, const void* ds, int N,
+                           int HW, int F, const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                           float* dbeta, float* coefA, float* coefB, float* coefC, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

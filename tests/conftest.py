@@ -30,3 +30,12 @@ def hip_lib():
   assert torch.cuda.is_available(), 'GPU tests need a GPU'
   ops.set_library(None, is_double=False)
   return lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _library_tuning_follows_the_environment():
+  """monkeypatch restores the environment after a test; the library's asm_tuning struct follows it (real library only)"""
+  yield
+  from assembled_cnn_amd import lib, ops
+  if lib._lib is not None and not ops._IS_DOUBLE:
+    ops.refresh_tuning()

@@ -74,6 +74,15 @@ class CpuDouble(object):
   def asm_abi_version(self):
     return 1
 
+  def asm_tuning_defaults(self, t):
+    return None
+
+  def asm_set_tuning(self, t):
+    return 0
+
+  def asm_get_tuning(self, t):
+    return None
+
   # ---- conv ----------------------------------------------------------------------------------------
   def asm_conv2d_stats_blocks(self, d):
     d = _desc(d)

@@ -190,9 +190,9 @@ BIG_WGRAD_SHAPES = [
 def test_wgrad_256x256_kernel_forced_vs_oracle(hip_lib, shape, splits, monkeypatch):
   from assembled_cnn_amd import ops
   from oracle import assembled_oracle as O
-  monkeypatch.setenv('ASM_WGRAD_BIG', '1')
+  util.set_knob(monkeypatch, 'ASM_WGRAD_BIG', '1')
   if splits:
-    monkeypatch.setenv('ASM_WGRAD_SPLITS', str(splits))
+    util.set_knob(monkeypatch, 'ASM_WGRAD_SPLITS', str(splits))
   N, H, W, Cn, K, k, stride = shape
   g = torch.Generator().manual_seed(41)
   x = torch.randn((N, H, W, Cn), generator=g).to(BF)
@@ -210,13 +210,13 @@ def test_wgrad_256x256_kernel_forced_vs_oracle(hip_lib, shape, splits, monkeypat
   r = util.rel_l2(dw.cpu(), gw)
   assert r <= 2e-3, 'wgrad<256,256> rel_l2 %.3e (plan %s)' % (r, plan)
   # the same call with the 128-wide kernels gives the same numbers up to summation order
-  monkeypatch.setenv('ASM_WGRAD_BIG', '0')
+  util.set_knob(monkeypatch, 'ASM_WGRAD_BIG', '0')
   dw0 = torch.empty_like(dw)
   ops.conv_wgrad(d, x.cuda(), dy.cuda(), dw0)
   assert _plan(hip_lib, d)[1] == 128
   assert util.rel_l2(dw, dw0) <= 1e-4
   # deterministic (fixed-order slab reduce)
-  monkeypatch.setenv('ASM_WGRAD_BIG', '1')
+  util.set_knob(monkeypatch, 'ASM_WGRAD_BIG', '1')
   dw1 = torch.empty_like(dw)
   ops.conv_wgrad(d, x.cuda(), dy.cuda(), dw1)
   assert torch.equal(dw, dw1)
@@ -245,7 +245,7 @@ def test_wgrad_256x256_kernel_on_its_own_plan_vs_direct(hip_lib):
 def test_bn_partial_row_cap_is_a_per_call_knob(hip_lib, rows, monkeypatch):
   """ASM_BN_ROWS is read on every call: the same reduction through three partial-row tilings."""
   from assembled_cnn_amd import ops
-  monkeypatch.setenv('ASM_BN_ROWS', str(rows))
+  util.set_knob(monkeypatch, 'ASM_BN_ROWS', str(rows))
   M, Cn = 50176, 64
   g = torch.Generator(device='cuda').manual_seed(9)
   x = (torch.randn((M, Cn), generator=g, device='cuda') * 2 + 0.5).to(BF)
@@ -268,8 +268,8 @@ def test_igemm_variants_are_per_call_knobs(hip_lib, v2, parity, monkeypatch):
   ops.filter_transpose(w, wt, K, k, k, Cn)
   d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
   ref = ops.conv_dgrad(d, dy, wt)
-  monkeypatch.setenv('ASM_IGEMM_V2', str(v2))
-  monkeypatch.setenv('ASM_DGRAD_PARITY', str(parity))
+  util.set_knob(monkeypatch, 'ASM_IGEMM_V2', str(v2))
+  util.set_knob(monkeypatch, 'ASM_DGRAD_PARITY', str(parity))
   out = ops.conv_dgrad(d, dy, wt)
   dxn = torch.empty_like(ref)
   st = torch.cuda.current_stream().cuda_stream
@@ -285,7 +285,7 @@ def test_wgrad_halo_kernel_forced_vs_oracle(hip_lib, shape, monkeypatch):
   its own layer: against the oracle's autograd and bit-reproducible."""
   from assembled_cnn_amd import ops
   from oracle import assembled_oracle as O
-  monkeypatch.setenv('ASM_WGRAD_HALO', '2')
+  util.set_knob(monkeypatch, 'ASM_WGRAD_HALO', '2')
   N, H, W, Cn, K = shape
   g = torch.Generator().manual_seed(43)
   x = torch.randn((N, H, W, Cn), generator=g).to(BF)
@@ -303,7 +303,7 @@ def test_wgrad_halo_kernel_forced_vs_oracle(hip_lib, shape, monkeypatch):
   dw1 = torch.empty_like(dw)
   ops.conv_wgrad(d, x.cuda(), dy.cuda(), dw1)
   assert torch.equal(dw, dw1)
-  monkeypatch.setenv('ASM_WGRAD_HALO', '0')
+  util.set_knob(monkeypatch, 'ASM_WGRAD_HALO', '0')
   dw0 = torch.empty_like(dw)
   ops.conv_wgrad(d, x.cuda(), dy.cuda(), dw0)
   assert _plan(hip_lib, d)[1] != -1 and util.rel_l2(dw, dw0) <= 1e-4

@@ -65,7 +65,7 @@ SHAPES = [
 @pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
 def test_fprop_dgrad_wgrad_vs_oracle(hip_lib, shape, mode, monkeypatch):
   from assembled_cnn_amd import ops
-  monkeypatch.setenv('ASM_IGEMM_MODE', str(mode))   # global->LDS staging flavour of the igemm kernel
+  util.set_knob(monkeypatch, 'ASM_IGEMM_MODE', str(mode))   # global->LDS staging flavour of the igemm kernel
   monkeypatch.setenv('ASM_DENSE_SMALL', '0')        # [N,1,1,C] shapes too: this test is about the convolution kernels
   N, H, W, Cn, K, k, stride = shape
   x = _rand((N, H, W, Cn), 1)
@@ -256,9 +256,9 @@ def test_big_tile_variants(hip_lib, shape, tile, mode, monkeypatch):
   """the 256x128 / 256x256 (8-wave) tile configurations, forced through ASM_IGEMM_TILE, incl. ragged M, masked N
   and the two-partials-per-tile statistics epilogue."""
   from assembled_cnn_amd import ops
-  monkeypatch.setenv('ASM_IGEMM_TILE', str(tile))
+  util.set_knob(monkeypatch, 'ASM_IGEMM_TILE', str(tile))
   if mode:
-    monkeypatch.setenv('ASM_IGEMM_MODE', str(mode))
+    util.set_knob(monkeypatch, 'ASM_IGEMM_MODE', str(mode))
   N, H, W, Cn, K, k, stride = shape
   x = _rand((N, H, W, Cn), 21)
   w = _rand((K, k, k, Cn), 22, scale=(1.0 / (k * k * Cn)) ** 0.5)
@@ -277,7 +277,7 @@ def test_big_tile_variants(hip_lib, shape, tile, mode, monkeypatch):
   wt = torch.zeros((Cn, k, k, K), dtype=BF, device='cuda')
   ops.filter_transpose(w.cuda(), wt, K, k, k, Cn)
   dx = ops.conv_dgrad(d, dy.cuda(), wt)
-  monkeypatch.setenv('ASM_IGEMM_TILE', '1')
+  util.set_knob(monkeypatch, 'ASM_IGEMM_TILE', '1')
   dx1 = ops.conv_dgrad(d, dy.cuda(), wt)
   y1, _ = ops.conv_fprop(d, x.cuda(), w.cuda())
   # same K-order of accumulation in every tile config -> identical bits
@@ -323,7 +323,7 @@ def test_dgrad_with_masked_addend(hip_lib, shape, pfa, monkeypatch):
   product: the lazily masked shortcut gradient is the same gradient.  Both epilogue variants (addend fetched inside the
   store passes / prefetched ahead of them, ASM_IGEMM_PFA) and in-place accumulation (dx == addend)."""
   from assembled_cnn_amd import ops
-  monkeypatch.setenv('ASM_IGEMM_PFA', str(pfa))
+  util.set_knob(monkeypatch, 'ASM_IGEMM_PFA', str(pfa))
   N, H, W, Cn, K, k, stride = shape
   g = torch.Generator(device='cuda').manual_seed(17)
   d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
@@ -339,7 +339,7 @@ def test_dgrad_with_masked_addend(hip_lib, shape, pfa, monkeypatch):
   a = ops.conv_dgrad(d, dy, wt, addend, mask)
   b = ops.conv_dgrad(d, dy, wt, masked)
   assert torch.equal(a, b)
-  monkeypatch.setenv('ASM_IGEMM_PFA', str(1 - pfa))
+  util.set_knob(monkeypatch, 'ASM_IGEMM_PFA', str(1 - pfa))
   assert torch.equal(a, ops.conv_dgrad(d, dy, wt, addend, mask)), 'the two epilogue variants must agree bit for bit'
   # in-place fan-in accumulation through the C ABI: dx aliases the addend
   from assembled_cnn_amd.ops import L, _ptr, _stream, check

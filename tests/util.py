@@ -59,3 +59,10 @@ def perturb_bn_state(om, seed):
       om.vars.state[name] = torch.from_numpy(rng.normal(0, 0.1, size=tuple(t.shape))).to(t.dtype)
     else:
       om.vars.state[name] = torch.from_numpy(rng.uniform(0.5, 1.5, size=tuple(t.shape))).to(t.dtype)
+
+
+def set_knob(monkeypatch, name: str, value):
+  """set an ASM_* kernel-selection variable for this test and hand it to the library (which reads no environment)"""
+  from assembled_cnn_amd import ops
+  monkeypatch.setenv(name, str(value))
+  ops.refresh_tuning()

@@ -9,7 +9,7 @@ WHAT="${*:-stats}"
 REPO=$(pwd)
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-roofline"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-roofline --no-gradsync"
 for w in $WHAT; do
   case $w in
     stats)
@@ -21,7 +21,7 @@ for w in $WHAT; do
       for c in FETCH_SIZE WRITE_SIZE; do
         rocprofv3 --pmc $c -d $REPO/gpurun_out/pmc_${TAG}_$c -o p --output-format csv -- $BENCH --steps 2 --warmup 1 > $REPO/gpurun_out/pmc_${TAG}_$c.log 2>&1
       done
-      python $REPO/tools/pmc_traffic_step.py $REPO/gpurun_out/pmc_${TAG}_FETCH_SIZE $REPO/gpurun_out/pmc_${TAG}_WRITE_SIZE 3 > $REPO/gpurun_out/${TAG}_step_hbm_traffic.md
+      python $REPO/tools/pmc_traffic_step.py $REPO/gpurun_out/pmc_${TAG}_FETCH_SIZE $REPO/gpurun_out/pmc_${TAG}_WRITE_SIZE 3 $REPO/gpurun_out/${TAG}_step_class_traffic.json > $REPO/gpurun_out/${TAG}_step_hbm_traffic.md
       ;;
     dominant)
       for c in FETCH_SIZE WRITE_SIZE; do
