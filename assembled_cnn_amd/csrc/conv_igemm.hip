@@ -618,8 +618,10 @@ struct Cfg2 {
   static_assert(LDS <= 160 * 1024, "lds");
 };
 
-// SCHED 1 (asm_tuning.conv_sched = 1): the LDS-DMA pieces of step k+1 are issued IN BETWEEN the MFMA groups of step k
-// instead of all at once right after the barrier.  Every wave comes out of the barrier at the same moment, and one piece
+// SCHED 1: the LDS-DMA pieces of step k+1 are issued IN BETWEEN the MFMA groups of step k instead of all at once right
+// after the barrier (default for the 3x3 layers, asm_tuning.conv_sched).  Also tried (round 3, same box, conv_bench): pinning
+// the fragment reads of group kk+1 at the head of group kk with sched_barrier(0) -- 2.62 vs 2.55 ms over the 12 heaviest
+// shapes, slower than the compiler's own interleave, dropped.  Every wave comes out of the barrier at the same moment, and one piece
 // costs its wave 60-180 issue cycles (v_readfirstlane + M0 write + the buffer_load itself): with 8 pieces up front both waves
 // of a SIMD sit in their issue phase together and the matrix pipe idles for that long at the head of every step.
 template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS, bool PFA = false, bool POOL = false,

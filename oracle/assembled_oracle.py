@@ -738,15 +738,16 @@ class Model(object):
       w = vs.conv_kernel(1, x.shape[1], self.embedding_size, layer_name='embedding_dense')
       ctx.note_conv(x)
       e = ctx.q(_conv_raw(x, ctx.qw(w), 1, 1))
-      e = batch_norm(ctx, e, training, momentum=bnm, layer_name='embedding_dense_batch_normalization')
+      # :591-592 applies tf.nn.relu to the squeezed embedding unless it is returned; relu commutes with the storage
+      # rounding, so it is folded into the batch-norm group here (one recorded group output, as the product computes it)
+      e = batch_norm(ctx, e, training, momentum=bnm, layer_name='embedding_dense_batch_normalization',
+                     relu=not return_embedding)
       squeezed = e.flatten(1)
     else:
       squeezed = x.flatten(1)
     if return_embedding:
       self.taps = ctx.taps
       return squeezed
-    if self.embedding_size > 0:
-      squeezed = ctx.q(F.relu(squeezed))
     kernel, bias = vs.dense_vars(squeezed.shape[1], self.num_classes, self.dense_bias_init)
     logits = squeezed @ ctx.qw(kernel) + bias  # fp32 logits (nets/run_loop_classification.py:123)
     ctx.tap('final_dense', logits)

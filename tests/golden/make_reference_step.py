@@ -199,7 +199,7 @@ def run_preprocessing(tf):
     tf.set_compute_dtype(torch.float64)
 
 
-def generate():
+def generate(only=None):
   T.install_import_hooks()
   import tensorflow as tf
   assert 'tf_shim' in tf.__file__, tf.__file__
@@ -207,6 +207,8 @@ def generate():
   from nets import run_loop_classification as run_loop
   out = {'_generator': 'tests/golden/make_reference_step.py', '_reference': T.REF, 'steps': {}}
   for name in STEP_CONFIGS:
+    if only is not None and name not in only:
+      continue
     out['steps'][name] = run_step_config(tf, model_fns, run_loop, name)
     s0 = out['steps'][name]['steps'][0]
     print(name, 'loss %.6f' % s0['loss'], 'ce %.6f' % s0['cross_entropy'], out['steps'][name]['n_grads'], 'gradients')
@@ -218,9 +220,14 @@ def generate():
 
 
 def main():
-  out = generate()
+  only = None
+  if '--only' in sys.argv:       # --check --only r50v1-ls,...: regenerate and compare a subset of the step configurations
+    only = sys.argv[sys.argv.index('--only') + 1].split(',')
+  out = generate(only)
   if '--check' in sys.argv:
     old = json.load(open(OUT))
+    if only is not None:
+      old['steps'] = {k: v for k, v in old['steps'].items() if k in only}
     a, b = json.dumps(out, sort_keys=True), json.dumps(old, sort_keys=True)
     assert a == b, 'regenerated fixture differs from the committed file'
     print('fixture reproduces')

@@ -29,6 +29,10 @@ CONFIGS = {
     'a-r152': dict(resnet_size=152, resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
                    anti_alias_filter_size=3, bl_alpha=1, bl_beta=2),
     'se-proj': dict(resnet_size=50, use_se_block=True, anti_alias_type='proj', anti_alias_filter_size=3),
+    # the two off-recipe configurations of tests/golden/reference_taps.json: GeM pooling + embedding head on ResNet-101,
+    # and no_downsample + flatten pooling + the sigmoid loss's dense-bias initialisation
+    'r101v1-gem-emb': dict(resnet_size=101, pool_type='gem', embedding_size=128),
+    'r50v1-nodown-flatten-sigmoid': dict(resnet_size=50, no_downsample=True, pool_type='flatten', loss_type='sigmoid'),
 }
 
 
