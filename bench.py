@@ -9,10 +9,10 @@ One "step" = one pass of the whole hot path over one synthetic minibatch already
 mean-subtract(+mixup) -> forward -> softmax-CE(+label smoothing) -> backward -> [gradient all-reduce]
 -> momentum-SGD.  Weak scaling: the per-GPU batch is fixed as N grows.  Rank 0 prints ONE JSON line.
 
-The timed region runs every kernel on ONE HIP stream, so that the per-kernel figures below (and the rocprofv3 summaries under
-profiles/, taken from this same command) are properties of the kernels; `overlap` (N = 1) is the rate of the same steps with
-the product's side streams on (weight gradients beside the dgrad chain, the big branch of a BigLittle stage beside the
-little one), where kernels share the CUs and individual durations depend on their neighbours.
+The timed region is the product as it ships: at N = 1 the weight gradients run beside the input-gradient chain and (forward)
+the big branch of each BigLittle stage beside the little one, on side streams.  Kernels then share the CUs, so the per-class
+figures below come from instrumented single-stream steps run after the timed region; `single_stream` is the rate of the same
+steps with every kernel on one stream (--single-stream times that instead).
 
 Extra objects on the line:
   roofline      what BASELINE.json's north_star names: the 3x3-convolution CLASS (every 3x3 fprop, input-gradient and
@@ -276,9 +276,10 @@ def main():
   ap.add_argument('--workload', default='assemble-r50', choices=sorted(WORKLOADS))
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-roofline', action='store_true')
-  ap.add_argument('--overlap', action='store_true',
-                  help='time the step with the weight-gradient / BigLittle side streams on (the product default); '
-                       'without it the timed region is single-stream and the overlapped rate is reported as an extra')
+  ap.add_argument('--single-stream', action='store_true',
+                  help='time the step with every kernel on ONE stream (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0); without it the '
+                       'timed region is the product default (weight gradients at N = 1 and the big branch of a BigLittle '
+                       'stage on side streams) and the single-stream rate is reported as an extra')
   ap.add_argument('--dump-convs', default='', help='write the per-conv-shape HIP-event times of the instrumented step here (markdown)')
   ap.add_argument('--no-gradsync', action='store_true', help='N = 1: skip the extra leg with the gradient exchange attached')
   ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='precision of the exchanged gradient buckets')
@@ -315,11 +316,12 @@ def main():
     from tests.cpu_double import CpuDouble      # test infrastructure, only under --dry-run-cpu
     _ops.set_library(CpuDouble(), is_double=True)
 
-  # The timed region runs every kernel on ONE stream: per-kernel HIP-event durations (the `roofline` and `step` objects)
-  # and the rocprofv3 summaries under profiles/ are then properties of the kernels.  With the side streams on (weight
-  # gradients beside the dgrad chain, the big branch of a BigLittle stage beside the little one) kernels share the CUs and
-  # their individual durations depend on what happens to run next to them; that rate is reported as `overlap`.
-  if not args.overlap:
+  # The timed region is the product as it ships: weight gradients beside the dgrad chain (N = 1; with a gradient exchange
+  # attached they stay on the compute stream, dp.GradSync) and the big branch of a BigLittle stage beside the little one
+  # (forward) on side streams.  Kernels then share the CUs and their individual durations depend on what runs next to
+  # them, so the per-class HIP-event sums (`roofline`, `step`) come from instrumented SINGLE-stream steps after the timed
+  # region, where a duration is a property of the kernel; the single-stream rate is reported as `single_stream`.
+  if args.single_stream:
     os.environ['ASM_WGRAD_STREAM'] = '0'
     os.environ['ASM_BL_STREAMS'] = '0'
   from assembled_cnn_amd import dp, ops
@@ -392,6 +394,24 @@ def main():
     el = float(t)
   class_sum = None
   INSTR = 3
+  single = None
+  if not dry and not args.single_stream and (not args.no_roofline or (world == 1 and not args.no_gradsync)):
+    # everything below runs on ONE stream
+    os.environ['ASM_BL_STREAMS'] = '0'
+    tr.model.arena.join_side_stream()
+    tr.model.arena.side_stream = None
+    if world == 1:
+      for _ in range(2):
+        step()
+      sync()
+      t1 = time.time()
+      for _ in range(args.steps):
+        step()
+      sync()
+      el1 = time.time() - t1
+      single = {'value': round(B * world * args.steps / el1, 2), 'ms_per_step': round(1000.0 * el1 / args.steps, 3),
+                'what': 'the same %d steps with every kernel on one HIP stream (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0): the '
+                        'state the per-class HIP-event sums and the rocprofv3 summaries under profiles/ describe' % args.steps}
   if not args.no_roofline:   # instrumented steps after the timed region: HIP events around every conv and BN-family call
     step()
     ct = ops.ConvTimer(classes=True)
@@ -412,23 +432,9 @@ def main():
           by = 2.0 * N_ * (H_ * W_ * C_ + Ho_ * Ho_ * K_) * n
           f.write('| %s | %d %dx%dx%d -> %d, %dx%d/%d | %d | %.4f | %.0f | %.0f |\n' % (
               kind, N_, H_, W_, C_, K_, R_, S_, st_, n, ms, conv_flops(k) * n / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9))
-  overlap = None
-  if world == 1 and not args.overlap and not args.no_roofline:   # the same steps with the side streams on (product default)
-    os.environ['ASM_BL_STREAMS'] = '1'
-    tr.model.arena.enable_side_stream()
-    for _ in range(2):
-      step()
-    sync()
-    t1 = time.time()
-    for _ in range(args.steps):
-      step()
-    sync()
-    el2 = time.time() - t1
-    overlap = {'value': round(B * world * args.steps / el2, 2), 'ms_per_step': round(1000.0 * el2 / args.steps, 3),
-               'what': 'the same %d steps with weight gradients and the big branch of each BigLittle stage on a second '
-                       'HIP stream (the product default; per-kernel durations are then contention-dependent)' % args.steps}
-  if world == 1 and not args.no_gradsync and not args.overlap:
-    dp_info = _gradsync_leg(tr, step, sync, args, 1000.0 * el / args.steps)
+  if world == 1 and not args.no_gradsync and not dry:
+    base_ms = single['ms_per_step'] if single is not None else 1000.0 * el / args.steps
+    dp_info = _gradsync_leg(tr, step, sync, args, base_ms)
   loss = float(tr.cross_entropy())
   if not (loss == loss) or loss > 50:
     raise SystemExit('training diverged (loss=%r): the number would be invalid' % loss)
@@ -512,7 +518,9 @@ def main():
       out['step'] = st_obj
     except Exception as e:   # reporting extras must never lose the measured number
       out['step'] = {'error': repr(e)}
-    out['streams'] = 'overlapped (weight-gradient + BigLittle side streams)' if args.overlap else 'single'
+    out['streams'] = ('single (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0)' if args.single_stream else
+                      'product default: the big branch of each BigLittle stage (forward)%s on a second HIP stream'
+                      % (' and the weight gradients' if world == 1 else ''))
     out['launches'] = {'abi_calls_per_step': round(abi_calls, 1),
                        'note': 'C-ABI calls of one step in the timed region (one kernel launch each, except: strided input '
                                'gradients = one per parity class, weight gradients = kernel + slab reduce); the rocprofv3 '
@@ -521,8 +529,8 @@ def main():
       out['dp'] = dp_info
     if dry:
       out['data'] = 'DRY RUN on CPU (test double of the C ABI, gloo): control flow only, the value means nothing'
-    if overlap is not None:
-      out['overlap'] = overlap
+    if single is not None:
+      out['single_stream'] = single
     if world == 1 and not args.no_cpu_baseline:
       try:
         out['cpu_baseline'] = cpu_baseline(args.workload)
