@@ -49,8 +49,7 @@ class GradSync(object):
     if getattr(arena, 'side_stream', None) is not None:
       # bucket launches are ordered against the compute stream only, so with an exchange attached the weight
       # gradients go back onto the compute stream (nn.ConvKernel.backward checks arena.on_grad / side_stream)
-      arena.join_side_stream()
-      arena.side_stream = None
+      arena.disable_side_stream()
     if comm_dtype not in ('fp32', 'bf16'):
       raise ValueError("comm_dtype must be 'fp32' (the reference's all-reduce precision) or 'bf16'")
     self.arena = arena

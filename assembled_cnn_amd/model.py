@@ -118,7 +118,7 @@ class Model(object):
     # time in same-box A/B runs (round 1: 8330 vs 8190 img/s; round 2: 29.59 / 29.71 vs 29.83 / 29.84 ms).
     # ASM_WGRAD_STREAM=0 keeps everything on the compute stream.  Single-GPU only: dp.GradSync (whose bucket launches are
     # ordered against the compute stream) switches it off when it attaches.
-    if os.environ.get('ASM_WGRAD_STREAM', '1') != '0':
+    if ops.knob('ASM_WGRAD_STREAM', '1') != '0':
       self.arena.enable_side_stream()     # no-op on the CPU test double
 
   def __call__(self, inputs, training, reuse=False, use_resnet_d=False, keep_prob=1.0, return_embedding=False,
@@ -161,14 +161,19 @@ class Model(object):
       raise RuntimeError('no forward pass with a tape to differentiate')
     self._ctx.dlogits = dlogits
     self.arena.release_grads()      # a previous backward that raised mid-block must not leave notifications queued
-    self._ctx.backward()
+    cuda = self.arena.side_stream is not None
+    self.arena.compute_stream = torch.cuda.current_stream() if cuda else None    # looked up once, not per weight gradient
+    try:
+      self._ctx.backward()
+    finally:
+      self.arena.compute_stream = None
     self._ctx = None
     self.arena.join_side_stream()
 
   # -----------------------------------------------------------------------------------------------
   def _branch_stream(self, ctx: Ctx, x: Var):
     """second HIP stream for the big branch of a BigLittle stage (forward pass), or None"""
-    if ctx.dry or x.data is None or not x.data.is_cuda or os.environ.get('ASM_BL_STREAMS', '1') == '0':
+    if ctx.dry or x.data is None or not x.data.is_cuda or ops.knob('ASM_BL_STREAMS', '1') == '0':
       return None
     if getattr(ctx, 'keep_prob', 1.0) < 1.0:
       return None          # DropBlock draws come from one generator in creation order

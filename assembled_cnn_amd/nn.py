@@ -31,7 +31,7 @@ DEFER_BN = os.environ.get('ASM_BN_DEFER', '1') != '0'
 
 def dual_bn_on() -> bool:
   """ASM_BN_DUAL=0: two separate batch-norm backwards for a projection block (A/B runs, tests); read per call"""
-  return os.environ.get('ASM_BN_DUAL', '1') != '0'
+  return ops.knob('ASM_BN_DUAL', '1') != '0'
 
 
 def _round_up(n: int, m: int) -> int:
@@ -78,6 +78,8 @@ class ParamArena(object):
     # on a second HIP stream beside the dgrad -> BN-backward chain: MFMA-bound wgrad blocks and HBM-bound
     # normalisation kernels share the CUs.  None = everything on the compute stream.
     self.side_stream = None
+    self._sides = []
+    self.compute_stream = None       # the stream the running backward pass was started on (set by Model.backward)
 
   def notify_grad(self, name: str):
     """The gradient slot of ``name`` has been enqueued (on the compute stream, or on the weight-gradient stream
@@ -107,12 +109,30 @@ class ParamArena(object):
 
   def enable_side_stream(self):
     if self.w32 is not None and self.w32.is_cuda and self.side_stream is None:
-      self.side_stream = torch.cuda.Stream(device=self.w32.device)
+      # ASM_WGRAD_STREAMS=n: n side streams taken round robin, so that consecutive weight gradients (leaves of the
+      # backward graph, independent of each other) may also overlap each other.  Same box, ms per step: 1 stream 27.09 /
+      # 27.13, 2 streams 26.96 / 26.96, 3 streams 27.07; no side stream 27.40.
+      n = max(1, int(ops.knob('ASM_WGRAD_STREAMS', '2')))
+      self._sides = [torch.cuda.Stream(device=self.w32.device) for _ in range(n)]
+      self._side_rr = 0
+      self.side_stream = self._sides[0]
+
+  def pick_side_stream(self):
+    if self.side_stream is None:
+      return None
+    s = self._sides[self._side_rr % len(self._sides)]
+    self._side_rr += 1
+    return s
 
   def join_side_stream(self):
     """Make the compute stream wait for every weight gradient enqueued so far."""
     if self.side_stream is not None:
-      torch.cuda.current_stream().wait_stream(self.side_stream)
+      for s in self._sides:
+        torch.cuda.current_stream().wait_stream(s)
+
+  def disable_side_stream(self):
+    self.join_side_stream()
+    self.side_stream, self._sides = None, []
 
   def register(self, name, shape, decay, init) -> ParamSpec:
     if self.finalized:
@@ -510,11 +530,18 @@ class ConvKernel(object):
   def wgrad_streamed(self, d, x: torch.Tensor, dy: torch.Tensor):
     """dW into the gradient arena, on the weight-gradient side stream when there is one"""
     a = self.arena
-    side = a.side_stream if a.on_grad is None else None
+    side = a.pick_side_stream() if a.on_grad is None else None
     if side is not None:
-      side.wait_stream(torch.cuda.current_stream())     # x and dy were produced on the compute stream
-      with torch.cuda.stream(side):
-        self._wgrad(d, x, dy)
+      side.wait_stream(a.compute_stream or torch.cuda.current_stream())     # x and dy were produced on the compute stream
+      if self.stem or ops.timer_on():                    # these allocate / record events through torch: its own context
+        with torch.cuda.stream(side):
+          self._wgrad(d, x, dy)
+      else:
+        ops.launch_on(side)
+        try:
+          self._wgrad(d, x, dy)
+        finally:
+          ops.launch_on(None)
       x.record_stream(side)                               # keep the caching allocator from recycling them early
       dy.record_stream(side)
     else:
@@ -755,7 +782,7 @@ class SKUnit(object):
     # select, their backward twins), so the 2F-channel normalised tensor, its ReLU mask and the gradient df are never
     # written (csrc/sk_fused.hip).  ASM_SK_FUSED=0 keeps the materialising path (A/B runs, inference uses it too:
     # there the conv epilogue already emits f).
-    if ctx.training and not ctx.dry and 2 * self.filters <= 2048 and os.environ.get('ASM_SK_FUSED', '1') != '0':
+    if ctx.training and not ctx.dry and 2 * self.filters <= 2048 and ops.knob('ASM_SK_FUSED', '1') != '0':
       return self._call_fused(ctx, x, stride)
     F_ = self.filters
     f = conv_bn(ctx, x, self.conv, self.bn, stride, relu=True)
@@ -804,7 +831,7 @@ class SKUnit(object):
     # OFF by default: the two per-image passes are latency-bound (one workgroup per image, 3.4 TB/s), the 32 extra
     # accumulators slow them by more than the removed reduce pass costs (28.98 vs 28.37 ms per step, same box).
     # ASM_SK_FACTOR=1 turns it on.
-    factor = ctx.tape is not None and os.environ.get('ASM_SK_FACTOR', '0') == '1'
+    factor = ctx.tape is not None and ops.knob('ASM_SK_FACTOR', '0') == '1'
     if factor:
       s_t, mask_stats = ops.sk_gap_bn(y, scale, shift, F_, mean, invstd)
       s = Var(s_t)
@@ -902,7 +929,7 @@ def avg_pool(ctx: Ctx, x: Var, k: int, stride: int, pad: int, count_valid: bool)
       if y.grad is None:
         raise RuntimeError('avg_pool backward: no gradient reached this layer')
       if (x.needs_grad and x.pool_grad is None and stride in (1, 2) and stride <= k <= 2 * stride and
-          os.environ.get('ASM_POOL_FUSE', '1') != '0'):
+          ops.knob('ASM_POOL_FUSE', '1') != '0'):
         # leave the contribution in pooled form: the block's first 1x1 convolution gathers it in its input-gradient
         # epilogue (its backward runs after this one: model._bottleneck orders the tape that way)
         x.pool_grad = (y.grad, k, stride, pad, count_valid)

@@ -39,9 +39,23 @@ def abi_calls() -> int:
   return _lib.CALLS[0]
 
 
+_KNOBS = {}
+
+
+def knob(name: str, default: str) -> str:
+  """An ASM_* host-side switch.  Read from the environment ONCE (a training step asks ~1500 times: os.environ.get was
+  2 ms of host time per step) and again after refresh_tuning()."""
+  v = _KNOBS.get(name)
+  if v is None:
+    v = _KNOBS[name] = os.environ.get(name, default)
+  return v
+
+
 def refresh_tuning():
-  """Re-read the ASM_* kernel-selection variables of THIS process and hand them to the library (asm_set_tuning).  The
-  library reads no environment itself; lib.load() does this once, tests / A/B tools call it after changing a knob."""
+  """Re-read the ASM_* variables of THIS process: the host-side switches (knob) and the kernel-selection ones, which are
+  handed to the library (asm_set_tuning).  The library reads no environment itself; lib.load() does this once, tests /
+  A/B tools call it after changing a variable."""
+  _KNOBS.clear()
   if _IS_DOUBLE:
     return None
   return _lib.apply_env_tuning(L())
@@ -57,9 +71,31 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
   return t.data_ptr()
 
 
+# torch.cuda.current_stream() builds a Stream object through four Python layers (~8 us; ~1200 calls per training step);
+# the raw handle of the current stream is one C call away
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_CUR_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
+_STREAM_OVERRIDE = None
+
+
+def launch_on(stream: Optional["torch.cuda.Stream"]):
+  """Every following C-ABI call goes to ``stream`` instead of torch's current stream (None = back to the current stream).
+  For launch-only regions -- nothing inside may allocate through torch, whose caching allocator keys blocks by ITS current
+  stream: the weight-gradient side stream uses it instead of a ``with torch.cuda.stream(...)`` block (~15 us of host time
+  per use, 117 uses per step)."""
+  global _STREAM_OVERRIDE
+  _STREAM_OVERRIDE = None if stream is None else stream.cuda_stream
+
+
 def _stream() -> int:
   if _IS_DOUBLE:
     return 0
+  if _STREAM_OVERRIDE is not None:
+    return _STREAM_OVERRIDE
+  if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+    return _RAW_STREAM(_CUR_DEVICE())
   return torch.cuda.current_stream().cuda_stream
 
 
@@ -148,13 +184,17 @@ def set_conv_timer(t: Optional[ConvTimer]):
   _TIMER = t
 
 
+def timer_on() -> bool:
+  return _TIMER is not None
+
+
 def _bn_ev(nbytes):
   return _TIMER.start_class('bn', nbytes) if (_TIMER is not None and _TIMER.classes) else None
 
 
 def dense_small_on() -> bool:
   """ASM_DENSE_SMALL=0 keeps the [N,1,1,C] layers on the implicit-GEMM convolution (A/B runs, tests); read per call."""
-  return os.environ.get('ASM_DENSE_SMALL', '1') != '0'
+  return knob('ASM_DENSE_SMALL', '1') != '0'
 
 
 def _is_dense(d: ConvDesc) -> bool:
@@ -170,7 +210,7 @@ def dense_bn_ok(M: int, K: int, N: int) -> bool:
   OPT-IN (ASM_DENSE_BN=1): measured 0.2 ms per step SLOWER than dense_small + bn_small (27.61 vs 27.40 ms, same box) -- one
   CU has to pull the whole [256 x K] operand through its own L1, and the batch-norm phases are a chain of barriers."""
   global _DENSE_BN_ROWS
-  if not dense_small_on() or os.environ.get('ASM_DENSE_BN', '0') != '1':
+  if not dense_small_on() or knob('ASM_DENSE_BN', '0') != '1':
     return False
   if _DENSE_BN_ROWS is None:
     _DENSE_BN_ROWS = int(L().asm_dense_bn_max_rows())
@@ -240,9 +280,9 @@ def conv_fprop_bn(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, scale, shift, r
 
 def dgrad_pool_ok(d: ConvDesc) -> bool:
   """can asm_conv2d_dgrad_pooled take this layer (1x1, stride 1, on the igemm2 path)?  ASM_POOL_FUSE=0: never"""
-  return (os.environ.get('ASM_POOL_FUSE', '1') != '0' and d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0
-          and d.C % 8 == 0 and d.K % 32 == 0 and not _is_dense(d) and os.environ.get('ASM_IGEMM_V2', '1') != '0'
-          and os.environ.get('ASM_IGEMM_MODE', '0') in ('', '0'))
+  return (knob('ASM_POOL_FUSE', '1') != '0' and d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0
+          and d.C % 8 == 0 and d.K % 32 == 0 and not _is_dense(d) and knob('ASM_IGEMM_V2', '1') != '0'
+          and knob('ASM_IGEMM_MODE', '0') in ('', '0'))
 
 
 def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional[torch.Tensor] = None,
@@ -274,6 +314,7 @@ def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional
 
 
 _ws_cache = {}
+_ws_retired = []
 
 
 def _workspace(nbytes: int, like: torch.Tensor) -> Optional[torch.Tensor]:
@@ -284,6 +325,10 @@ def _workspace(nbytes: int, like: torch.Tensor) -> Optional[torch.Tensor]:
   key = (str(like.device), _stream())
   buf = _ws_cache.get(key)
   if buf is None or buf.numel() < nbytes:
+    if buf is not None:
+      # Outgrown buffers are kept, not freed: under launch_on() the caching allocator does not know which stream still
+      # reads the old one (it would recycle it for the stream that allocated it).  A handful per process, at start-up.
+      _ws_retired.append(buf)
     buf = torch.empty((nbytes,), dtype=torch.uint8, device=like.device)
     _ws_cache[key] = buf
   return buf

@@ -176,6 +176,7 @@ class Trainer(object):
     self.grad_sync = grad_sync
     self.world_size = world_size
     self.last = {}
+    self._graph = self._static = self._graph_out = None
 
   # -----------------------------------------------------------------------------------------------
   def prepare_inputs(self, images, labels, lam1=None, lam2=None):
@@ -225,6 +226,13 @@ class Trainer(object):
   # -----------------------------------------------------------------------------------------------
   def train_step(self, images, labels, lam1=None, lam2=None, lr: Optional[float] = None,
                  dropblock_uniforms=None):
+    if self._graph is not None and dropblock_uniforms is None:
+      return self._replay(images, labels, lam1, lam2, lr)
+    loss_rows, loss_scale, keep_prob = self._forward_backward(images, labels, lam1, lam2, dropblock_uniforms)
+    return self._apply(loss_rows, loss_scale, keep_prob, lr)
+
+  def _forward_backward(self, images, labels, lam1, lam2, dropblock_uniforms=None):
+    """Everything of a step that does not depend on the step number: inputs -> loss rows, gradients in the arena."""
     p = self.p
     m = self.model
     x, onehot, teacher = self.prepare_inputs(images, labels, lam1, lam2)
@@ -233,7 +241,6 @@ class Trainer(object):
     m(x, True, use_resnet_d=p.use_resnet_d, prepadded=True, keep_prob=keep_prob,
       dropblock_uniforms=dropblock_uniforms)
     loss_scale = p.get_loss_scale()
-    sig = None
     if p.cls_loss_type == 'softmax':      # losses/cls_losses.py:27-33 (+ KD, run_loop_classification.py:156-162)
       loss_rows, dlogits = ops.softmax_ce(m.logits_padded, m.ldc, onehot, teacher, B, p.num_classes,
                                           p.label_smoothing, p.kd_temp, loss_scale, m.ldc)
@@ -245,7 +252,12 @@ class Trainer(object):
     else:
       raise AssertionError('cross_entropy is None')   # losses/cls_losses.py:40
     m.backward(dlogits)
-    a = m.arena
+    return loss_rows, loss_scale, keep_prob
+
+  def _apply(self, loss_rows, loss_scale, keep_prob, lr=None):
+    """[gradient exchange ->] momentum-SGD at the step's learning rate (a host scalar: outside any captured graph)."""
+    p = self.p
+    a = self.model.arena
     if self.grad_sync is not None:
       self.grad_sync(a.g32)
     lr = self.lr_fn(self.global_step) if lr is None else lr
@@ -259,6 +271,45 @@ class Trainer(object):
     self.global_step += 1
     self.last = {'loss_rows': loss_rows, 'lr': lr, 'keep_prob': keep_prob}
     return loss_rows
+
+  # ---- the step as ONE HIP graph -------------------------------------------------------------------------------------
+  def capture(self, images, labels, lam1=None, lam2=None, warmup: int = 2):
+    """Record inputs -> forward -> loss -> backward (every launch of it, side streams included) into a HIP graph over
+    static input buffers; train_step then copies its arguments into those buffers, replays the graph (one host call
+    instead of ~850) and runs the exchange + optimiser as usual.  The step enqueues in ~18 ms of host time against ~27 ms of
+    GPU time on a 5 GHz host: a slower host, or eight ranks sharing one, makes the eager step host-bound.
+    Not available with DropBlock (its keep_prob and random draws change per step) or an attached gradient exchange
+    (bucket launches are interleaved with the backward by the host)."""
+    if self._graph is not None:
+      raise RuntimeError('a step graph is already captured: release_graph() first')
+    if self.keep_prob_fn is not None:
+      raise NotImplementedError('DropBlock changes keep_prob and its draws every step: the step cannot be one static graph')
+    if self.grad_sync is not None:
+      raise NotImplementedError('with a gradient exchange attached the bucket launches are host-driven: eager steps only')
+    if not images.is_cuda:
+      raise RuntimeError('capture needs device tensors')
+    static = [t.clone() if t is not None else None for t in (images, labels, lam1, lam2)]
+    for _ in range(warmup):     # one-time initialisation (workspaces, kernel attributes, side streams) stays out of the graph
+      self.train_step(images, labels, lam1, lam2)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+      out = self._forward_backward(*static)
+    self._graph, self._static, self._graph_out = g, static, out
+    return self
+
+  def release_graph(self):
+    self._graph = self._static = self._graph_out = None
+
+  def _replay(self, images, labels, lam1, lam2, lr):
+    for dst, src in zip(self._static, (images, labels, lam1, lam2)):
+      if (dst is None) != (src is None) or (dst is not None and (dst.shape != src.shape or dst.dtype != src.dtype)):
+        raise ValueError('the captured step takes inputs of the shapes / dtypes it was captured with')
+      if dst is not None and dst.data_ptr() != src.data_ptr():
+        dst.copy_(src, non_blocking=True)
+    self._graph.replay()
+    loss_rows, loss_scale, keep_prob = self._graph_out
+    return self._apply(loss_rows, loss_scale, keep_prob, lr)
 
   def cross_entropy(self) -> torch.Tensor:
     """mean over the batch of (CE + KD) of the last step (device scalar)."""

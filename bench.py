@@ -19,7 +19,7 @@ Extra objects on the line:
                 weight-gradient launch of a step, time-weighted) against the gfx950 dense bf16 MFMA peak (2.5 PFLOP/s,
                 MI355X_MICROARCH.md): achieved = the class's algorithmic FLOPs / its HIP-event time.  `dominant_layer` keeps
                 the single heaviest conv launch (picked in a warm-up step, timed with HIP events on the launch stream over
-                the timed region), `hbm` the batch-norm family against the HBM peak; `traffic` = HBM bytes per step of the
+                the K single-stream steps), `hbm` the batch-norm family against the HBM peak; `traffic` = HBM bytes per step of the
                 class from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes OF THIS COMMAND (profiles/, tools/profile_round.sh).
   dp            N = 1: the step with the gradient exchange attached to an RCCL group of ONE (real bucket launches, stream
                 waits, casts; no link traffic) and `exchange_ms_exposed` = that step - the plain step.  N > 1: the bucket
@@ -230,7 +230,7 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
   (bf16) cast is real, only the link traffic is missing.  exchange_ms_exposed = step with the exchange - step without."""
   import socket
   import torch.distributed as dist
-  from assembled_cnn_amd import dp
+  from assembled_cnn_amd import dp, ops
   try:
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -240,6 +240,7 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
       os.environ['NCCL_DEBUG'] = 'WARN'     # no version banner on stdout next to the one JSON line
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
     os.environ['ASM_BL_STREAMS'] = '0'      # compared with the single-stream step (GradSync hands the weight-gradient stream back)
+    ops.refresh_tuning()
     gs = dp.GradSync(tr.model.arena, comm_dtype=args.comm_dtype)
     tr.grad_sync = gs
     for _ in range(2):
@@ -375,7 +376,7 @@ def main():
       summ = timer.summary()
       dominant = max(summ, key=lambda k: summ[k][1]) if summ else None
   timer = None
-  if dominant is not None:
+  if dominant is not None and args.single_stream:
     timer = ops.ConvTimer(only=dominant)
     ops.set_conv_timer(timer)
 
@@ -398,17 +399,21 @@ def main():
   if not dry and not args.single_stream and (not args.no_roofline or (world == 1 and not args.no_gradsync)):
     # everything below runs on ONE stream
     os.environ['ASM_BL_STREAMS'] = '0'
-    tr.model.arena.join_side_stream()
-    tr.model.arena.side_stream = None
+    ops.refresh_tuning()
+    tr.model.arena.disable_side_stream()
     if world == 1:
       for _ in range(2):
         step()
+      if dominant is not None:      # the heaviest layer's launches, HIP events on the launch stream over this leg
+        timer = ops.ConvTimer(only=dominant)
+        ops.set_conv_timer(timer)
       sync()
       t1 = time.time()
       for _ in range(args.steps):
         step()
       sync()
       el1 = time.time() - t1
+      ops.set_conv_timer(None)
       single = {'value': round(B * world * args.steps / el1, 2), 'ms_per_step': round(1000.0 * el1 / args.steps, 3),
                 'what': 'the same %d steps with every kernel on one HIP stream (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0): the '
                         'state the per-class HIP-event sums and the rocprofv3 summaries under profiles/ describe' % args.steps}
@@ -469,7 +474,10 @@ def main():
       dominant_obj = {'kernel': kname, 'achieved': round(ach, 2), 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                       'launches_timed': n, 'avg_launch_ms': round(ms / n, 4), 'flops_per_launch': fl, 'traffic': traffic,
                       'traffic_source': 'profiles/%s (rocprofv3 --pmc passes over tools/conv_bench.py of this layer)' % PMC_FILE,
-                      'timed': 'HIP events on the launch stream around every launch of this layer over the timed region'}
+                      'timed': 'HIP events on the launch stream around every launch of this layer over the %d steps of the '
+                               '%s' % (args.steps, 'timed region (single stream)' if args.single_stream else
+                                       'single-stream leg (`single_stream`): beside another stream\'s kernels a duration '
+                                       'is not a property of the kernel')}
     try:
       sb = step_bound(args.workload, B)
       ms_step = 1000.0 * el / args.steps

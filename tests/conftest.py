@@ -34,8 +34,10 @@ def hip_lib():
 
 @pytest.fixture(autouse=True)
 def _library_tuning_follows_the_environment():
-  """monkeypatch restores the environment after a test; the library's asm_tuning struct follows it (real library only)"""
+  """monkeypatch restores the environment after a test; the cached host-side switches and the library's asm_tuning struct
+  follow it"""
   yield
   from assembled_cnn_amd import lib, ops
+  ops._KNOBS.clear()           # the host-side switches are cached per process (ops.knob)
   if lib._lib is not None and not ops._IS_DOUBLE:
     ops.refresh_tuning()

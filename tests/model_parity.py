@@ -351,6 +351,7 @@ def check_teacher_forced_backward(name, device, batch, size, label_smoothing=0.1
   for k, v in (env or {}).items():
     old_env[k] = os.environ.get(k)
     os.environ[k] = v
+  ops.refresh_tuning()
   try:
     om, pm = make_pair(name, device, batch, size)
     d = uses_d(name)
@@ -584,6 +585,7 @@ def check_teacher_forced_backward(name, device, batch, size, label_smoothing=0.1
         os.environ.pop(k, None)
       else:
         os.environ[k] = v
+    ops.refresh_tuning()
 
 
 def check_train_forward_at_size(name, device, n_in, size, mixup_type=0, label_smoothing=0.0, kd_temp=0.0, logits_tol=6e-2,

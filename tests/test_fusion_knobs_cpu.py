@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from tests import model_parity as MP
+from tests import util
 
 
 def _run(monkeypatch, fused: bool, name='a-r50-d', batch=2, size=64, gatherable=True):
@@ -14,8 +15,8 @@ def _run(monkeypatch, fused: bool, name='a-r50-d', batch=2, size=64, gatherable=
   if not gatherable:      # the pooled gradient stays pending until somebody reads .grad, which scatters it
     monkeypatch.setattr(ops, 'dgrad_pool_ok', lambda d: False)
   for k in ('ASM_POOL_FUSE', 'ASM_BN_DUAL', 'ASM_DENSE_SMALL', 'ASM_SK_FUSED'):
-    monkeypatch.setenv(k, '1' if fused else '0')
-  monkeypatch.setenv('ASM_DENSE_BN', '1' if fused else '0')
+    util.set_knob(monkeypatch, k, '1' if fused else '0')
+  util.set_knob(monkeypatch, 'ASM_DENSE_BN', '1' if fused else '0')
   monkeypatch.setattr(nn, 'DEFER_BN', fused)
   monkeypatch.setattr(nn, 'LAZY_DZ', fused)
   _, pm = MP.make_pair(name, 'cpu', batch, size)

@@ -66,7 +66,7 @@ SHAPES = [
 def test_fprop_dgrad_wgrad_vs_oracle(hip_lib, shape, mode, monkeypatch):
   from assembled_cnn_amd import ops
   util.set_knob(monkeypatch, 'ASM_IGEMM_MODE', str(mode))   # global->LDS staging flavour of the igemm kernel
-  monkeypatch.setenv('ASM_DENSE_SMALL', '0')        # [N,1,1,C] shapes too: this test is about the convolution kernels
+  util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', '0')        # [N,1,1,C] shapes too: this test is about the convolution kernels
   N, H, W, Cn, K, k, stride = shape
   x = _rand((N, H, W, Cn), 1)
   w = _rand((K, k, k, Cn), 2, scale=(1.0 / (k * k * Cn)) ** 0.5)

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from tests import model_parity as mp
+from tests import util
 
 pytestmark = pytest.mark.gpu
 
@@ -164,8 +165,8 @@ def test_side_streams_change_no_bit_over_several_steps(hip_lib, monkeypatch, nam
   img, x, labels = mp.inputs(8, 96)
   outs = []
   for knob in ('1', '0'):
-    monkeypatch.setenv('ASM_WGRAD_STREAM', knob)
-    monkeypatch.setenv('ASM_BL_STREAMS', knob)
+    util.set_knob(monkeypatch, 'ASM_WGRAD_STREAM', knob)
+    util.set_knob(monkeypatch, 'ASM_BL_STREAMS', knob)
     hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
                  zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01, batch_size=8, label_smoothing=0.1)
     tr = Trainer(hp, seed=3, device='cuda')

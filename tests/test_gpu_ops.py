@@ -491,7 +491,7 @@ def test_dense_layers_route_through_dense_small_and_match_the_conv_kernels(hip_l
   ops.filter_transpose(w, wt, K, 1, 1, Cn)
   outs = {}
   for knob in ('1', '0'):
-    monkeypatch.setenv('ASM_DENSE_SMALL', knob)
+    util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', knob)
     d = ops.make_conv_desc(N_, 1, 1, Cn, K, 1, 1, 1, out_f32=True)
     y, _ = ops.conv_fprop(d, x, w, False)
     db = ops.make_conv_desc(N_, 1, 1, Cn, K, 1, 1, 1)
@@ -509,8 +509,8 @@ def test_dense_bn_fused_equals_conv_plus_bn_small(hip_lib, M, K, N, relu, monkey
   """fc + training-mode BN (+ReLU) in one launch == asm_conv2d_fprop + asm_bn_small_fwd; and its backward twin
   (input gradient of the next dense layer + BN backward) == asm_conv2d_dgrad + asm_bn_small_bwd."""
   from assembled_cnn_amd import ops
-  monkeypatch.setenv('ASM_DENSE_SMALL', '1')
-  monkeypatch.setenv('ASM_DENSE_BN', '1')
+  util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', '1')
+  util.set_knob(monkeypatch, 'ASM_DENSE_BN', '1')
   x = _rand((M, 1, 1, K), 1).cuda()
   w = _rand((N, 1, 1, K), 2, scale=K ** -0.5).cuda()
   gamma = (torch.rand(N, generator=torch.Generator().manual_seed(2)) + 0.5).cuda()
@@ -520,7 +520,7 @@ def test_dense_bn_fused_equals_conv_plus_bn_small(hip_lib, M, K, N, relu, monkey
   assert ops.dense_bn_ok(M, K, N)
   ypre, z, mask, mean, invstd = ops.dense_bn_fwd(d, x, w, gamma, beta, 1e-5, 0.997, mm, mv, relu, True)
   # the two-launch path
-  monkeypatch.setenv('ASM_DENSE_SMALL', '0')
+  util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', '0')
   y2, _ = ops.conv_fprop(d, x, w, False)
   mm2, mv2 = torch.zeros(N).cuda(), torch.ones(N).cuda()
   z2, mask2, mean2, invstd2 = ops.bn_small_fwd(y2, M, N, gamma, beta, 1e-5, 0.997, mm2, mv2, relu, True)
@@ -558,9 +558,9 @@ def test_sk_attention_path_fused_vs_unfused_whole_unit(hip_lib, monkeypatch):
   logits and every parameter gradient agree to bf16 noise."""
   from tests import model_parity as MP
   res = {}
-  monkeypatch.setenv('ASM_DENSE_BN', '1')      # the one-launch fc + batch norm forms too (opt-in)
+  util.set_knob(monkeypatch, 'ASM_DENSE_BN', '1')      # the one-launch fc + batch norm forms too (opt-in)
   for knob in ('1', '0'):
-    monkeypatch.setenv('ASM_DENSE_SMALL', knob)
+    util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', knob)
     om, pm = MP.make_pair('a-r50', 'cuda', 8, 64)
     _, x, _ = MP.inputs(8, 64)
     lp = pm(x.cuda(), True, use_resnet_d=False)
@@ -594,7 +594,7 @@ def test_dense_small_wgrad_vs_fp32_and_conv_kernel(hip_lib, M, Cin, Cout, ldy, m
   ref = dy.float().cpu().view(M, ldy)[:, :Cout].t() @ x.float().cpu().view(M, Cin)
   got = {}
   for knob in ('1', '0'):
-    monkeypatch.setenv('ASM_DENSE_SMALL', knob)
+    util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', knob)
     dw = torch.full((Cout, 1, 1, Cin), 3.0, device='cuda')
     ops.conv_wgrad(d, x, dy, dw)
     got[knob] = dw.cpu().view(Cout, Cin)

@@ -62,7 +62,8 @@ def perturb_bn_state(om, seed):
 
 
 def set_knob(monkeypatch, name: str, value):
-  """set an ASM_* kernel-selection variable for this test and hand it to the library (which reads no environment)"""
+  """set an ASM_* variable for this test: the host-side switches are cached (ops.knob) and the kernel-selection ones live in
+  the library's asm_tuning struct (it reads no environment), so both are refreshed"""
   from assembled_cnn_amd import ops
   monkeypatch.setenv(name, str(value))
   ops.refresh_tuning()

@@ -9,7 +9,8 @@ WHAT="${*:-stats}"
 REPO=$(pwd)
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-roofline --no-gradsync"
+# --single-stream: a kernel's duration (and its counters) are then properties of the kernel, not of what ran beside it
+BENCH="python $REPO/bench.py --single-stream --no-cpu-baseline --no-roofline --no-gradsync"
 for w in $WHAT; do
   case $w in
     stats)
