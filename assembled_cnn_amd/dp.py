@@ -46,10 +46,6 @@ class GradSync(object):
       # Trainer builds the model lazily on the first forward: a GradSync made before that would cut zero buckets and
       # every later step would all-reduce nothing while the replicas drift apart silently.
       raise RuntimeError('GradSync needs a built model: call model.build(...) (ParamArena.finalize) first')
-    if getattr(arena, 'side_stream', None) is not None:
-      # bucket launches are ordered against the compute stream only, so with an exchange attached the weight
-      # gradients go back onto the compute stream (nn.ConvKernel.backward checks arena.on_grad / side_stream)
-      arena.disable_side_stream()
     if comm_dtype not in ('fp32', 'bf16'):
       raise ValueError("comm_dtype must be 'fp32' (the reference's all-reduce precision) or 'bf16'")
     self.arena = arena
@@ -103,6 +99,9 @@ class GradSync(object):
   def _launch(self, s: int, i: int):
     lo, hi = self.segments[s][i]
     self._reduced += hi - lo
+    # RCCL's stream is ordered against the CURRENT stream only; the gradients of this bucket were written on the compute
+    # stream, the weight-gradient streams and (first block of a BigLittle big branch) the branch stream: join them all
+    self.arena.join_all_streams()
     if self._stage is not None:
       from . import ops
       ops.cast_f32_to_bf16(self.arena.g32[lo:hi], self._stage[lo:hi])

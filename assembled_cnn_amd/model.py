@@ -25,6 +25,10 @@ from typing import Optional
 import torch
 
 from . import nn, ops
+
+# the two torch stream primitives the walker uses, as module attributes so that a CPU test can stand in for them
+_current_stream = torch.cuda.current_stream
+_stream_ctx = torch.cuda.stream
 from .nn import BatchNorm, ConvKernel, Ctx, SEUnit, SKUnit, Var, conv_bn
 
 
@@ -116,8 +120,7 @@ class Model(object):
     # Weight gradients are leaves of the backward graph, so they run on a second HIP stream beside the
     # dgrad -> BN-backward chain and fill the tail rounds of the 1-workgroup-per-CU convolution tiles: -0.4 .. -0.8 % step
     # time in same-box A/B runs (round 1: 8330 vs 8190 img/s; round 2: 29.59 / 29.71 vs 29.83 / 29.84 ms).
-    # ASM_WGRAD_STREAM=0 keeps everything on the compute stream.  Single-GPU only: dp.GradSync (whose bucket launches are
-    # ordered against the compute stream) switches it off when it attaches.
+    # ASM_WGRAD_STREAM=0 keeps everything on the compute stream.  dp.GradSync joins these streams before every bucket launch.
     if ops.knob('ASM_WGRAD_STREAM', '1') != '0':
       self.arena.enable_side_stream()     # no-op on the CPU test double
 
@@ -179,7 +182,51 @@ class Model(object):
       return None          # DropBlock draws come from one generator in creation order
     if self._bl_stream is None:
       self._bl_stream = torch.cuda.Stream(device=x.data.device)
+      self.arena.extra_streams.append(self._bl_stream)
     return self._bl_stream
+
+  def _bl_backward(self, ctx: Ctx, side, big_out: Var, big_first, big_rest, little):
+    """Backward of the two branches of a BigLittle stage as ONE tape entry: the big branch's blocks 2..n (half resolution,
+    small-M deep-K tiles) on the branch stream beside the little branch (full resolution, bandwidth-bound) on the compute
+    stream -- the same pairing as in the forward pass; then, streams joined, the big branch's first block, whose input
+    gradient carries the fan-in add with the little branch's.  The host feeds the two streams in turns of a few tape
+    entries.  Gradient-ready notifications of the big branch are deferred until the little branch (created later) is
+    through: dp.GradSync's watermark stays monotone.  ASM_BL_BWD=0 (or ASM_BL_STREAMS=0) keeps the plain tape order."""
+    arena = ctx.arena
+    TURN = 3        # tape entries per turn: about one bottleneck block
+
+    def run():
+      main = _current_stream()
+      big, lit = list(reversed(big_rest)), list(reversed(little))
+      # The big branch's output gradient (whatever lazy form it is in) was allocated on the compute stream and is read on
+      # the branch stream; its consumer drops it while the little branch keeps allocating on the compute stream, and the
+      # caching allocator would hand the block out again while the branch stream still reads it.  Kept alive until the join.
+      keep = (big_out._grad, big_out.grad_mask, big_out.pre_dy, big_out.pool_grad, big_out.pending)
+      side.wait_stream(main)            # the merge's backward produced both branches' output gradients on the compute stream
+      bi = li = 0
+      try:
+        while bi < len(big) or li < len(lit):
+          if bi < len(big):
+            arena.defer_grads(True)
+            arena.compute_stream = side
+            with _stream_ctx(side):
+              for fn in big[bi:bi + TURN]:
+                fn()
+            bi += TURN
+            arena.compute_stream = main
+            arena.defer_grads(False)
+          for fn in lit[li:li + TURN]:
+            fn()
+          li += TURN
+      finally:
+        arena.compute_stream = main
+        arena.defer_grads(False)
+      main.wait_stream(side)
+      del keep
+      arena.flush_deferred()
+      for fn in reversed(big_first):
+        fn()
+    return run
 
   def _bottleneck(self, ctx: Ctx, x: Var, filters, projection, strides, zero_gamma, aa_size, aa_type,
                   last_relu=True, expansion=4, db_gamma_scale=None) -> Var:
@@ -290,6 +337,7 @@ class Model(object):
     # first block: projection + stride + anti-alias args; last_relu is NOT forwarded (:151-155)
     x = self._bottleneck(ctx, x, filters, proj, strides, self.zero_gamma, aa_size, aa_type, True, expansion,
                          db_gamma_scale)
+    ctx.first_block_end = len(ctx.tape) if ctx.tape is not None else None     # (the BigLittle backward split, _bl_backward)
     for i in range(1, num_blocks):     # :157-161
       x = self._bottleneck(ctx, x, filters, None, 1, self.zero_gamma, 0, "",
                            last_relu if i == num_blocks - 1 else True, expansion, db_gamma_scale)
@@ -365,14 +413,16 @@ class Model(object):
         # stream waits, so every cross-stream tensor is produced before it is read and the caching allocator
         # only ever recycles a block inside the stream that owns it.  ASM_BL_STREAMS=0 keeps one stream.
         side = self._branch_stream(ctx, x)
+        tb0 = len(ctx.tape) if ctx.tape is not None else None
         if side is not None:
-          side.wait_stream(torch.cuda.current_stream())
-          with torch.cuda.stream(side):
+          side.wait_stream(_current_stream())
+          with _stream_ctx(side):
             big = self._block_layer(ctx, x, num_filters, num_blocks - 1, 2, 'big{}'.format(i + 1),
                                     use_bl=True, last_relu=False, db_gamma_scale=dbs)
         else:
           big = self._block_layer(ctx, x, num_filters, num_blocks - 1, 2, 'big{}'.format(i + 1),
                                   use_bl=True, last_relu=False, db_gamma_scale=dbs)
+        tb1, tbf = (len(ctx.tape), ctx.first_block_end) if ctx.tape is not None else (None, None)
         ctx.pop_scope()
         ctx.push_scope('little{}'.format(i + 1))
         little = self._block_layer(ctx, x, num_filters // self.alpha, max(1, num_blocks // self.beta - 1), 1,
@@ -382,7 +432,10 @@ class Model(object):
         be = L(lambda: BatchNorm(ctx, num_filters * 4))
         ctx.pop_scope()
         if side is not None:
-          torch.cuda.current_stream().wait_stream(side)
+          _current_stream().wait_stream(side)
+          if tb0 is not None and tb1 > tbf and ops.knob('ASM_BL_BWD', '1') != '0':
+            tape = ctx.tape
+            tape[tb0:] = [self._bl_backward(ctx, side, big, tape[tb0:tbf], tape[tbf:tb1], tape[tb1:])]
         # relu(BN(little_e) + UpSampling2D(big)) :493-501
         x = conv_bn(ctx, little, ce, be, 1, relu=True, residual=big, res_mode=2)
         ctx.push_scope('merge{}'.format(i + 1))

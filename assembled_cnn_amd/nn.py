@@ -71,6 +71,8 @@ class ParamArena(object):
     self.on_grad: Optional[Callable[[int], None]] = None  # dp.GradSync.notify (gradient-ready watermark)
     self._held: List[int] = []                            # notifications queued between hold_grads() and pass_grads()
     self._holding = False
+    self._deferred: List[int] = []
+    self._deferring = False
     self.wt_specs: List[dict] = []   # CRSK (dgrad operand) copies: one flat bf16 arena, one batched launch
     self.wt16 = None
     self._wt_table = None
@@ -80,13 +82,16 @@ class ParamArena(object):
     self.side_stream = None
     self._sides = []
     self.compute_stream = None       # the stream the running backward pass was started on (set by Model.backward)
+    self.extra_streams = []          # other streams gradient work may run on (the model's BigLittle branch stream)
 
   def notify_grad(self, name: str):
     """The gradient slot of ``name`` has been enqueued (on the compute stream, or on the weight-gradient stream
     for conv kernels); backward order is the reverse of creation order, so every slot above it in its segment has
     been enqueued too."""
     if self.on_grad is not None:
-      if self._holding:
+      if self._deferring:
+        self._deferred.append(self.specs[name].offset)
+      elif self._holding:
         self._held.append(self.specs[name].offset)
       else:
         self.on_grad(self.specs[name].offset)
@@ -105,6 +110,19 @@ class ParamArena(object):
     held, self._held, self._holding = self._held, [], False
     if self.on_grad is not None:
       for off in held:
+        self.on_grad(off)
+
+  # The big branch of a BigLittle stage runs its backward on a second stream BESIDE the little branch's (model.py): its
+  # variables were created before the little branch's, so while the two are interleaved its notifications are deferred
+  # (a list of their own: the projection blocks inside either branch keep using hold / pass / release) and replayed, in
+  # the order they were made, once the little branch is through and the streams are joined.
+  def defer_grads(self, on: bool):
+    self._deferring = bool(on) and self.on_grad is not None
+
+  def flush_deferred(self):
+    deferred, self._deferred, self._deferring = self._deferred, [], False
+    if self.on_grad is not None:
+      for off in deferred:
         self.on_grad(off)
 
   def enable_side_stream(self):
@@ -133,6 +151,17 @@ class ParamArena(object):
   def disable_side_stream(self):
     self.join_side_stream()
     self.side_stream, self._sides = None, []
+
+  def join_all_streams(self):
+    """Make the CURRENT stream wait for everything enqueued so far on every stream this model launches gradient work on
+    (the compute stream of the running backward pass, the weight-gradient streams, the BigLittle branch stream): what
+    dp.GradSync does before it hands a bucket to RCCL, whose stream is ordered against the current stream only."""
+    if self.w32 is None or not self.w32.is_cuda:
+      return
+    cur = torch.cuda.current_stream()
+    for s in [self.compute_stream] + list(self._sides) + list(self.extra_streams):
+      if s is not None and s != cur:
+        cur.wait_stream(s)
 
   def register(self, name, shape, decay, init) -> ParamSpec:
     if self.finalized:
@@ -525,12 +554,11 @@ class ConvKernel(object):
       ops.stem_unpack_grad(dwp, a.g(self.name), self.cout, self.k)
     else:
       ops.conv_wgrad(d, x, dy, a.g(self.name))
-    a.notify_grad(self.name)
 
   def wgrad_streamed(self, d, x: torch.Tensor, dy: torch.Tensor):
     """dW into the gradient arena, on the weight-gradient side stream when there is one"""
     a = self.arena
-    side = a.pick_side_stream() if a.on_grad is None else None
+    side = a.pick_side_stream()
     if side is not None:
       side.wait_stream(a.compute_stream or torch.cuda.current_stream())     # x and dy were produced on the compute stream
       if self.stem or ops.timer_on():                    # these allocate / record events through torch: its own context
@@ -546,6 +574,7 @@ class ConvKernel(object):
       dy.record_stream(side)
     else:
       self._wgrad(d, x, dy)
+    a.notify_grad(self.name)     # on the compute stream's side of things: dp.GradSync joins the other streams itself
 
   def backward(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool,
                addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None, pool=None

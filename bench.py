@@ -9,8 +9,8 @@ One "step" = one pass of the whole hot path over one synthetic minibatch already
 mean-subtract(+mixup) -> forward -> softmax-CE(+label smoothing) -> backward -> [gradient all-reduce]
 -> momentum-SGD.  Weak scaling: the per-GPU batch is fixed as N grows.  Rank 0 prints ONE JSON line.
 
-The timed region is the product as it ships: at N = 1 the weight gradients run beside the input-gradient chain and (forward)
-the big branch of each BigLittle stage beside the little one, on side streams.  Kernels then share the CUs, so the per-class
+The timed region is the product as it ships: the weight gradients run beside the input-gradient chain and the big branch of
+each BigLittle stage beside the little one, on side streams.  Kernels then share the CUs, so the per-class
 figures below come from instrumented single-stream steps run after the timed region; `single_stream` is the rate of the same
 steps with every kernel on one stream (--single-stream times that instead).
 
@@ -230,7 +230,7 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
   (bf16) cast is real, only the link traffic is missing.  exchange_ms_exposed = step with the exchange - step without."""
   import socket
   import torch.distributed as dist
-  from assembled_cnn_amd import dp, ops
+  from assembled_cnn_amd import dp
   try:
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -239,8 +239,6 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
     if os.environ.get('NCCL_DEBUG', '').upper() in ('', 'VERSION'):
       os.environ['NCCL_DEBUG'] = 'WARN'     # no version banner on stdout next to the one JSON line
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
-    os.environ['ASM_BL_STREAMS'] = '0'      # compared with the single-stream step (GradSync hands the weight-gradient stream back)
-    ops.refresh_tuning()
     gs = dp.GradSync(tr.model.arena, comm_dtype=args.comm_dtype)
     tr.grad_sync = gs
     for _ in range(2):
@@ -279,7 +277,7 @@ def main():
   ap.add_argument('--no-roofline', action='store_true')
   ap.add_argument('--single-stream', action='store_true',
                   help='time the step with every kernel on ONE stream (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0); without it the '
-                       'timed region is the product default (weight gradients at N = 1 and the big branch of a BigLittle '
+                       'timed region is the product default (weight gradients and the big branch of a BigLittle '
                        'stage on side streams) and the single-stream rate is reported as an extra')
   ap.add_argument('--dump-convs', default='', help='write the per-conv-shape HIP-event times of the instrumented step here (markdown)')
   ap.add_argument('--no-gradsync', action='store_true', help='N = 1: skip the extra leg with the gradient exchange attached')
@@ -317,9 +315,8 @@ def main():
     from tests.cpu_double import CpuDouble      # test infrastructure, only under --dry-run-cpu
     _ops.set_library(CpuDouble(), is_double=True)
 
-  # The timed region is the product as it ships: weight gradients beside the dgrad chain (N = 1; with a gradient exchange
-  # attached they stay on the compute stream, dp.GradSync) and the big branch of a BigLittle stage beside the little one
-  # (forward) on side streams.  Kernels then share the CUs and their individual durations depend on what runs next to
+  # The timed region is the product as it ships: weight gradients beside the dgrad chain and the big branch of a BigLittle
+  # stage beside the little one on side streams (dp.GradSync joins them before each bucket launch).  Kernels then share the CUs and their individual durations depend on what runs next to
   # them, so the per-class HIP-event sums (`roofline`, `step`) come from instrumented SINGLE-stream steps after the timed
   # region, where a duration is a property of the kernel; the single-stream rate is reported as `single_stream`.
   if args.single_stream:
@@ -393,10 +390,12 @@ def main():
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
+  if world == 1 and not args.no_gradsync and not dry:   # same streams as the timed region, plus the exchange
+    dp_info = _gradsync_leg(tr, step, sync, args, 1000.0 * el / args.steps)
   class_sum = None
   INSTR = 3
   single = None
-  if not dry and not args.single_stream and (not args.no_roofline or (world == 1 and not args.no_gradsync)):
+  if not dry and not args.single_stream and not args.no_roofline:
     # everything below runs on ONE stream
     os.environ['ASM_BL_STREAMS'] = '0'
     ops.refresh_tuning()
@@ -437,9 +436,6 @@ def main():
           by = 2.0 * N_ * (H_ * W_ * C_ + Ho_ * Ho_ * K_) * n
           f.write('| %s | %d %dx%dx%d -> %d, %dx%d/%d | %d | %.4f | %.0f | %.0f |\n' % (
               kind, N_, H_, W_, C_, K_, R_, S_, st_, n, ms, conv_flops(k) * n / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9))
-  if world == 1 and not args.no_gradsync and not dry:
-    base_ms = single['ms_per_step'] if single is not None else 1000.0 * el / args.steps
-    dp_info = _gradsync_leg(tr, step, sync, args, base_ms)
   loss = float(tr.cross_entropy())
   if not (loss == loss) or loss > 50:
     raise SystemExit('training diverged (loss=%r): the number would be invalid' % loss)
@@ -527,8 +523,7 @@ def main():
     except Exception as e:   # reporting extras must never lose the measured number
       out['step'] = {'error': repr(e)}
     out['streams'] = ('single (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0)' if args.single_stream else
-                      'product default: the big branch of each BigLittle stage (forward)%s on a second HIP stream'
-                      % (' and the weight gradients' if world == 1 else ''))
+                      'product default: the weight gradients and the big branch of each BigLittle stage on side streams')
     out['launches'] = {'abi_calls_per_step': round(abi_calls, 1),
                        'note': 'C-ABI calls of one step in the timed region (one kernel launch each, except: strided input '
                                'gradients = one per parity class, weight gradients = kernel + slab reduce); the rocprofv3 '

@@ -64,3 +64,64 @@ def test_projection_block_keeps_the_gradient_watermark_monotone(cpu_double):
     last[s] = off
   kernels = [sp.offset for n, sp in a.specs.items() if n.endswith('/kernel')]
   assert set(kernels) <= set(seen), 'every kernel gradient is announced'
+
+
+class _FakeStream(object):
+  """stands in for a HIP stream on the CPU double: records who waited for whom"""
+  def __init__(self, name, log):
+    self.name, self.log = name, log
+
+  def wait_stream(self, other):
+    self.log.append(('wait', self.name, other.name))
+
+
+def test_biglittle_backward_on_two_streams_is_the_same_backward(cpu_double, monkeypatch):
+  """The big branch's blocks 2..n run their backward interleaved with the little branch's (on the GPU: on the branch stream);
+  on the CPU double, with stand-in streams, the reordered tape must give bit-identical gradients, fork / join the streams
+  around the interleaved part and keep the gradient-ready watermark monotone with every kernel announced."""
+  import contextlib
+  from assembled_cnn_amd import model as pmodel
+
+  def run(two_streams):
+    log = []
+    main, side = _FakeStream('main', log), _FakeStream('side', log)
+    cur = [main]
+
+    @contextlib.contextmanager
+    def ctx(s):
+      log.append(('enter', s.name))
+      cur.append(s)
+      try:
+        yield
+      finally:
+        cur.pop()
+    if two_streams:
+      monkeypatch.setattr(pmodel, '_current_stream', lambda: cur[-1])
+      monkeypatch.setattr(pmodel, '_stream_ctx', ctx)
+      monkeypatch.setattr(pmodel.Model, '_branch_stream', lambda self, c, x: None if c.dry else side)
+    _, pm = MP.make_pair('a-r50-d', 'cpu', 2, 64)
+    _, x, _ = MP.inputs(2, 64)
+    a = pm.arena
+    seen = []
+    a.on_grad = seen.append
+    lp = pm(x, True, use_resnet_d=True)
+    dl = torch.zeros((2, 1, 1, pm.ldc), dtype=torch.bfloat16)
+    dl[:, 0, 0, :1001] = (torch.softmax(lp.float(), 1) / 2).to(torch.bfloat16)
+    pm.backward(dl)
+    a.on_grad = None
+    monkeypatch.undo()
+    return a, seen, log, a.g32.clone()
+
+  a1, seen1, log1, g1 = run(False)
+  a2, seen2, log2, g2 = run(True)
+  assert not log1 and torch.equal(g1, g2), 'the two-stream backward must be the same backward'
+  last = [1 << 62, 1 << 62]
+  for off in seen2:
+    s = 0 if off < a2.decay_elems else 1
+    assert off <= last[s], 'watermark moved up'
+    last[s] = off
+  assert sorted(seen1) == sorted(seen2)
+  # three BigLittle stages: forward fork + join each, backward fork + several turns on the side stream + join each
+  waits = [e for e in log2 if e[0] == 'wait']
+  assert waits.count(('wait', 'side', 'main')) == 6 and waits.count(('wait', 'main', 'side')) == 6
+  assert sum(1 for e in log2 if e == ('enter', 'side')) >= 3 + 3

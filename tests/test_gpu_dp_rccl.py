@@ -72,3 +72,56 @@ def test_gradsync_over_rccl_world1_is_identity_and_overlapped(hip_lib):
       tr.model.arena.on_grad = None
   finally:
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_buckets_wait_for_every_stream_that_writes_gradients(hip_lib):
+  """With the weight-gradient and BigLittle side streams ON (the default), a bucket handed to RCCL must already hold the
+  gradients written on those streams.  World size 1 makes the fp32 exchange an in-place identity, which would hide a bucket
+  launched too early; the bf16 exchange does not: its narrowing cast reads the bucket when it is launched and the widened
+  result overwrites it, so a gradient that arrived late would come back as bf16(stale value).  Expected, bit for bit:
+  bf16-rounded gradients of the same step without an exchange.  4 MiB buckets (40 launches inside the backward pass),
+  several steps, a batch large enough for the side streams to lag."""
+  import torch.distributed as dist
+  from assembled_cnn_amd import dp
+  from assembled_cnn_amd.train import HParams, Trainer
+  from tests import model_parity as mpar
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  assert not dist.is_initialized()
+  dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1)
+  try:
+    hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
+                 use_resnet_d=True, zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01,
+                 weight_decay=1e-4, batch_size=32)
+    img, _, labels = mpar.inputs(32, 128)
+    img, labels = img.cuda(), labels.cuda()
+    plain = Trainer(hp, seed=0, device='cuda')
+    plain.model.build((128, 128), use_resnet_d=True)
+    tr = Trainer(hp, seed=0, device='cuda', world_size=1)
+    tr.model.build((128, 128), use_resnet_d=True)
+    assert tr.model.arena.side_stream is not None
+    sync = dp.GradSync(tr.model.arena, bucket_bytes=4 << 20, comm_dtype='bf16')
+    assert tr.model.arena.side_stream is not None, 'the exchange must not switch the side streams off'
+    for step in range(4):
+      plain._forward_backward(img, labels, None, None)
+      tr._forward_backward(img, labels, None, None)
+      sync(tr.model.arena.g32)
+      torch.cuda.synchronize()
+      want = plain.model.arena.g32.to(torch.bfloat16).float()
+      got = tr.model.arena.g32
+      bad = int((want != got).sum())
+      if bad:
+        a = plain.model.arena
+        names = [n for n, sp in a.specs.items()
+                 if not torch.equal(want[sp.offset:sp.offset + sp.numel], got[sp.offset:sp.offset + sp.numel])]
+        raise AssertionError('step %d: %d gradient elements differ from the bf16-rounded gradients of the plain step, in %d '
+                             'variables: %s' % (step, bad, len(names), names[:12]))
+      # same optimiser step on both (from the plain gradients), so that the next comparison starts from equal weights
+      tr.model.arena.g32.copy_(plain.model.arena.g32)
+      plain._apply(None, 1.0, 1.0)
+      tr.grad_sync = None
+      tr._apply(None, 1.0, 1.0)
+      assert torch.equal(tr.model.arena.w32, plain.model.arena.w32)
+    tr.model.arena.on_grad = None
+  finally:
+    dist.destroy_process_group()

@@ -156,13 +156,16 @@ def test_full_size_layer_shapes_run(hip_lib):
   assert tr.model.num_params() == 41867721
 
 
-@pytest.mark.parametrize('name', ['a-r50-d'])
-def test_side_streams_change_no_bit_over_several_steps(hip_lib, monkeypatch, name):
-  """The weight-gradient side stream and the BigLittle big-branch stream (both default-on) against ONE stream: three
-  consecutive training steps (so the caching allocator recycles blocks across steps and streams), then an evaluation
-  forward and a tape-less training-mode forward -- identical weights, moving statistics, momentum and logits, bit for bit."""
+@pytest.mark.parametrize('size,steps', [(64, 8), (96, 4)])
+def test_side_streams_change_no_bit_over_several_steps(hip_lib, monkeypatch, size, steps):
+  """The weight-gradient side streams and the BigLittle branch stream (forward: the big branch beside the little one;
+  backward: its blocks 2..n beside the little branch's; all default-on) against ONE stream: consecutive training steps
+  (so the caching allocator recycles blocks across steps and streams -- at batch 8 the kernels are short, the host is the
+  bottleneck and a block freed too early IS handed out again while another stream still reads it: this is the test that
+  found the big branch's output gradient being recycled under the branch stream), then an evaluation forward and a
+  tape-less training-mode forward -- identical, finite weights, moving statistics, momentum and logits, bit for bit."""
   from assembled_cnn_amd.train import HParams, Trainer
-  img, x, labels = mp.inputs(8, 96)
+  img, x, labels = mp.inputs(8, size)
   outs = []
   for knob in ('1', '0'):
     util.set_knob(monkeypatch, 'ASM_WGRAD_STREAM', knob)
@@ -170,7 +173,7 @@ def test_side_streams_change_no_bit_over_several_steps(hip_lib, monkeypatch, nam
     hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
                  zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01, batch_size=8, label_smoothing=0.1)
     tr = Trainer(hp, seed=3, device='cuda')
-    for _ in range(3):
+    for _ in range(steps):
       tr.train_step(img.cuda(), labels.cuda())
     assert (tr.model.arena.side_stream is not None) == (knob == '1')
     ev = tr.eval_logits(x.cuda()).clone()
@@ -179,7 +182,43 @@ def test_side_streams_change_no_bit_over_several_steps(hip_lib, monkeypatch, nam
     a = tr.model.arena
     outs.append((a.w32.clone(), a.m32.clone(), a.state.clone(), ev, tl, tr.last['loss_rows'].clone()))
   for p, q in zip(*outs):
-    assert torch.equal(p, q)
+    assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
+
+
+def test_the_step_as_one_hip_graph_is_the_same_step(hip_lib):
+  """Trainer.capture: inputs -> forward -> loss -> backward recorded into a HIP graph (side streams included), replayed
+  over static input buffers with the optimiser outside.  Two eager steps + four replays on alternating batches against six
+  eager steps: identical losses, weights, momentum and moving statistics, bit for bit.  And what it refuses."""
+  from assembled_cnn_amd.train import HParams, Trainer
+  hp = dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
+            zero_gamma=True, learning_rate_decay_type='cosine', base_learning_rate=0.01, batch_size=8, label_smoothing=0.1)
+  batches = [mp.inputs(8, 64, seed=s) for s in (1, 2)]
+  batches = [(b[0].cuda(), b[2].cuda()) for b in batches]
+  runs = []
+  for graphed in (False, True):
+    tr = Trainer(HParams(**hp), seed=0, device='cuda')
+    losses = []
+    for s in range(6):
+      if graphed and s == 2:
+        tr.capture(batches[0][0], batches[0][1], warmup=0)
+      tr.train_step(*batches[s % 2])
+      losses.append(float(tr.cross_entropy()))
+    torch.cuda.synchronize()
+    a = tr.model.arena
+    runs.append((losses, a.w32.clone(), a.m32.clone(), a.state.clone()))
+    if graphed:
+      with pytest.raises(RuntimeError):
+        tr.capture(*batches[0])                                   # already captured
+      with pytest.raises(ValueError):
+        tr.train_step(batches[0][0][:4], batches[0][1][:4])     # not the captured shapes
+      tr.release_graph()
+      tr.train_step(batches[0][0][:4].contiguous(), batches[0][1][:4].contiguous())   # eager again
+  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+  for p, q in zip(runs[0][1:], runs[1][1:]):
+    assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
+  db = Trainer(HParams(**dict(hp, use_dropblock=True)), seed=0, device='cuda')
+  with pytest.raises(NotImplementedError):
+    db.capture(*batches[0])
 
 
 @pytest.mark.parametrize('name,size', [('r101v1-gem-emb', 64), ('r50v1-nodown-flatten-sigmoid', 32)])

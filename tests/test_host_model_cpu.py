@@ -107,3 +107,12 @@ def test_teacher_forced_backward_parity_on_the_double(cpu_double):
   errs, st = mp.check_teacher_forced_backward('a-r50-d', 'cpu', 4, 64)
   k = st['kinds']
   assert st['forced'] >= 80 and k['dout'] >= 60 and k['dW'] + k['dW-squeeze'] == 117 and len(errs) >= 400
+
+
+def test_step_graph_capture_needs_a_gpu(cpu_double):
+  """Trainer.capture is a device feature: host tensors are refused (no CPU fallback path to capture)"""
+  from assembled_cnn_amd.train import HParams, Trainer
+  tr = Trainer(HParams(resnet_version=1, batch_size=2), seed=0, device='cpu')
+  img, _, labels = mp.inputs(2, 32)
+  with pytest.raises(RuntimeError):
+    tr.capture(img, labels)

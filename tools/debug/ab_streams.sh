@@ -8,7 +8,7 @@ run() { # label, env...
 : > gpurun_out/ab_streams.log
 for i in 1 2; do
 run default A=1
-run ws1 ASM_WGRAD_STREAMS=1
+run no_bl_bwd ASM_BL_BWD=0
 run single ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0
 done
 cat gpurun_out/ab_streams.log
