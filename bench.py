@@ -47,7 +47,7 @@ if ROOT not in sys.path:
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PMC_FILE = 'round2_pmc_traffic.json'          # dominant layer, tools/conv_bench.py in isolation (round 2)
-CLASS_TRAFFIC_FILE = 'round3_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
+CLASS_TRAFFIC_FILE = 'round3_b_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
 HBM_PEAK_GBS = 8000.0            # spec; MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {
@@ -360,18 +360,22 @@ def main():
       if not dry:
         torch.cuda.synchronize()
 
+  def pick_dominant():
+    """one step with HIP events around every conv launch -> the (kind, shape) with the most time"""
+    t = ops.ConvTimer()
+    ops.set_conv_timer(t)
+    step()
+    torch.cuda.synchronize()
+    ops.set_conv_timer(None)
+    summ = t.summary()
+    return max(summ, key=lambda k: summ[k][1]) if summ else None
+
   dominant = None
   for i in range(args.warmup):
-    last = i == args.warmup - 1
-    if last and not args.no_roofline:
-      timer = ops.ConvTimer()
-      ops.set_conv_timer(timer)
-    step()
-    if last and not args.no_roofline:
-      torch.cuda.synchronize()
-      ops.set_conv_timer(None)
-      summ = timer.summary()
-      dominant = max(summ, key=lambda k: summ[k][1]) if summ else None
+    if i == args.warmup - 1 and not args.no_roofline and args.single_stream:
+      dominant = pick_dominant()
+    else:
+      step()
   timer = None
   if dominant is not None and args.single_stream:
     timer = ops.ConvTimer(only=dominant)
@@ -401,8 +405,8 @@ def main():
     ops.refresh_tuning()
     tr.model.arena.disable_side_stream()
     if world == 1:
-      for _ in range(2):
-        step()
+      step()
+      dominant = pick_dominant() if not args.no_roofline else None      # picked on one stream: durations are the kernels' own
       if dominant is not None:      # the heaviest layer's launches, HIP events on the launch stream over this leg
         timer = ops.ConvTimer(only=dominant)
         ops.set_conv_timer(timer)
