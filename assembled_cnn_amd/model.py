@@ -175,7 +175,7 @@ class Model(object):
 
   # -----------------------------------------------------------------------------------------------
   def _branch_stream(self, ctx: Ctx, x: Var):
-    """second HIP stream for the big branch of a BigLittle stage (forward pass), or None"""
+    """the HIP stream the big branch of a BigLittle stage runs on (forward, and blocks 2..n of its backward), or None"""
     if ctx.dry or x.data is None or not x.data.is_cuda or ops.knob('ASM_BL_STREAMS', '1') == '0':
       return None
     if getattr(ctx, 'keep_prob', 1.0) < 1.0:
@@ -408,10 +408,10 @@ class Model(object):
         ctx.push_scope('stage{}'.format(i + 1))
         ctx.push_scope('big{}'.format(i + 1))
         # The big branch (half resolution: small-M, deep-K tiles that leave CUs idle) and the little branch (full
-        # resolution, bandwidth-bound) are independent until the merge: in the FORWARD pass the big branch is
-        # enqueued on a second HIP stream so the two fill each other's gaps.  Both directions are fenced by
-        # stream waits, so every cross-stream tensor is produced before it is read and the caching allocator
-        # only ever recycles a block inside the stream that owns it.  ASM_BL_STREAMS=0 keeps one stream.
+        # resolution, bandwidth-bound) are independent until the merge: the big branch is enqueued on a second HIP stream
+        # so the two fill each other's gaps -- here in the forward pass, and again in the backward pass (_bl_backward).
+        # Both directions are fenced by stream waits, so every cross-stream tensor is produced before it is read and the
+        # caching allocator only ever recycles a block inside the stream that owns it.  ASM_BL_STREAMS=0 keeps one stream.
         side = self._branch_stream(ctx, x)
         tb0 = len(ctx.tape) if ctx.tape is not None else None
         if side is not None:
