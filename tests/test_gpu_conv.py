@@ -319,8 +319,8 @@ def test_fprop_with_folded_inference_bn(hip_lib, shape, res, relu):
                                    (32, 14, 14, 256, 1024, 1, 1)], ids=lambda s: 'x'.join(map(str, s)))
 @pytest.mark.parametrize('pfa', [0, 1], ids=['addend-inline', 'addend-prefetched'])
 def test_dgrad_with_masked_addend(hip_lib, shape, pfa, monkeypatch):
-  """asm_conv2d_dgrad_masked(addend, mask) == asm_conv2d_dgrad(addend * mask) bit for bit, and asm_mask_apply is that
-  product: the lazily masked shortcut gradient is the same gradient.  Both epilogue variants (addend fetched inside the
+  """asm_conv2d_dgrad_masked(addend, mask) against the oracle's input gradient + addend * [mask bit]; == asm_conv2d_dgrad(
+  addend * mask) bit for bit, and asm_mask_apply is that product: the lazily masked shortcut gradient is the same gradient.  Both epilogue variants (addend fetched inside the
   store passes / prefetched ahead of them, ASM_IGEMM_PFA) and in-place accumulation (dx == addend)."""
   from assembled_cnn_amd import ops
   util.set_knob(monkeypatch, 'ASM_IGEMM_PFA', str(pfa))
@@ -339,6 +339,12 @@ def test_dgrad_with_masked_addend(hip_lib, shape, pfa, monkeypatch):
   a = ops.conv_dgrad(d, dy, wt, addend, mask)
   b = ops.conv_dgrad(d, dy, wt, masked)
   assert torch.equal(a, b)
+  # against the oracle: the convolution's input gradient (autograd of its conv2d_fixed_padding) + addend * [mask bit]
+  from oracle import assembled_oracle as O
+  xr = torch.zeros((N, H, W, Cn), requires_grad=True)
+  yr = O._conv_raw(xr.permute(0, 3, 1, 2), w.float().cpu().permute(1, 2, 3, 0), k, stride)
+  gx, = torch.autograd.grad(yr, [xr], dy.float().cpu().permute(0, 3, 1, 2))
+  _check(a, gx + addend.float().cpu() * bits.float().cpu(), name='dgrad + masked addend vs oracle')
   util.set_knob(monkeypatch, 'ASM_IGEMM_PFA', str(1 - pfa))
   assert torch.equal(a, ops.conv_dgrad(d, dy, wt, addend, mask)), 'the two epilogue variants must agree bit for bit'
   # in-place fan-in accumulation through the C ABI: dx aliases the addend
@@ -357,7 +363,8 @@ def test_dgrad_with_masked_addend(hip_lib, shape, pfa, monkeypatch):
 ], ids=lambda s: 'x'.join(map(str, s)))
 @pytest.mark.parametrize('masked', [False, True], ids=['plain', 'masked-addend'])
 def test_dgrad_with_pooled_gradient_gathered_in_the_epilogue(hip_lib, shape, pool, masked):
-  """asm_conv2d_dgrad_pooled == asm_conv2d_dgrad[_masked] followed by asm_avgpool_bwd(addend = that) up to one bf16
+  """asm_conv2d_dgrad_pooled against the oracle (fp32: the 1x1 input gradient + addend * [mask bit] + the autograd gradient of
+  the oracle's average pool), and == asm_conv2d_dgrad[_masked] followed by asm_avgpool_bwd(addend = that) up to one bf16
   rounding (the fused form rounds the sum once)."""
   from assembled_cnn_amd import ops
   N, H, W, Cn, K, k, stride = shape
@@ -386,6 +393,12 @@ def test_dgrad_with_pooled_gradient_gathered_in_the_epilogue(hip_lib, shape, poo
   if masked:
     bits = ((mask.cpu().to(torch.int32)[:, :, None] >> torch.arange(8, dtype=torch.int32)) & 1).reshape(-1, Cn)
     ref = ref + addend.float().cpu().view(-1, Cn) * bits
-  pz = ops.avgpool_bwd(dpool, (N, H, W, Cn), pk, pst, ppad, cv).float().cpu().view(-1, Cn)
-  ref = ref + pz
+  # the pooled part from the ORACLE's average pool (autograd), not from the product's scatter kernel
+  from oracle import assembled_oracle as O
+  xr = torch.zeros((N, Cn, H, W), requires_grad=True)
+  pr = O.avg_pool_same(xr, pk, pst) if cv else O.avg_pool_valid(O.fixed_padding(xr, pk) if ppad else xr, pk, pst)
+  assert tuple(pr.shape) == (N, Cn, Hp, Wp)
+  pz, = torch.autograd.grad(pr, [xr], dpool.float().cpu().permute(0, 3, 1, 2))
+  ref = ref + pz.permute(0, 2, 3, 1).reshape(-1, Cn)
   assert util.rel_l2(fused.float().cpu().view(-1, Cn), ref) <= 4e-3
+  assert util.max_abs(fused.float().cpu().view(-1, Cn), ref) <= float(ref.abs().max()) * 2 ** -7 + 1e-6

@@ -604,8 +604,9 @@ def test_dense_small_wgrad_vs_fp32_and_conv_kernel(hip_lib, M, Cin, Cout, ldy, m
 
 @pytest.mark.parametrize('M,Cn', [(2 * 28 * 28, 256), (1000, 72), (256 * 7 * 7, 2048), (3 * 56 * 56, 128)])
 def test_bn_bwd_dual_equals_two_separate_backwards(hip_lib, M, Cn):
-  """out = relu(bn_a(xa) + bn_b(xb)) (block-final + projection-shortcut batch norm): one reduce + one apply for both
-  == two asm_bn_bwd_reduce / finalize / apply chains on the same (dout, mask)."""
+  """out = relu(bn_a(xa) + bn_b(xb)) (block-final + projection-shortcut batch norm): one reduce + one apply for both,
+  against the oracle's autograd through its two batch norms, and == two asm_bn_bwd_reduce / finalize / apply chains on the
+  same (dout, mask)."""
   from assembled_cnn_amd import ops
   g = torch.Generator(device='cuda').manual_seed(5)
   xa = torch.randn((M, Cn), generator=g, device='cuda').to(BF)
@@ -621,6 +622,24 @@ def test_bn_bwd_dual_equals_two_separate_backwards(hip_lib, M, Cn):
     bns.append((gamma, mean.contiguous(), invstd.contiguous()))
   outs = [torch.empty(Cn, device='cuda') for _ in range(4)]
   dxa, dxb = ops.bn_bwd_dual(dy, xa, xb, mask, M, Cn, bns[0] + (outs[0], outs[1]), bns[1] + (outs[2], outs[3]))
+  # against the oracle: autograd through its two training-mode batch norms, fed the masked gradient g = dy * [mask bit]
+  from oracle import assembled_oracle as O
+  bits = ((mask.cpu().to(torch.int32)[:, :, None] >> torch.arange(8, dtype=torch.int32)) & 1).reshape(M, Cn).float()
+  vs = O.VarStore(0)
+  octx = O.Ctx(vs, True)
+  vs.begin_call()
+  leaves, total = [], 0.0
+  for tag, x, (gamma, _, _) in (('a', xa, bns[0]), ('b', xb, bns[1])):
+    xr = x.float().cpu().t().reshape(1, Cn, M, 1).clone().requires_grad_(True)      # NCHW with H = M, W = 1
+    g_, b_ = vs.bn_vars(Cn, False, layer_name='bn_' + tag)[:2]
+    with torch.no_grad():
+      g_.copy_(gamma.cpu())
+    total = total + O.batch_norm(octx, xr, True, momentum=0.9, layer_name='bn_' + tag)
+    leaves += [xr, g_, b_]
+  gr = torch.autograd.grad(total, leaves, (dy.float().cpu() * bits).t().reshape(1, Cn, M, 1))
+  for i, (dx, dg, db) in enumerate(((dxa, outs[0], outs[1]), (dxb, outs[2], outs[3]))):
+    _close(dx, gr[3 * i].reshape(Cn, M).t(), rel=6e-3, name='dual dx vs oracle')
+    assert util.rel_l2(dg.cpu(), gr[3 * i + 1]) <= 2e-3 and util.rel_l2(db.cpu(), gr[3 * i + 2]) <= 2e-3
   for x, (gamma, mean, invstd), dx, dg, db in ((xa, bns[0], dxa, outs[0], outs[1]), (xb, bns[1], dxb, outs[2], outs[3])):
     dg2, db2 = torch.empty(Cn, device='cuda'), torch.empty(Cn, device='cuda')
     dx2, _ = ops.bn_bwd(dy, x, mask, True, M, Cn, gamma, mean, invstd, dg2, db2, False)
@@ -645,3 +664,7 @@ def test_bn_apply_dual_is_bit_identical_to_two_passes(hip_lib, M, Cn, relu):
     y1 = ops.bn_apply(xa, M, Cn, co[0], co[1], zb, 1, False)
     y2 = ops.bn_apply_dual(xa, xb, M, Cn, co[0], co[1], co[2], co[3], False)
   assert torch.equal(y1, y2)
+  # and against the definition in fp32 on the host: [relu](scale_a * xa + shift_a + bf16(scale_b * xb + shift_b))
+  c = [t.cpu() for t in co]
+  want = xa.float().cpu() * c[0] + c[1] + (xb.float().cpu() * c[2] + c[3]).to(BF).float()
+  _close(y2, torch.relu(want) if relu else want, name='dual apply vs definition')
