@@ -20,14 +20,14 @@ Extra objects on the line:
                 MI355X_MICROARCH.md): achieved = the class's algorithmic FLOPs / its HIP-event time.  `dominant_layer` keeps
                 the single heaviest conv launch (picked in a warm-up step, timed with HIP events on the launch stream over
                 the K single-stream steps), `hbm` the batch-norm family against the HBM peak; `traffic` = HBM bytes per step of the
-                class from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes OF THIS COMMAND (profiles/, tools/profile_round.sh).
+                class from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --single-stream` (profiles/, tools/profile_round.sh).
   dp            N = 1: the step with the gradient exchange attached to an RCCL group of ONE (real bucket launches, stream
                 waits, casts; no link traffic) and `exchange_ms_exposed` = that step - the plain step.  N > 1: the bucket
                 plan of the run.  No N > 1 number exists in this repository until the driver's SCALE run.
   step          the whole step against its per-layer bound sum_l max(flops_l / 2.5 PFLOP/s, bytes_l / 8 TB/s)
                 (every conv as fprop + dgrad + wgrad with un-fused algorithmic bytes, every batch norm
-                as 3 + 5 tensor passes), plus two class figures from HIP events of ONE instrumented step run after
-                the timed region: the 3x3-convolution class against the MFMA peak, the batch-norm family against
+                as 3 + 5 tensor passes), plus two class figures from HIP events of three instrumented single-stream steps run
+                after the timed region: the 3x3-convolution class against the MFMA peak, the batch-norm family against
                 the HBM peak.
   cpu_baseline  the CPU oracle (a restatement of the reference's TF graph; TF 1.14 itself cannot run
                 here) timed on this host's cores, BASELINE.md section 2: value = training step of the same network
@@ -511,7 +511,7 @@ def main():
             'frac': c33['frac_of_mfma_peak'], 'traffic': cls_traffic.get('conv3x3_class_bytes_per_step'),
             'kernel': '3x3 convolution class: every 3x3 fprop / input-gradient / weight-gradient launch of a step (%d launches, '
                       '%.3f ms, %.1f algorithmic GFLOP), time-weighted' % (c33['launches'], c33['ms_per_step'], f33 / 1e9),
-            'traffic_source': 'profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command, '
+            'traffic_source': 'profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --single-stream`, '
                               'tools/profile_round.sh; not measured in this run)' % CLASS_TRAFFIC_FILE,
             'dominant_layer': dominant_obj}
         if 'bn_class' in st_obj:
