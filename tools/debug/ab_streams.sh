@@ -1,4 +1,4 @@
-# same-box A/B of stream / runtime knobs: bash tools/debug/ab_streams.sh (on the GPU box)
+# same-box A/B of the stream knobs: bash tools/debug/ab_streams.sh (on the GPU box; ~10 s per line)
 mkdir -p gpurun_out
 run() { # label, env...
   lab=$1; shift
@@ -7,9 +7,11 @@ run() { # label, env...
 }
 : > gpurun_out/ab_streams.log
 for i in 1 2; do
-run turn3 ASM_BL_TURN=3
-run turn1 ASM_BL_TURN=1
-run turn6 ASM_BL_TURN=6
-run turn100 ASM_BL_TURN=100
+run default A=1
+run one_wgrad_stream ASM_WGRAD_STREAMS=1
+run no_bl_bwd ASM_BL_BWD=0
+run no_bl ASM_BL_STREAMS=0
+run no_wgrad_stream ASM_WGRAD_STREAM=0
+run single ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0
 done
 cat gpurun_out/ab_streams.log
