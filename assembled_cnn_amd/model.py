@@ -164,6 +164,8 @@ class Model(object):
       raise RuntimeError('no forward pass with a tape to differentiate')
     self._ctx.dlogits = dlogits
     self.arena.release_grads()      # a previous backward that raised mid-block must not leave notifications queued
+    self.arena.defer_grads(False)
+    self.arena._deferred = []
     cuda = self.arena.side_stream is not None
     self.arena.compute_stream = torch.cuda.current_stream() if cuda else None    # looked up once, not per weight gradient
     try:
