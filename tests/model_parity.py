@@ -28,6 +28,10 @@ CONFIGS = {
                     anti_alias_filter_size=3),
     'a-r152': dict(resnet_size=152, resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
                    anti_alias_filter_size=3, bl_alpha=1, bl_beta=2),
+    # BigLittle with beta = 1: the little branch has as many blocks as the big one (2 / 3 / 5), so both lists of the
+    # two-stream backward interleave are long (the published recipes' little branch is one block at depth 50)
+    'a-r50-beta1-d': dict(resnet_size=50, resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
+                          anti_alias_filter_size=3, bl_alpha=2, bl_beta=1),
     'se-proj': dict(resnet_size=50, use_se_block=True, anti_alias_type='proj', anti_alias_filter_size=3),
     # the two off-recipe configurations of tests/golden/reference_taps.json: GeM pooling + embedding head on ResNet-101,
     # and no_downsample + flatten pooling + the sigmoid loss's dense-bias initialisation

@@ -75,7 +75,8 @@ class _FakeStream(object):
     self.log.append(('wait', self.name, other.name))
 
 
-def test_biglittle_backward_on_two_streams_is_the_same_backward(cpu_double, monkeypatch):
+@pytest.mark.parametrize('name,joins', [('a-r50-d', 6), ('a-r50-beta1-d', 6)])
+def test_biglittle_backward_on_two_streams_is_the_same_backward(cpu_double, monkeypatch, name, joins):
   """The big branch's blocks 2..n run their backward interleaved with the little branch's (on the GPU: on the branch stream);
   on the CPU double, with stand-in streams, the reordered tape must give bit-identical gradients, fork / join the streams
   around the interleaved part and keep the gradient-ready watermark monotone with every kernel announced."""
@@ -99,7 +100,7 @@ def test_biglittle_backward_on_two_streams_is_the_same_backward(cpu_double, monk
       monkeypatch.setattr(pmodel, '_current_stream', lambda: cur[-1])
       monkeypatch.setattr(pmodel, '_stream_ctx', ctx)
       monkeypatch.setattr(pmodel.Model, '_branch_stream', lambda self, c, x: None if c.dry else side)
-    _, pm = MP.make_pair('a-r50-d', 'cpu', 2, 64)
+    _, pm = MP.make_pair(name, 'cpu', 2, 64)
     _, x, _ = MP.inputs(2, 64)
     a = pm.arena
     seen = []
@@ -123,5 +124,5 @@ def test_biglittle_backward_on_two_streams_is_the_same_backward(cpu_double, monk
   assert sorted(seen1) == sorted(seen2)
   # three BigLittle stages: forward fork + join each, backward fork + several turns on the side stream + join each
   waits = [e for e in log2 if e[0] == 'wait']
-  assert waits.count(('wait', 'side', 'main')) == 6 and waits.count(('wait', 'main', 'side')) == 6
+  assert waits.count(('wait', 'side', 'main')) == joins and waits.count(('wait', 'main', 'side')) == joins
   assert sum(1 for e in log2 if e == ('enter', 'side')) >= 3 + 3

@@ -68,7 +68,8 @@ def test_config5_shard_at_size_128_images_kd(hip_lib):
   assert rep['batch'] == 128
 
 
-@pytest.mark.parametrize('name,batch,size', [('r50v1', 16, 64), ('a-r50-d', 16, 128), ('se-proj', 16, 64), ('a-r152', 16, 96)])
+@pytest.mark.parametrize('name,batch,size', [('r50v1', 16, 64), ('a-r50-d', 16, 128), ('se-proj', 16, 64), ('a-r152', 16, 96),
+                                             ('a-r50-beta1-d', 16, 128)])
 def test_teacher_forced_backward_per_layer_parity(hip_lib, name, batch, size):
   """The hand-written backward tape, layer by layer, without depth amplification (tests/model_parity.py): every conv ->
   BN [-> + residual] [-> ReLU] group, SK unit and SE / DropBlock block output is a forced point -- the gradient the tape
@@ -76,7 +77,8 @@ def test_teacher_forced_backward_per_layer_parity(hip_lib, name, batch, size):
   8e-3; [N,1,1,d] squeeze tensors 2e-2) and then replaced by it; every trainable variable's gradient is compared at the
   end (dW, dgamma, dbeta <= 6e-3; see the harness for the three documented noise classes).  Runs the DEFAULT fused paths:
   lazily masked shortcut / merge gradients, deferred + dual batch norm of projection shortcuts, the pooled gradient
-  gathered in conv1's input-gradient epilogue, the fused SK backward, the reordered projection-block tape."""
+  gathered in conv1's input-gradient epilogue, the fused SK backward, the reordered projection-block tape, the BigLittle
+  backward interleaved on two streams (a-r152 and the beta = 1 variant have little branches of many blocks)."""
   errs, st = mp.check_teacher_forced_backward(name, 'cuda', batch, size)
   assert st['forced'] >= 45 and len(errs) >= 200, st
   assert sum(st['kinds'][k] for k in ('dout', 'dout-lazy', 'dx', 'dout-squeeze', 'dx-squeeze')) >= (100 if 'a-r' in name else 50)
