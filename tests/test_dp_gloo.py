@@ -20,9 +20,39 @@ def _free_port():
   return p
 
 
-def _worker(rank, world, port, out_dir):
+class _FakeStream(object):
+  def __init__(self, name):
+    self.name = name
+
+  def wait_stream(self, other):
+    pass
+
+
+def _two_stream_tape():
+  """Make the walker take its GPU path on the CPU double: the big branch of every BigLittle stage goes through
+  model._bl_backward (interleaved with the little branch, notifications deferred), with stand-in streams."""
+  import contextlib
+  from assembled_cnn_amd import model as pmodel
+  main, side, cur = _FakeStream('main'), _FakeStream('side'), []
+  cur.append(main)
+
+  @contextlib.contextmanager
+  def ctx(s):
+    cur.append(s)
+    try:
+      yield
+    finally:
+      cur.pop()
+  pmodel._current_stream = lambda: cur[-1]
+  pmodel._stream_ctx = ctx
+  pmodel.Model._branch_stream = lambda self, c, x: None if c.dry else side
+
+
+def _worker(rank, world, port, out_dir, two_stream_tape=False):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
   torch.set_num_threads(2)
+  if two_stream_tape:
+    _two_stream_tape()
   from assembled_cnn_amd import dp, ops
   from assembled_cnn_amd.train import HParams, Trainer
   from tests.cpu_double import CpuDouble
@@ -105,9 +135,12 @@ def _worker(rank, world, port, out_dir):
   dist.destroy_process_group()
 
 
-def test_dp_world2_gloo(tmp_path):
+@pytest.mark.parametrize('two_stream_tape', [False, True], ids=['tape-order', 'biglittle-interleaved'])
+def test_dp_world2_gloo(tmp_path, two_stream_tape):
+  """second run: the tape order of the GPU (big branch of each BigLittle stage interleaved with the little branch, its
+  gradient-ready notifications deferred) under the same invariants -- real bucket launches over gloo while the tape runs"""
   port = _free_port()
-  mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  mp.spawn(_worker, args=(2, port, str(tmp_path), two_stream_tape), nprocs=2, join=True)
   assert (tmp_path / 'ok').exists()
 
 
