@@ -273,13 +273,16 @@ class Trainer(object):
     return loss_rows
 
   # ---- the step as ONE HIP graph -------------------------------------------------------------------------------------
-  def capture(self, images, labels, lam1=None, lam2=None, warmup: int = 2):
+  def capture(self, images, labels, lam1=None, lam2=None, warmup: int = 2, capture_error_mode: str = 'global'):
     """Record inputs -> forward -> loss -> backward (every launch of it, side streams included) into a HIP graph over
     static input buffers; train_step then copies its arguments into those buffers, replays the graph (one host call
     instead of ~850) and runs the exchange + optimiser as usual.  The step enqueues in ~18 ms of host time against ~27 ms of
     GPU time on a 5 GHz host: a slower host, or eight ranks sharing one, makes the eager step host-bound.
     Not available with DropBlock (its keep_prob and random draws change per step) or an attached gradient exchange
-    (bucket launches are interleaved with the backward by the host)."""
+    (bucket launches are interleaved with the backward by the host).  ``warmup`` real training steps run first (one-time
+    initialisation must not be recorded).  The graph keeps every activation of a step in its private memory pool until
+    release_graph(); ``capture_error_mode='thread_local'`` if other threads (an input pipeline) touch the device while
+    capturing.  ASM_* switches are frozen into the recording."""
     if self._graph is not None:
       raise RuntimeError('a step graph is already captured: release_graph() first')
     if self.keep_prob_fn is not None:
@@ -293,7 +296,7 @@ class Trainer(object):
       self.train_step(images, labels, lam1, lam2)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode=capture_error_mode):
       out = self._forward_backward(*static)
     self._graph, self._static, self._graph_out = g, static, out
     return self
