@@ -13,17 +13,30 @@ struct RowTiling {
   int vcb;        // vector columns handled concurrently (<= 256)
   int rpb;        // row lanes per block
   int rows_per_block;
-  int blocks;
+  int blocks;     // row blocks = partial rows per channel
+  int slices;     // channel slices: a workgroup reduces rows_per_block rows of ONE slice (grid = blocks * slices)
+  int vc_slice;   // vector columns per slice
 };
 
 RowTiling make_tiling(int M, int C) {
   RowTiling t;
   t.vcols = C / 8;
-  t.vcb = t.vcols < 256 ? t.vcols : 256;
+  // Channel slices (round 4).  The reducers want ~1024 workgroups (4 per CU: with 512 they ran at 4.4 TB/s, with 1024 at
+  // 5.7 TB/s -- occupancy-bound streaming), and until now every workgroup covered ALL channels of its rows: 1024 partial
+  // rows per channel, which the finalize kernel behind the reducer walks as a chain of dependent L2 round trips (16 rows
+  // per lane: 6.5 us for a launch that moves a few hundred KB, ~80 such launches per backward pass).  With the channels
+  // cut into slices of >= 64 (a row segment stays a whole 128-byte line) the same 1024 workgroups leave 1024 / slices
+  // partial rows per channel.  asm_tuning.bn_slices: 0 = this rule, n = at most n slices (1 = the old tiling).
+  int want = asm_tune().bn_slices;
+  if (want <= 0) want = 8;
+  int sl = t.vcols / 8;
+  if (sl > want) sl = want;
+  if (sl < 1) sl = 1;
+  t.slices = sl;
+  t.vc_slice = cdiv(t.vcols, sl);
+  t.vcb = t.vc_slice < 256 ? t.vc_slice : 256;
   t.rpb = 256 / t.vcb;
-  // <= 1024 partial rows = <= 1024 blocks = 4 workgroups (16 waves) per CU: with 512 the reducers ran at 4.4 TB/s,
-  // with 1024 at 5.7 TB/s (occupancy-bound streaming).  The finalize kernels read 1024 rows without a compaction pass.
-  const int cap = asm_tune().bn_rows;
+  const int cap = asm_tune().bn_rows / sl > 0 ? asm_tune().bn_rows / sl : 1;
   int rows = cdiv(M, cap);
   rows = cdiv(rows, t.rpb) * t.rpb;
   if (rows < t.rpb * 4) rows = t.rpb * 4;
@@ -46,14 +59,16 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
   const int vc0 = tid % t.vcb;
   const int rr = tid / t.vcb;
   const bool active = rr < t.rpb;
-  const int row_begin = blockIdx.x * t.rows_per_block;
+  const int rblk = blockIdx.x / t.slices, slice = blockIdx.x - rblk * t.slices;
+  const int vc_lo = slice * t.vc_slice, vc_hi = min(t.vcols, vc_lo + t.vc_slice);
+  const int row_begin = rblk * t.rows_per_block;
   const int row_end = min(M, row_begin + t.rows_per_block);
-  for (int vcbase = 0; vcbase < t.vcols; vcbase += t.vcb) {
+  for (int vcbase = vc_lo; vcbase < vc_hi; vcbase += t.vcb) {
     const int vc = vcbase + vc0;
     float s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
-    if (active && vc < t.vcols) {
+    if (active && vc < vc_hi) {
       float mu[8], is[8];
       if (MODE == 1) {
 #pragma unroll
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
       float acc = 0.f;
       for (int r = 0; r < t.rpb; ++r) acc += red[(which * t.rpb + r) * ncol + col];
       const int ch = vcbase * 8 + col;
-      if (ch < C) partial[((size_t)blockIdx.x * 2 + which) * C + ch] = acc;
+      if (ch < vc_hi * 8) partial[((size_t)rblk * 2 + which) * C + ch] = acc;
     }
   }
 }
@@ -443,14 +458,16 @@ __global__ __launch_bounds__(256) void rowreduce2_kernel(const bf16_t* __restric
   const int vc0 = tid % t.vcb;
   const int rr = tid / t.vcb;
   const bool active = rr < t.rpb;
-  const int row_begin = blockIdx.x * t.rows_per_block;
+  const int rblk = blockIdx.x / t.slices, slice = blockIdx.x - rblk * t.slices;
+  const int vc_lo = slice * t.vc_slice, vc_hi = min(t.vcols, vc_lo + t.vc_slice);
+  const int row_begin = rblk * t.rows_per_block;
   const int row_end = min(M, row_begin + t.rows_per_block);
-  for (int vcbase = 0; vcbase < t.vcols; vcbase += t.vcb) {
+  for (int vcbase = vc_lo; vcbase < vc_hi; vcbase += t.vcb) {
     const int vc = vcbase + vc0;
     float s[8], sa[8], sb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = sa[e] = sb[e] = 0.f;
-    if (active && vc < t.vcols) {
+    if (active && vc < vc_hi) {
       float ma[8], ia[8], mb[8], ib[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -506,14 +523,14 @@ __global__ __launch_bounds__(256) void rowreduce2_kernel(const bf16_t* __restric
       float acc = 0.f;
       for (int r = 0; r < t.rpb; ++r) acc += red[(which * t.rpb + r) * ncol + col];
       const int ch = vcbase * 8 + col;
-      if (ch < C) {
+      if (ch < vc_hi * 8) {
         if (which == 0) {
-          pa[((size_t)blockIdx.x * 2 + 0) * C + ch] = acc;
-          pb[((size_t)blockIdx.x * 2 + 0) * C + ch] = acc;
+          pa[((size_t)rblk * 2 + 0) * C + ch] = acc;
+          pb[((size_t)rblk * 2 + 0) * C + ch] = acc;
         } else if (which == 1) {
-          pa[((size_t)blockIdx.x * 2 + 1) * C + ch] = acc;
+          pa[((size_t)rblk * 2 + 1) * C + ch] = acc;
         } else {
-          pb[((size_t)blockIdx.x * 2 + 1) * C + ch] = acc;
+          pb[((size_t)rblk * 2 + 1) * C + ch] = acc;
         }
       }
     }
@@ -792,7 +809,7 @@ extern "C" int asm_bn_stats_blocks(int M, int C) {
 extern "C" int asm_bn_stats(const void* x, int M, int C, float* stats_partial, void* stream) {
   ASM_REQUIRE(x && stats_partial && M > 0 && C > 0 && C % 8 == 0, "bn_stats: bad arguments (M=%d C=%d)", M, C);
   RowTiling t = make_tiling(M, C);
-  ASM_LAUNCH((rowreduce_kernel<0>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream,
+  ASM_LAUNCH((rowreduce_kernel<0>), dim3(t.blocks * t.slices), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, nullptr, nullptr, 0, M, C, nullptr, nullptr, t, stats_partial);
   ASM_CHECK_LAUNCH("bn_stats");
   return ASM_OK;
@@ -860,7 +877,7 @@ extern "C" int asm_bn_bwd_reduce(const void* dy, const void* x, const void* yout
   ASM_REQUIRE(dy && x && mean && invstd && partial && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
   ASM_REQUIRE(relu >= 0 && relu <= 2 && (!relu || yout), "bn_bwd_reduce: relu mask needs the forward output / bitmask");
   RowTiling t = make_tiling(M, C);
-  ASM_LAUNCH((rowreduce_kernel<1>), dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH((rowreduce_kernel<1>), dim3(t.blocks * t.slices), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (const bf16_t*)x, (const bf16_t*)yout, relu, M, C, mean, invstd, t, partial);
   ASM_CHECK_LAUNCH("bn_bwd_reduce");
   return ASM_OK;
@@ -939,7 +956,7 @@ extern "C" int asm_bn_bwd_reduce2(const void* dy, const void* xa, const void* xb
   ASM_REQUIRE(dy && xa && xb && relu_mask && mean_a && invstd_a && mean_b && invstd_b && partial_a && partial_b && M > 0 &&
                   C > 0 && C % 8 == 0, "bn_bwd_reduce2: bad arguments");
   RowTiling t = make_tiling(M, C);
-  ASM_LAUNCH(rowreduce2_kernel, dim3(t.blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+  ASM_LAUNCH(rowreduce2_kernel, dim3(t.blocks * t.slices), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                      (const bf16_t*)xa, (const bf16_t*)xb, relu_mask, M, C, mean_a, invstd_a, mean_b, invstd_b, t, partial_a,
                      partial_b);
   ASM_CHECK_LAUNCH("bn_bwd_reduce2");

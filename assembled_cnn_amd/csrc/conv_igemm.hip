@@ -828,6 +828,230 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// igemm3_kernel: 3x3 / stride 1 / pad 1 (fprop and its input gradient) with the ACTIVATION rows resident across the taps.
+//
+// Over the flattened pixel index m = (img, h, w) a 3x3 stride-1 convolution reads, for tap (r, s), the pixel
+// m + (r - 1) * W + (s - 1): the nine taps are nine LINEAR row shifts of one [M][C] matrix, and what zero padding adds is
+// a per-(pixel, tap) predicate (row / column of the tap outside the image), not a different address pattern.  igemm2
+// stages a fresh 128-row activation tile for every tap (9 x 16 KB per 64-channel chunk, nearly all of it the same pixels
+// again, through L2 -> LDS); here the 128 + 2 W + 2 rows the nine taps touch are LDS-DMA'd ONCE per 64-channel chunk
+// (double-buffered over chunks: the next chunk's rows arrive one 32-row piece per tap under the current chunk's MFMAs),
+// only the filter tile is streamed per tap, and a tap's activation fragment is a ds_read_b128 at a shifted row.  An
+// out-of-image tap redirects the lane's fragment address to an all-zero row (one v_cndmask per tap and 32-row tile; the
+// predicate bits are computed once per workgroup).  LDS-DMA traffic per chunk: 24 + 9 x 16 KB instead of 9 x 32 KB.
+// Measured on the standalone probe (tools/probes/conv_probe.hip, MI355X, same box, plain epilogue): 14x14x512 -> 1024
+// 464 -> 396 us, 14x14x256 -> 512 126 -> 115, 28x28x128 -> 256 138 -> 122, 7x7x256 -> 512 35.6 -> 32.7 us against the
+// best gather-form tile of each layer; with the filter DMA as the only per-step traffic the loop runs within 4 % of its
+// own MFMA + LDS-read time.  80 KB of LDS: two workgroups per CU, so one's epilogue runs under the other's main loop.
+// Requires Ci % 64 == 0, at least two chunks (a single chunk has nothing to prefetch under), W <= 30, dense NHWC input.
+constexpr int H3_ROWS = 192;   // halo rows per buffer (128 + 2 W + 2 <= 191: the last row is never written -> stays zero)
+
+template <int BN, bool STATS, bool PFA>
+__global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
+  constexpr int BM = 128, BK = 64, WGM = 2, WGN = 2;
+  using C = Cfg<BM, BN, BK, WGM, WGN, false, STATS, 2>;
+  constexpr int RPP = C::RPP, ROWB = C::ROWB, WP = C::WP;
+  constexpr int TM = C::TM, TN = C::TN, WTM = C::WTM, WTN = C::WTN;
+  constexpr int HP = H3_ROWS / RPP;                 // halo pieces per wave and chunk
+  constexpr int HALO = H3_ROWS * ROWB, WST = BN * ROWB;
+  constexpr int KK = BK / 16, NTAP = 9;
+  constexpr unsigned ZERO_ROW = (unsigned)(H3_ROWS - 1) * ROWB;
+  static_assert(RPP == 32 && H3_ROWS % RPP == 0 && HP <= NTAP - 1, "halo pieces are issued one per tap");
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // halo[2] | filter ring[2]; reused by the epilogue
+  unsigned char* const wring = smem + 2 * HALO;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  int logical;
+  {
+    const int nb = p.n_blocks, q = nb >> 3, r = nb & 7;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = (int)fd_div((unsigned)logical, p.fd_ntn);
+  const int tile_n = logical - tile_m * p.n_tiles_n;
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+  const int chunk = tid & 7, r0 = tid >> 3;
+  const int csw = (chunk ^ swz<BK>(r0)) << 3;      // the source-side swizzle (RPP % 16 == 0: the same for every pass)
+  const int Wd = p.Wi;
+  const int hrows = BM + 2 * Wd + 2;
+
+  // ---- prologue: halo / filter source offsets, per-(pixel, tap) predicates ----
+  unsigned vh[HP];
+#pragma unroll
+  for (int j = 0; j < HP; ++j) {
+    const int hr = r0 + j * RPP;
+    const int g = tile_m * BM - (Wd + 1) + hr;      // pixel of halo row hr
+    vh[j] = (hr < hrows && g >= 0 && g < p.M) ? ((unsigned)g * (unsigned)p.Ci + (unsigned)csw) * 2u : ASM_OOB;
+  }
+  unsigned vw[WP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    const int n = tile_n * BN + r0 + j * RPP;
+    vw[j] = n < p.Co ? ((unsigned)n * (unsigned)p.w_row_pitch + (unsigned)csw) * 2u : ASM_OOB;
+  }
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // loop tap t = (r, s) reads the pixel (h + ts * (r - 1), w + ts * (s - 1)), ts = +1 (fprop) / -1 (input gradient)
+  unsigned vmask[TM];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int m = tile_m * BM + wm * WTM + b * 32 + l31;
+    const unsigned mm = m < p.M ? (unsigned)m : 0u;
+    const unsigned img = fd_div(mm, p.fd_howo);
+    const unsigned rem = mm - img * (unsigned)p.HoWo;
+    const int h = (int)fd_div(rem, p.fd_wo);
+    const int w = (int)rem - h * p.Wo;
+    unsigned mk = 0;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      const int dr = p.tsign * (t / 3 - 1), ds = p.tsign * (t % 3 - 1);
+      const bool ok = m < p.M && (unsigned)(h + dr) < (unsigned)p.Hi && (unsigned)(w + ds) < (unsigned)p.Wi;
+      mk |= (ok ? 1u : 0u) << t;
+    }
+    vmask[b] = mk;
+  }
+  const int wrow0 = wave * 8;
+  const unsigned tapw = (unsigned)p.Ci * 2u;
+
+  auto issue_halo = [&](int hb, unsigned xso, const int j) {
+    unsigned char* hs = smem + hb * HALO;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(hs + (j * RPP + wrow0) * ROWB), 16, (int)vh[j], (int)xso, 0, 0);
+  };
+  auto issue_w = [&](int stage, unsigned wso, const int lo, const int hi) {
+    unsigned char* ws = wring + stage * WST;
+#pragma unroll
+    for (int j = 0; j < WP; ++j)
+      if (j >= lo && j < hi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(ws + (j * RPP + wrow0) * ROWB), 16, (int)vw[j], (int)wso, 0, 0);
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  unsigned fwo[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int rw_ = wn * WTN + l31;
+    fwo[kk] = rw_ * ROWB + (((kk * 2 + lhi) ^ swz<BK>(rw_)) << 4);
+  }
+  const int xrow0 = wm * WTM + l31;     // halo row of this lane's first pixel at the shift (-1, -1)
+  // byte offsets (inside a halo buffer) of this lane's activation fragments for loop tap t, k-substep 0; the swizzle is
+  // keyed on the halo row (+32 rows keep it), an out-of-image tap reads the zero row
+  unsigned xbv[TM];
+  auto set_tap = [&](const int t) {
+    const int dr = p.tsign * (t / 3 - 1), ds = p.tsign * (t % 3 - 1);
+    const int row = xrow0 + (dr + 1) * Wd + (ds + 1);
+    const unsigned xb = (unsigned)row * ROWB + ((unsigned)(lhi ^ swz<BK>(row)) << 4);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) xbv[b] = ((vmask[b] >> t) & 1u) ? xb + (unsigned)(b * 32 * ROWB) : ZERO_ROW;
+  };
+  bf16x8 fwb[2][TN], fxb[2][TM];
+  auto load_frags = [&](int hb, int stage, const int kk, const int buf) {
+    const unsigned char* ws = wring + stage * WST;
+    const unsigned char* hs = smem + hb * HALO;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) fwb[buf][a] = *reinterpret_cast<const bf16x8*>(ws + fwo[kk] + a * 32 * ROWB);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) fxb[buf][b] = *reinterpret_cast<const bf16x8*>(hs + (xbv[b] ^ (unsigned)(kk << 5)));
+  };
+  auto mma = [&](const int buf) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwb[buf][a], fxb[buf][b], acc[a][b], 0, 0, 0);
+  };
+  auto tap_off = [&](const int t) -> unsigned { return (unsigned)(p.wt0 + (t / 3) * p.wtr + (t % 3) * p.wts) * tapw; };
+
+  {
+    // ---- chunk 0's rows + the first filter tile; then one barrier per (chunk, tap) step.  A step opens with the barrier
+    // that publishes its filter tile, issues the NEXT step's DMA at once (a whole step of MFMAs to land under: with only
+    // 4 + 1 pieces per wave, spreading them over the step as igemm2 does leaves the last ones ~200 cycles before the wait)
+    // and runs the previous step's last MFMA group under its own first fragment reads ----
+#pragma unroll
+    for (int j = 0; j < HP; ++j) issue_halo(0, 0u, j);
+    issue_w(0, tap_off(0), 0, WP);
+#pragma unroll
+    for (int a = 0; a < TN; ++a) fwb[(KK - 1) & 1][a] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};   // the first "previous group" adds 0
+#pragma unroll
+    for (int b = 0; b < TM; ++b) fxb[(KK - 1) & 1][b] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    int cur = 0, hb = 0;
+    unsigned kcb = 0;
+#pragma unroll 1
+    for (int kc = 0; kc < p.kchunks; ++kc) {
+      const bool has_next = kc + 1 < p.kchunks;
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // this step's filter tile (at tap 0: this chunk's rows) visible; the
+                                                 // stage / rows the DMA below overwrites have been read by every wave
+        set_tap(t);
+        load_frags(hb, cur, 0, 0);
+        mma((KK - 1) & 1);
+        const bool more = (t + 1 < NTAP) || has_next;
+        const int tn = (t + 1 < NTAP) ? t + 1 : 0;           // compile time after unrolling
+        if (has_next && t < HP) issue_halo(hb ^ 1, kcb + BK * 2, t);
+        if (more) issue_w(cur ^ 1, (t + 1 < NTAP ? kcb : kcb + BK * 2) + tap_off(tn), 0, WP);
+#pragma unroll
+        for (int kk = 0; kk + 1 < KK; ++kk) {
+          load_frags(hb, cur, kk + 1, (kk + 1) & 1);
+          mma(kk & 1);
+        }
+        cur ^= 1;
+      }
+      kcb += BK * 2;
+      hb ^= 1;
+    }
+    mma((KK - 1) & 1);
+  }
+  __syncthreads();   // every wave's fragment reads are done: the epilogue reuses the region
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, false, STATS, PFA, false>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+}
+
+template <int BN, bool STATS, bool PFA>
+int launch3_one(const IGemmArgs& a, hipStream_t st) {
+  using C = Cfg<128, BN, 64, 2, 2, false, STATS, 2>;
+  constexpr int LDS = cmax(cmax(2 * H3_ROWS * 128 + 2 * BN * 128, C::EPI), C::RED);
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  auto kern = igemm3_kernel<BN, STATS, PFA>;
+  static bool attr_done[ASM_MAX_DEVICES] = {};
+  if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done); e != hipSuccess)
+    ASM_FAIL(ASM_EHIP, "igemm3_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
+  ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(256), LDS, st, a);
+  ASM_CHECK_LAUNCH("igemm3_kernel");
+  return ASM_OK;
+}
+
+// returns 1 when the layer is not one igemm3_kernel covers
+int try_igemm3(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
+  if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.pool_dy) return 1;
+  if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return 1;
+  if (a.wt0 != 0 || a.wtr != 3 || a.wts != 1) return 1;
+  if (a.Ci % 64 || a.Ci < 128 || a.Co <= 64 || a.Wi > (H3_ROWS - 1 - 128 - 2) / 2) return 1;
+  if (a.HoWo != a.Hi * a.Wi || a.Wo != a.Wi || a.M % a.HoWo) return 1;
+  if (a.x_pix_pitch != a.Ci || a.x_row_pitch != a.Wi * a.Ci || a.x_img_pitch != a.Hi * a.Wi * a.Ci) return 1;
+  a.n_tiles_n = cdiv(a.Co, 128);
+  a.n_blocks = cdiv(a.M, 128) * a.n_tiles_n;
+  a.kchunks = a.Ci / 64;
+  a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
+  const int pfa_env = asm_tune().igemm_pfa;
+  const bool pfa = a.addend != nullptr && (pfa_env >= 0 ? pfa_env != 0 : a.n_blocks <= 1024);
+  if (stats) return launch3_one<128, true, false>(a, st);
+  if (pfa) return launch3_one<128, false, true>(a, st);
+  return launch3_one<128, false, false>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // conv_halo_kernel: stride-1 3x3 convolution (and its input gradient) for the NARROW high-resolution layers
 // (Ci in {32, 64}, 112 x 112 maps: the BigLittle module-0 / ResNet-D stem convolutions).
 // The gather-GEMM stages one activation tile PER TAP, so the 9 taps of a 3x3 read (almost) the same pixels 9 times
@@ -1159,6 +1383,18 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
     bool bigv = heavy && a.Co >= 256 && b256v >= 192;
     if (ftile == 1) bigv = false;
     if (ftile == 3 && a.Ci % 64 == 0) bigv = true;
+    // igemm3_kernel (128 x 128 tiles, activation rows resident across the taps, two workgroups per CU) against igemm2
+    // (tools/conv_bench.py --iters 50, same box, steady state): it wins wherever igemm2 would run 128-row tiles
+    // (28x28x128 -> 256 input gradient 124 -> 112 us, 7x7x256 -> 512 37 -> 35 / 48.6 -> 40, 7x7x512 -> 1024 input gradient
+    // 114 -> 108, 14x14x128 -> 256 input gradient 35.8 -> 33.2) and on the 784-tile short-reduction forward layer
+    // (28x28x128 -> 256: 131 -> 117.5); against the 256 x 256 tile it loses 3 - 15 % where that tile fills the chip
+    // (its 8-wave loop reads 0.75 instead of 1 LDS fragment per MFMA and has half the barriers), so those stay.
+    // asm_tuning.igemm3 = 2 forces it wherever the shape allows (tests).
+    const int h3 = asm_tune().igemm3;
+    if (ftile == 0 && h3 && (h3 == 2 || !bigv || (b256v >= 768 && a.Ci <= 128))) {
+      rc = try_igemm3(a, out_f32, stats, st);
+      if (rc != 1) return rc;
+    }
     // Small-M, deep-K layers (7x7 maps at batch 256: 98 row tiles): with 128 x 128 tiles a 256-channel output makes only
     // 196 workgroups for the 512 resident slots; 128 x 64 tiles double the workgroup count (ASM_IGEMM_SMALLM=1, A/B knob).
     const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Co, 128);

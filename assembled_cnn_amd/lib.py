@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ASM_HIP_LIB') or os.path.join(HERE, 'libasm_hip.so')
 
 ASM_OK, ASM_EINVAL, ASM_ENOTSUP, ASM_EHIP = 0, -1, -2, -3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class AsmError(RuntimeError):
@@ -63,7 +63,7 @@ class Tuning(C.Structure):
   """struct asm_tuning: the kernel-selection overrides (the library itself reads no environment variable)"""
   _fields_ = [(n, C.c_int32) for n in (
       'igemm_mode', 'igemm_tile', 'igemm_v2', 'conv_halo', 'igemm_smallm', 'igemm_pfa', 'igemm_bk64_1x1', 'dgrad_parity',
-      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched')] + [('reserved', C.c_int32 * 6)]
+      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched', 'igemm3', 'bn_slices')] + [('reserved', C.c_int32 * 4)]
 
 
 # environment variable of the HOST -> asm_tuning field (same-box A/B runs, tests); unset = the library's default
@@ -71,7 +71,7 @@ TUNING_ENV = {'ASM_IGEMM_MODE': 'igemm_mode', 'ASM_IGEMM_TILE': 'igemm_tile', 'A
               'ASM_CONV_HALO': 'conv_halo', 'ASM_IGEMM_SMALLM': 'igemm_smallm', 'ASM_IGEMM_PFA': 'igemm_pfa',
               'ASM_IGEMM_BK64_1X1': 'igemm_bk64_1x1', 'ASM_DGRAD_PARITY': 'dgrad_parity', 'ASM_WGRAD_HALO': 'wgrad_halo',
               'ASM_WGRAD_BIG': 'wgrad_big', 'ASM_WGRAD_SPLITS': 'wgrad_splits', 'ASM_WGRAD_LINEAR': 'wgrad_linear',
-              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched'}
+              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched', 'ASM_IGEMM3': 'igemm3', 'ASM_BN_SLICES': 'bn_slices'}
 
 
 def apply_env_tuning(lib) -> 'Tuning':
@@ -217,14 +217,19 @@ def load(path: str = LIB_PATH) -> C.CDLL:
   # devices, streams or allocations ("no ROCm-capable device is detected" at the first launch on a healthy GPU).
   import torch  # noqa: F401
   lib = C.CDLL(path)
+  # the version check comes first: a stale build must report the ABI mismatch, not a missing symbol
+  ver = getattr(lib, 'asm_abi_version', None)
+  if ver is None:
+    raise AsmError('%s does not export asm_abi_version: not a libasm_hip.so' % path)
+  ver.restype, ver.argtypes = C.c_int, []
+  if ver() != ABI_VERSION:
+    raise AsmError('libasm_hip.so ABI version %d != %d (rebuild: python -m assembled_cnn_amd.build)' % (ver(), ABI_VERSION))
   for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
     fn = getattr(lib, name, None)
     if fn is None:
       raise AsmError('libasm_hip.so does not export %s' % name)
     fn.restype = res
     fn.argtypes = args
-  if lib.asm_abi_version() != ABI_VERSION:
-    raise AsmError('libasm_hip.so ABI version %d != %d' % (lib.asm_abi_version(), ABI_VERSION))
   apply_env_tuning(lib)
   _lib = lib
   return lib

@@ -35,7 +35,7 @@ extern "C" {
 #define ASM_ENOTSUP (-2)
 #define ASM_EHIP (-3)
 
-#define ASM_ABI_VERSION 1
+#define ASM_ABI_VERSION 2
 
 const char* asm_last_error(void);
 int asm_abi_version(void);
@@ -62,7 +62,12 @@ typedef struct asm_tuning {
   int32_t bn_rows;         /* partial rows (= workgroups) of the batch-norm reducers                                       */
   int32_t conv_sched;      /* LDS-DMA issue of the MFMA conv kernels: 0 per layer (3x3: spread between the MFMA groups,
                               1x1: all at the head of the step); 1: always spread; 2: never                              */
-  int32_t reserved[6];
+  int32_t igemm3;          /* 3x3 stride-1 layers with >= 128 input channels on maps up to 30 wide with the activation rows
+                              resident across the nine taps (igemm3_kernel): 1: where it measured faster than igemm2's
+                              tile for the layer; 2: wherever the shape allows; 0: never                                */
+  int32_t bn_slices;       /* channel slices of the batch-norm reducers (fewer partial rows per channel for the finalize
+                              kernels): 0: C / 64 capped at 8; n: capped at n (1: every workgroup covers all channels)   */
+  int32_t reserved[4];
 } asm_tuning;
 void asm_tuning_defaults(asm_tuning* t);
 int asm_set_tuning(const asm_tuning* t);

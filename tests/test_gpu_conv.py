@@ -58,6 +58,10 @@ SHAPES = [
     (2, 16, 32, 64, 32, 3, 1),      # conv_halo_kernel: 8 x 16 patches with a resident halo, Ci 64 -> 32
     (3, 8, 16, 32, 64, 3, 1),       # conv_halo_kernel: one patch per image, Ci 32 -> 64
     (1, 24, 48, 32, 32, 3, 1),      # conv_halo_kernel: 3 x 3 patches, Ci 32 -> 32
+    (2, 14, 14, 128, 256, 3, 1),    # igemm3_kernel (rows resident across the taps): 2 chunks, 4 row tiles with a ragged last one
+    (5, 7, 7, 192, 136, 3, 1),      # igemm3_kernel: 3 chunks, K tail inside the second N tile (136 = 128 + 8), images inside a tile
+    (1, 9, 30, 128, 128, 3, 1),     # igemm3_kernel: widest map it takes (W = 30), H != W
+    (3, 5, 11, 256, 72, 3, 1),      # igemm3_kernel: narrow N tile (72 of 128), 4 chunks, odd H / W
 ]
 
 
@@ -402,3 +406,36 @@ def test_dgrad_with_pooled_gradient_gathered_in_the_epilogue(hip_lib, shape, poo
   ref = ref + pz.permute(0, 2, 3, 1).reshape(-1, Cn)
   assert util.rel_l2(fused.float().cpu().view(-1, Cn), ref) <= 4e-3
   assert util.max_abs(fused.float().cpu().view(-1, Cn), ref) <= float(ref.abs().max()) * 2 ** -7 + 1e-6
+
+
+IGEMM3_SHAPES = [(2, 14, 14, 128, 256), (5, 7, 7, 192, 136), (1, 9, 30, 128, 128), (3, 5, 11, 256, 72), (4, 28, 28, 128, 256),
+                 (16, 14, 14, 512, 1024)]
+
+
+@pytest.mark.parametrize('shape', IGEMM3_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_igemm3_is_igemm2_bit_for_bit(hip_lib, shape, monkeypatch):
+  """igemm3_kernel keeps the activation rows resident across the nine taps instead of re-staging a tile per tap; the
+  products are accumulated in the same (chunk, tap, k) order as igemm2_kernel's, so every output (forward with its fused
+  statistics, input gradient plain / with a fan-in addend / with a masked addend) must be IDENTICAL, border pixels, ragged
+  row tiles and channel tails included."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K = shape
+  x = _rand((N, H, W, Cn), 11).cuda()
+  w = _rand((K, 3, 3, Cn), 12, scale=(1.0 / (9 * Cn)) ** 0.5).cuda()
+  dy = _rand((N, H, W, K), 13).cuda()
+  addend = _rand((N, H, W, Cn), 14).cuda()
+  mask = torch.randint(0, 256, (N, H, W, Cn // 8), dtype=torch.uint8, generator=torch.Generator().manual_seed(15)).cuda()
+  d = ops.make_conv_desc(N, H, W, Cn, K, 3, 3, 1)
+  wt = torch.zeros((Cn, 3, 3, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w, wt, K, 3, 3, Cn)
+  outs = {}
+  for knob in ('2', '0'):
+    util.set_knob(monkeypatch, 'ASM_IGEMM3', knob)
+    y, st = ops.conv_fprop(d, x, w, want_stats=True)
+    y2, _ = ops.conv_fprop(d, x, w, want_stats=False)
+    dx = ops.conv_dgrad(d, dy, wt)
+    dxa = ops.conv_dgrad(d, dy, wt, addend=addend)
+    dxm = ops.conv_dgrad(d, dy, wt, addend=addend, addend_mask=mask)
+    outs[knob] = (y, st, y2, dx, dxa, dxm)
+  for a, b, name in zip(outs['2'], outs['0'], ('fprop', 'stats', 'fprop-nostats', 'dgrad', 'dgrad+addend', 'dgrad+masked')):
+    assert torch.equal(a, b), name

@@ -20,6 +20,7 @@ def main():
   ap.add_argument('--batch', type=int, default=256)
   ap.add_argument('--iters', type=int, default=10)
   ap.add_argument('--only', default='')
+  ap.add_argument('--uniform', action='store_true', help='uniform [-1, 1) operands instead of normal ones')
   args = ap.parse_args()
   shapes = [(k, c) for k, c in conv_shapes(args.workload, args.batch).items() if not k[8]]
 
@@ -37,9 +38,11 @@ def main():
   for k, cnt in shapes:
     N, H, W, Cn, K, R, S, st, _ = k
     d = ops.make_conv_desc(N, H, W, Cn, K, R, S, st)
-    x = torch.randn((N, H, W, Cn), generator=g, device='cuda').to(torch.bfloat16)
-    w = (torch.randn((K, R, S, Cn), generator=g, device='cuda') * (R * S * Cn) ** -0.5).to(torch.bfloat16)
-    dy = torch.randn((N, d.Ho, d.Wo, K), generator=g, device='cuda').to(torch.bfloat16)
+    rnd = (lambda shp: torch.rand(shp, generator=g, device='cuda') * 2 - 1) if args.uniform else (
+        lambda shp: torch.randn(shp, generator=g, device='cuda'))
+    x = rnd((N, H, W, Cn)).to(torch.bfloat16)
+    w = (rnd((K, R, S, Cn)) * (R * S * Cn) ** -0.5).to(torch.bfloat16)
+    dy = rnd((N, d.Ho, d.Wo, K)).to(torch.bfloat16)
     wt = torch.zeros((Cn, R, S, K), dtype=torch.bfloat16, device='cuda')
     ops.filter_transpose(w, wt, K, R, S, Cn)
     dw = torch.empty((K, R, S, Cn), dtype=torch.float32, device='cuda')

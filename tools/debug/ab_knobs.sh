@@ -1,0 +1,18 @@
+# same-box A/B of kernel-selection knobs on the whole step: bash tools/debug/ab_knobs.sh LABEL=ENV=VAL[,ENV=VAL] ...
+# (on the GPU box; ~12 s per line, every configuration twice, interleaved)
+mkdir -p gpurun_out
+out=gpurun_out/ab_knobs.log
+: > $out
+run() { # label, env...
+  lab=$1; shift
+  r=$(env "$@" python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-roofline --no-gradsync 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('single_stream',{}).get('ms_per_step'))")
+  echo "$lab $r" >> $out
+}
+for i in 1 2; do
+  run default A=1
+  for spec in "$@"; do
+    lab=${spec%%=*}; envs=${spec#*=}
+    run $lab $(echo $envs | tr ',' ' ')
+  done
+done
+cat $out
