@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void sk_bn_bwd_reduce_kernel(const bf16_t* __r
       for (int q = 0; q < U; ++q) {
         const int rq = r + q * g.rpb;
         const size_t m = (size_t)n * g.HW + (rq < r_end ? rq : r);
-        vy[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + m * C2 + vc * 8));
+        vy[q] = *reinterpret_cast<const u32x4*>(y + m * C2 + vc * 8);   // plain: the apply pass behind re-reads y (bn.hip)
         vg[q] = ldv(dv, m * g.F + cv * 8);
       }
 #pragma unroll
