@@ -17,10 +17,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // ---- error plumbing -------------------------------------------------------------------------
 void asm_set_error(const char* fmt, ...);
-#define ASM_FAIL(code, ...)      \
-  do {                           \
-    asm_set_error(__VA_ARGS__);  \
-    return (code);               \
+// launches of this thread that have not reached their ASM_CHECK_LAUNCH yet (see below); any error return resets it, so a
+// path that leaves between ASM_LAUNCH and the check cannot leave later argument checks blind to stale sticky errors
+inline thread_local int asm_unchecked_launches = 0;
+#define ASM_FAIL(code, ...)       \
+  do {                            \
+    asm_set_error(__VA_ARGS__);   \
+    asm_unchecked_launches = 0;   \
+    return (code);                \
   } while (0)
 // hipGetLastError() is STICKY per host thread across ALL HIP users of the process: an error some other component left
 // behind (PyTorch probing devices / peers, a collective library, ...) would be reported by ASM_CHECK_LAUNCH as the
@@ -28,7 +32,6 @@ void asm_set_error(const char* fmt, ...);
 // argument checks at the top of an entry point are where that stale state is dropped -- but ONLY while this thread has no
 // launch of its own waiting for its ASM_CHECK_LAUNCH (asm_unchecked_launches, counted by ASM_LAUNCH): an ASM_REQUIRE that
 // a later edit places after a launch can therefore never swallow that launch's error.
-inline thread_local int asm_unchecked_launches = 0;
 #define ASM_LAUNCH(...)             \
   do {                              \
     ++asm_unchecked_launches;       \

@@ -426,6 +426,11 @@ extern "C" int asm_dense_small(const void* p, int ldp, const void* q, int ldq, i
   ASM_REQUIRE(K % 16 == 0 && ldp % 8 == 0 && ldq % 8 == 0 && ldp >= K && ldq >= K,
               "dense_small: the reduction must be a multiple of 16 and rows 16-byte aligned (K=%d ldp=%d ldq=%d)", K, ldp, ldq);
   ASM_REQUIRE(ldo >= N && ldo % 4 == 0, "dense_small: bad output row stride %d", ldo);
+  // `out` owns its whole rows: the pad columns N .. ldo-1 are WRITTEN (zeros) by the 32-column tile that holds column
+  // N-1, so the padding must end inside that tile -- a wider row (a column slice of a larger matrix) is refused rather
+  // than half-zeroed or clobbered
+  ASM_REQUIRE(ldo <= cdiv(N, 32) * 32, "dense_small: row stride %d pads N=%d past its last 32-column tile (out must own whole rows "
+              "with fewer than 32 pad columns)", ldo, N);
   ASM_REQUIRE(aligned16(p) && aligned16(q) && aligned16(out) && (!addend || aligned16(addend)), "dense_small: unaligned pointer");
   DenseArgs a;
   a.p = (const bf16_t*)p; a.q = (const bf16_t*)q; a.out = out; a.addend = (const bf16_t*)addend;

@@ -30,7 +30,7 @@ DEFER_BN = os.environ.get('ASM_BN_DEFER', '1') != '0'
 
 
 def dual_bn_on() -> bool:
-  """ASM_BN_DUAL=0: two separate batch-norm backwards for a projection block (A/B runs, tests); read per call"""
+  """ASM_BN_DUAL=0: two separate batch-norm backwards for a projection block (A/B runs, tests); cached until ops.refresh_tuning()"""
   return ops.knob('ASM_BN_DUAL', '1') != '0'
 
 
@@ -131,7 +131,9 @@ class ParamArena(object):
       # backward graph, independent of each other) may also overlap each other.  Same box, ms per step: 1 stream 27.09 /
       # 27.13, 2 streams 26.96 / 26.96, 3 streams 27.07; no side stream 27.40.
       n = max(1, int(ops.knob('ASM_WGRAD_STREAMS', '2')))
-      self._sides = [torch.cuda.Stream(device=self.w32.device) for _ in range(n)]
+      # ASM_WGRAD_PRIO: HIP stream priority of the weight-gradient streams (-1 high, 0 normal, 1 low)
+      prio = int(ops.knob('ASM_WGRAD_PRIO', '0'))
+      self._sides = [torch.cuda.Stream(device=self.w32.device, priority=prio) for _ in range(n)]
       self._side_rr = 0
       self.side_stream = self._sides[0]
 

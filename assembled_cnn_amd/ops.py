@@ -77,23 +77,27 @@ _RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 _CUR_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
 
 
-_STREAM_OVERRIDE = None
+import threading  # noqa: E402
+
+# per host THREAD: an input-pipeline or evaluation thread that calls ops while the training thread has a weight gradient
+# redirected to a side stream keeps launching on its own current stream
+_TLS = threading.local()
 
 
 def launch_on(stream: Optional["torch.cuda.Stream"]):
-  """Every following C-ABI call goes to ``stream`` instead of torch's current stream (None = back to the current stream).
-  For launch-only regions -- nothing inside may allocate through torch, whose caching allocator keys blocks by ITS current
-  stream: the weight-gradient side stream uses it instead of a ``with torch.cuda.stream(...)`` block (~15 us of host time
-  per use, 117 uses per step)."""
-  global _STREAM_OVERRIDE
-  _STREAM_OVERRIDE = None if stream is None else stream.cuda_stream
+  """Every following C-ABI call OF THIS THREAD goes to ``stream`` instead of torch's current stream (None = back to the
+  current stream).  For launch-only regions -- nothing inside may allocate through torch, whose caching allocator keys
+  blocks by ITS current stream: the weight-gradient side stream uses it instead of a ``with torch.cuda.stream(...)`` block
+  (~15 us of host time per use, 117 uses per step)."""
+  _TLS.stream = None if stream is None else stream.cuda_stream
 
 
 def _stream() -> int:
   if _IS_DOUBLE:
     return 0
-  if _STREAM_OVERRIDE is not None:
-    return _STREAM_OVERRIDE
+  ov = getattr(_TLS, 'stream', None)
+  if ov is not None:
+    return ov
   if _RAW_STREAM is not None and _CUR_DEVICE is not None:
     return _RAW_STREAM(_CUR_DEVICE())
   return torch.cuda.current_stream().cuda_stream
@@ -193,7 +197,7 @@ def _bn_ev(nbytes):
 
 
 def dense_small_on() -> bool:
-  """ASM_DENSE_SMALL=0 keeps the [N,1,1,C] layers on the implicit-GEMM convolution (A/B runs, tests); read per call."""
+  """ASM_DENSE_SMALL=0 keeps the [N,1,1,C] layers on the implicit-GEMM convolution (A/B runs, tests); cached until refresh_tuning()."""
   return knob('ASM_DENSE_SMALL', '1') != '0'
 
 

@@ -241,8 +241,10 @@ int asm_bn_small_bwd(const void* dy, const void* x, const uint8_t* relu_mask, in
  *                           accumulation, out f32 or bf16 with row stride ldo.  K % 16 == 0; ldp, ldq % 8 == 0.
  *                           fprop: p = x [M][Cin], q = kernel [Cout][Cin]; input gradient: p = dy [M][ldy], q = the
  *                           CRSK copy [Cin][ldk] (asm_filter_transpose), K = ldk.
- *                           Columns N .. ldo-1 of a padded output row (the classifier's 1001 -> 1008) are written as
- *                           zeros, so whole-row readers (isfinite checks, taps) never see uninitialised memory.
+ *                           `out` owns whole rows: columns N .. ldo-1 of a padded output row (the classifier's 1001 ->
+ *                           1008) are WRITTEN as zeros, so whole-row readers (isfinite checks, taps) never see
+ *                           uninitialised memory; ldo <= 32 * ceil(N / 32) (ASM_EINVAL otherwise: a column slice of a
+ *                           wider matrix is not a valid output).
  *   asm_dense_small_wgrad:  dw[n][k] = sum_m dy[m][n] * x[m][k]  (fp32 [Cout][ldw]; x [M][ldx], dy [M][ldy]).
  * (The one-launch dense + batch-norm forms, measured slower than these + asm_bn_small_*, are in asm_hip_debug.h.) */
 int asm_dense_small(const void* p, int ldp, const void* q, int ldq, int M, int N, int K, void* out, int ldo,

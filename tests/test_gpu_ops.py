@@ -480,6 +480,18 @@ def test_dense_small_vs_fp32(hip_lib, M, N, K, ldo, f32, addend):
   assert bool((got[:, N:] == 0.0).all()), 'pad columns N .. ldo-1 are written as zeros (include/asm_hip.h)'
 
 
+def test_dense_small_refuses_a_row_stride_it_cannot_zero(hip_lib):
+  """`out` owns whole rows and its pad columns are written as zeros by the tile that holds column N-1: a row stride beyond
+  that tile (a column slice of a wider matrix, or > 31 pad columns) is an argument error, not a half-zeroed row"""
+  from assembled_cnn_amd.ops import L, _ptr, _stream
+  from assembled_cnn_amd import lib
+  p, q = _rand((32, 64), 1).cuda(), _rand((32, 64), 2).cuda()
+  out = torch.full((32, 64), 7.0, dtype=torch.float32).cuda()
+  assert L().asm_dense_small(_ptr(p), 64, _ptr(q), 64, 32, 32, 64, _ptr(out), 64, 1, None, _stream()) == lib.ASM_EINVAL
+  assert bool((out == 7.0).all()), 'nothing may be written by a refused call'
+  assert L().asm_dense_small(_ptr(p), 64, _ptr(q), 64, 32, 30, 64, _ptr(out), 32, 1, None, _stream()) == lib.ASM_OK
+
+
 def test_dense_layers_route_through_dense_small_and_match_the_conv_kernels(hip_lib, monkeypatch):
   """ops.conv_fprop / conv_dgrad of a [N,1,1,C] layer: the dense kernel == the implicit-GEMM convolution (A/B knob)"""
   from assembled_cnn_amd import ops

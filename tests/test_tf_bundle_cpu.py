@@ -137,3 +137,15 @@ def test_model_round_trip_and_warm_start_through_tf_checkpoint_files(cpu_double,
   assert len(rep['missing_slots']) == len(c.arena.specs) and all(float(c.arena.m(n).abs().max()) == 0.0 for n in c.arena.specs)
   assert ck._is_dense_kernel('resnet_model/dense/kernel/Momentum') and not ck._is_dense_kernel('kernel/Momentum')
   assert not ck._is_dense_kernel('resnet_model/embedding_dense/kernel')
+
+
+def test_lane_parallel_crc32c_equals_the_bytewise_form():
+  """long buffers take the lane-parallel numpy path (CRC is linear over GF(2)); it must agree with the table walk at every
+  length around the lane switch, for odd lengths (zero padding in front) and through the Extend form"""
+  rng = np.random.default_rng(0)
+  for n in (65535, 65536, 65537, 100003, (1 << 20) + 7):
+    d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    ref = B._crc32c_bytes(d)
+    assert B.crc32c(d) == ref
+    k = n // 3
+    assert B.crc32c(d[k:], B.crc32c(d[:k])) == ref
