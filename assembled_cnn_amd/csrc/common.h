@@ -32,9 +32,11 @@ inline thread_local int asm_unchecked_launches = 0;
 // argument checks at the top of an entry point are where that stale state is dropped -- but ONLY while this thread has no
 // launch of its own waiting for its ASM_CHECK_LAUNCH (asm_unchecked_launches, counted by ASM_LAUNCH): an ASM_REQUIRE that
 // a later edit places after a launch can therefore never swallow that launch's error.
+void asm_count_launch();             // plan.hip: process-wide kernel-launch counter (asm_launch_count)
 #define ASM_LAUNCH(...)             \
   do {                              \
     ++asm_unchecked_launches;       \
+    asm_count_launch();             \
     hipLaunchKernelGGL(__VA_ARGS__); \
   } while (0)
 #define ASM_REQUIRE(cond, ...)                               \

@@ -299,6 +299,14 @@ extern "C" int asm_model_plan(const asm_model_cfg* cfg, int N, int H, int W, asm
 }
 
 
+// ---- kernel launches made by this library, process-wide (bench.py: kernels per training step) ----------------------------
+#include <atomic>
+namespace {
+std::atomic<unsigned long long> g_launches{0};
+}
+void asm_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" unsigned long long asm_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+
 // ---- kernel-selection overrides (include/asm_hip.h: asm_tuning) ----------------------------------------------------------
 namespace {
 asm_tuning make_default_tuning() {

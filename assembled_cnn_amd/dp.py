@@ -73,6 +73,19 @@ class GradSync(object):
       raise RuntimeError('GradSync buckets cover %d of %d gradient elements' % (self._covered, arena.total_elems))
     self._reset()
     arena.on_grad = self.notify if overlap else None
+    # Buckets are handed to RCCL from a stream of their own (round 4).  RCCL orders its internal stream against the stream
+    # that is CURRENT at the call; until now that was the compute stream, which therefore had to wait for the
+    # weight-gradient streams at every bucket launch -- six joins per step that serialised the weight gradients against
+    # the input-gradient chain exactly when there is a real exchange to hide.  Now only the launch stream waits (for the
+    # tails of the compute, weight-gradient and branch streams: at the moment the watermark passes a bucket, everything
+    # enqueued on them so far belongs to this bucket or to ones already launched), the narrowing cast of the bf16
+    # exchange runs there too, and the compute stream meets the exchange again in finish().  ASM_DP_LAUNCH_STREAM=0: the
+    # old form (the current stream joins every stream).
+    self._launch_stream = None
+    if arena.g32.is_cuda:
+      from . import ops
+      if ops.knob('ASM_DP_LAUNCH_STREAM', '1') != '0':
+        self._launch_stream = torch.cuda.Stream(device=arena.g32.device)
 
   def _reset(self):
     self._next = [0 for _ in self.segments]     # next bucket (index) to launch per segment
@@ -101,14 +114,23 @@ class GradSync(object):
     self._reduced += hi - lo
     # RCCL's stream is ordered against the CURRENT stream only; the gradients of this bucket were written on the compute
     # stream, the weight-gradient streams and (first block of a BigLittle big branch) the branch stream: join them all
-    self.arena.join_all_streams()
+    ls = self._launch_stream
+    if ls is not None:
+      self.arena.join_all_streams(into=ls)
+      with torch.cuda.stream(ls):
+        self._work.append((self._exchange(lo, hi), lo, hi))
+    else:
+      self.arena.join_all_streams()
+      self._work.append((self._exchange(lo, hi), lo, hi))
+
+  def _exchange(self, lo: int, hi: int):
     if self._stage is not None:
       from . import ops
       ops.cast_f32_to_bf16(self.arena.g32[lo:hi], self._stage[lo:hi])
       buf = self._stage[lo:hi]
     else:
       buf = self.arena.g32[lo:hi]
-    self._work.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi))
+    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
   def finish(self):
     """Launch whatever is left and make the compute stream wait for every bucket."""

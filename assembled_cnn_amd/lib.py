@@ -101,6 +101,7 @@ _D = C.POINTER(ConvDesc)
 SIGNATURES = {
     'asm_last_error': (C.c_char_p, []),
     'asm_abi_version': (_I, []),
+    'asm_launch_count': (C.c_ulonglong, []),
     'asm_tuning_defaults': (None, [C.POINTER(Tuning)]),
     'asm_set_tuning': (_I, [C.POINTER(Tuning)]),
     'asm_get_tuning': (None, [C.POINTER(Tuning)]),

@@ -154,16 +154,21 @@ class ParamArena(object):
     self.join_side_stream()
     self.side_stream, self._sides = None, []
 
-  def join_all_streams(self):
-    """Make the CURRENT stream wait for everything enqueued so far on every stream this model launches gradient work on
-    (the compute stream of the running backward pass, the weight-gradient streams, the BigLittle branch stream): what
-    dp.GradSync does before it hands a bucket to RCCL, whose stream is ordered against the current stream only."""
+  def join_all_streams(self, into=None):
+    """Make ``into`` (default: the CURRENT stream) wait for everything enqueued so far on every stream this model launches
+    gradient work on (the compute stream of the running backward pass -- or the current stream when no backward pass set
+    one --, the weight-gradient streams, the BigLittle branch stream): what dp.GradSync does before it hands a bucket to
+    RCCL, whose stream is ordered against the stream that is current at the call only."""
     if self.w32 is None or not self.w32.is_cuda:
       return
     cur = torch.cuda.current_stream()
-    for s in [self.compute_stream] + list(self._sides) + list(self.extra_streams):
-      if s is not None and s != cur:
-        cur.wait_stream(s)
+    dst = cur if into is None else into
+    srcs = [self.compute_stream if self.compute_stream is not None else cur] + list(self._sides) + list(self.extra_streams)
+    if into is not None and cur not in srcs:
+      srcs.append(cur)
+    for s in srcs:
+      if s is not None and s != dst:
+        dst.wait_stream(s)
 
   def register(self, name, shape, decay, init) -> ParamSpec:
     if self.finalized:

@@ -383,12 +383,14 @@ def main():
 
   sync()
   calls0 = ops.abi_calls()
+  kern0 = ops.L().asm_launch_count() if not dry else 0
   t0 = time.time()
   for _ in range(args.steps):
     rows = step()
   sync()
   el = time.time() - t0
   abi_calls = (ops.abi_calls() - calls0) / max(args.steps, 1)
+  kernels_per_step = ((ops.L().asm_launch_count() - kern0) / max(args.steps, 1)) if not dry else None
   ops.set_conv_timer(None)
   if world > 1:
     t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -490,7 +492,17 @@ def main():
         f33 = sum(conv_flops(k) * v[0] for k, v in convs.items() if k[6] == 3 and k[7] == 3)
         t33 = sum(v[1] for k, v in convs.items() if k[6] == 3 and k[7] == 3)
         tall = sum(v[1] for v in convs.values())
+        # algorithmic bytes of the class: every launch reads its input and filter once and writes its output once (bf16;
+        # a weight gradient reads x and dy and writes fp32 dW) -- what `traffic` (counter bytes) is to be held against
+        def conv_bytes(k):
+          kind, N_, H_, W_, C_, K_, R_, S_, st_ = k
+          Ho_ = H_ if st_ == 1 else (H_ - 1) // st_ + 1
+          Wo_ = W_ if st_ == 1 else (W_ - 1) // st_ + 1
+          io = 2.0 * (N_ * H_ * W_ * C_ + N_ * Ho_ * Wo_ * K_)
+          return io + (4.0 if kind == 'wgrad' else 2.0) * R_ * S_ * C_ * K_
+        b33 = sum(conv_bytes(k) * v[0] for k, v in convs.items() if k[6] == 3 and k[7] == 3)
         st_obj['conv3x3_class'] = {'ms_per_step': round(t33, 3), 'tflops': round(f33 / (t33 * 1e-3) / 1e12, 1),
+                                   'algorithmic_bytes_per_step': int(b33),
                                    'frac_of_mfma_peak': round(f33 / (t33 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                                    'launches': sum(v[0] for k, v in convs.items() if k[6] == 3 and k[7] == 3)}
         st_obj['conv_all_ms_per_step'] = round(tall, 3)
@@ -509,6 +521,7 @@ def main():
         out['roofline'] = {
             'bound': 'mfma', 'achieved': c33['tflops'], 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': c33['frac_of_mfma_peak'], 'traffic': cls_traffic.get('conv3x3_class_bytes_per_step'),
+            'algorithmic_bytes': c33['algorithmic_bytes_per_step'],
             'kernel': '3x3 convolution class: every 3x3 fprop / input-gradient / weight-gradient launch of a step (%d launches, '
                       '%.3f ms, %.1f algorithmic GFLOP), time-weighted' % (c33['launches'], c33['ms_per_step'], f33 / 1e9),
             'traffic_source': 'profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --single-stream`, '
@@ -528,10 +541,12 @@ def main():
       out['step'] = {'error': repr(e)}
     out['streams'] = ('single (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0)' if args.single_stream else
                       'product default: the weight gradients and the big branch of each BigLittle stage on side streams')
-    out['launches'] = {'abi_calls_per_step': round(abi_calls, 1),
-                       'note': 'C-ABI calls of one step in the timed region (one kernel launch each, except: strided input '
-                               'gradients = one per parity class, weight gradients = kernel + slab reduce); the rocprofv3 '
-                               'kernel count per step is in profiles/'}
+    out['launches'] = {'kernels_per_step': None if kernels_per_step is None else round(kernels_per_step, 1),
+                       'abi_calls_per_step': round(abi_calls, 1),
+                       'note': 'kernels_per_step: the library\'s own launch counter (asm_launch_count) across the timed region, '
+                               'every stream; torch launches nothing inside a step.  abi_calls_per_step: C-ABI calls (one launch '
+                               'each, except: strided input gradients = one per parity class, weight gradients = kernel + slab '
+                               'reduce); the rocprofv3 kernel count per step is in profiles/'}
     if dp_info is not None:
       out['dp'] = dp_info
     if dry:

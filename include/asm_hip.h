@@ -39,6 +39,9 @@ extern "C" {
 
 const char* asm_last_error(void);
 int asm_abi_version(void);
+/* kernels this library has launched so far in this process (every stream, every thread): a training step's launch count is
+ * the difference across it.  hipMemcpyAsync / hipMemsetAsync fills of the strided 1x1 input gradient are not kernels. */
+unsigned long long asm_launch_count(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel-selection overrides (tests, same-box A/B runs, tuning).  The defaults are the heuristics the

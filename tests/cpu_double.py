@@ -71,6 +71,9 @@ class CpuDouble(object):
   def asm_last_error(self):
     return self._err
 
+  def asm_launch_count(self):
+    return 0
+
   def asm_abi_version(self):
     return 1
 

@@ -113,6 +113,16 @@ def test_train_steps_assemble_mixup_ls(hip_lib):
                        mixup_type=1, rel_tol=3e-2)
 
 
+def test_train_trajectory_10_steps_within_one_percent(hip_lib):
+  """"after 10 SGD steps loss trajectories within 1 %" -- ResNet-50 v1.5, batch 32 (batch statistics over 32 x
+  HW samples, unlike the batch-8 smoke runs above), momentum SGD + weight decay + label smoothing, the product's whole
+  step (forward, loss, tape, side streams, optimiser, BN moving statistics) against the bf16-emulating oracle's
+  train_step on the same batch, every one of the 10 cross entropies within 1 % of the oracle's"""
+  lp, lo = mp.check_train_steps('r50v1', 'cuda', 32, 64, 10, dict(base_learning_rate=0.002, weight_decay=1e-4, label_smoothing=0.1),
+                                rel_tol=1e-2)
+  assert len(lp) == 10
+
+
 def test_train_steps_kd(hip_lib):
   mp.check_train_steps('r50v1', 'cuda', 8, 64, 2, dict(base_learning_rate=0.001, weight_decay=1e-4), kd_temp=1.0,
                        rel_tol=3e-2)

@@ -35,7 +35,8 @@ def conv3x3(k):
       r, q = int(a[7]), int(a[8])
       return r * q > 1 and q != 1 or (r, q) == (2, 1)
     return False
-  return k.startswith('conv_halo_kernel') or k.startswith('wgrad_halo_kernel') or bool(re.match(r'wgrad_kernel<\d+, \d+, false', k))
+  return (k.startswith('conv_halo_kernel') or k.startswith('wgrad_halo_kernel') or k.startswith('igemm3_kernel') or
+          bool(re.match(r'wgrad_kernel<\d+, \d+, false', k)))
 
 
 def bn_family(k):
