@@ -70,7 +70,8 @@ typedef struct asm_tuning {
                               tile for the layer; 2: wherever the shape allows; 0: never                                */
   int32_t bn_slices;       /* channel slices of the batch-norm reducers (fewer partial rows per channel for the finalize
                               kernels): 0: C / 64 capped at 8; n: capped at n (1: every workgroup covers all channels)   */
-  int32_t reserved[4];
+  int32_t bn_rev;          /* 1: the batch-norm reducers walk their tensors back to front (measured neutral); 0: front to back */
+  int32_t reserved[3];
 } asm_tuning;
 void asm_tuning_defaults(asm_tuning* t);
 int asm_set_tuning(const asm_tuning* t);
