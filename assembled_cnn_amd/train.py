@@ -179,6 +179,48 @@ class Trainer(object):
     self._graph = self._static = self._graph_out = None
 
   # -----------------------------------------------------------------------------------------------
+  def set_streams(self, on: bool):
+    """Side streams on (the default: weight gradients on two streams beside the input-gradient chain, the big branch of
+    every BigLittle stage beside the little one) or off (every kernel on the compute stream).  Results are bit-identical
+    either way (tests/test_gpu_model.py); only the overlap changes."""
+    import os
+    os.environ['ASM_WGRAD_STREAM'] = '1' if on else '0'
+    os.environ['ASM_BL_STREAMS'] = '1' if on else '0'
+    ops.refresh_tuning()
+    a = self.model.arena
+    if a.finalized:
+      if on:
+        a.enable_side_stream()
+      else:
+        a.disable_side_stream()
+
+  def calibrate_streams(self, step_fn, steps: int = 3, margin: float = 0.03):
+    """Time ``steps`` training steps with the side streams on and off and keep the faster setting.
+
+    Why this exists (round 4): how the HIP runtime maps this process's four streams onto hardware queues is not under the
+    program's control, and one mapping is pathological for this step -- the one-workgroup-per-CU 256 x 256 tiles of kernels
+    running on three or four TRULY concurrent hardware queues evict each other (37 - 57 ms per step
+    instead of 26; seen on some boxes for every process started right after another GPU process exited).  The side streams
+    are worth ~1.5 ms per step when the mapping is the usual one and cost 20 - 30 ms when it is not, so the trainer
+    measures instead of assuming: streams stay on unless they are more than ``margin`` SLOWER than one stream.
+    ``step_fn()`` runs one real training step (the steps taken here are ordinary steps).  Returns the measurements."""
+    import time
+    res = {}
+    for on in (True, False):
+      self.set_streams(on)
+      step_fn()                               # the first step after a switch re-creates streams / warms the allocator
+      torch.cuda.synchronize()
+      t0 = time.time()
+      for _ in range(steps):
+        step_fn()
+      torch.cuda.synchronize()
+      res['side_streams_ms' if on else 'single_stream_ms'] = round(1000.0 * (time.time() - t0) / steps, 3)
+    keep = res['side_streams_ms'] <= res['single_stream_ms'] * (1.0 + margin)
+    self.set_streams(keep)
+    res['chosen'] = 'side streams' if keep else 'single stream'
+    return res
+
+  # -----------------------------------------------------------------------------------------------
   def prepare_inputs(self, images, labels, lam1=None, lam2=None):
     """images: [Bin,H,W,3] uint8 / float32 (0..255).  labels: int32 [Bin] or, with kd_temp > 0,
     float32 [Bin, 2C] = concat(one-hot, teacher logits) (run_loop_classification.py:90-96).

@@ -376,6 +376,11 @@ def main():
       dominant = pick_dominant()
     else:
       step()
+  # stream calibration (untimed, after the warm-up): Trainer.calibrate_streams keeps the side streams unless this process's
+  # stream -> hardware-queue mapping makes them slower than one stream; ASM_STREAM_AUTOTUNE=0 skips it
+  stream_cal = None
+  if not dry and not args.single_stream and os.environ.get('ASM_STREAM_AUTOTUNE', '1') != '0':
+    stream_cal = tr.calibrate_streams(step)
   timer = None
   if dominant is not None and args.single_stream:
     timer = ops.ConvTimer(only=dominant)
@@ -541,6 +546,11 @@ def main():
       out['step'] = {'error': repr(e)}
     out['streams'] = ('single (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0)' if args.single_stream else
                       'product default: the weight gradients and the big branch of each BigLittle stage on side streams')
+    if stream_cal is not None:
+      out['streams_autotune'] = dict(stream_cal, what='Trainer.calibrate_streams after the warm-up, 3 untimed steps per setting: '
+                                     'the timed region runs the chosen one (side streams unless > 3 % slower than one stream)')
+      if stream_cal['chosen'] != 'side streams':
+        out['streams'] = 'single stream (chosen by Trainer.calibrate_streams: the side streams measured slower in this process)' 
     out['launches'] = {'kernels_per_step': None if kernels_per_step is None else round(kernels_per_step, 1),
                        'abi_calls_per_step': round(abi_calls, 1),
                        'note': 'kernels_per_step: the library\'s own launch counter (asm_launch_count) across the timed region, '

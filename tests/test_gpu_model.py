@@ -168,6 +168,34 @@ def test_full_size_layer_shapes_run(hip_lib):
   assert tr.model.num_params() == 41867721
 
 
+def test_stream_calibration_keeps_a_working_trainer(hip_lib, monkeypatch):
+  """Trainer.calibrate_streams times both settings on real steps and leaves the faster one switched on; whichever it picks,
+  the trainer keeps stepping (streams re-created / torn down cleanly) and set_streams flips the arena's side streams"""
+  from assembled_cnn_amd import ops
+  from assembled_cnn_amd.train import HParams, Trainer
+  monkeypatch.setenv('ASM_WGRAD_STREAM', '1')
+  monkeypatch.setenv('ASM_BL_STREAMS', '1')
+  ops.refresh_tuning()
+  hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
+               zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01, batch_size=8)
+  tr = Trainer(hp, seed=3, device='cuda')
+  img = util.seeded_images(8, 64, 64, 5).cuda()
+  lab = torch.randint(1, 1001, (8,), generator=torch.Generator().manual_seed(6), dtype=torch.int32).cuda()
+  res = tr.calibrate_streams(lambda: tr.train_step(img, lab), steps=2)
+  assert res['chosen'] in ('side streams', 'single stream') and res['side_streams_ms'] > 0 and res['single_stream_ms'] > 0
+  assert (tr.model.arena.side_stream is not None) == (res['chosen'] == 'side streams')
+  tr.set_streams(False)
+  assert tr.model.arena.side_stream is None
+  tr.train_step(img, lab)
+  tr.set_streams(True)
+  assert tr.model.arena.side_stream is not None
+  tr.train_step(img, lab)
+  torch.cuda.synchronize()
+  assert bool(torch.isfinite(tr.model.arena.w32).all())
+  monkeypatch.undo()
+  ops.refresh_tuning()
+
+
 @pytest.mark.parametrize('size,steps', [(64, 8), (96, 4)])
 def test_side_streams_change_no_bit_over_several_steps(hip_lib, monkeypatch, size, steps):
   """The weight-gradient side streams and the BigLittle branch stream (forward: the big branch beside the little one;
