@@ -1496,6 +1496,9 @@ struct PoolAdd {
 };
 static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
                       const uint8_t* addend_mask, void* dx, void* stream, const PoolAdd* pool = nullptr);
+// conv_dgrad_s2.hip: the one-launch 3x3 / stride-2 input gradient (returns 1 when the layer is not one it covers)
+int asm_dgrad_s2_try(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend, const uint8_t* addend_mask,
+                     void* dx, void* stream);
 
 extern "C" int asm_conv2d_dgrad(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
                                 void* dx, void* stream) {
@@ -1561,6 +1564,10 @@ static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, co
   // written through the strided-output epilogue: 9/4 instead of 9 tap passes.
   const int split_ok = asm_tune().dgrad_parity;
   const bool k3 = d->R == 3 && d->S == 3, k1 = d->R == 1 && d->S == 1 && d->pad == 0;
+  if (k3 && d->stride == 2 && !pool && asm_tune().igemm_mode == 0) {   // all four parity classes in one launch
+    const int rc = asm_dgrad_s2_try(d, dy, wt, addend, addend_mask, dx, stream);
+    if (rc != 1) return rc;
+  }
   if (split_ok && d->stride == 2 && (k3 || k1) && asm_tune().igemm_mode == 0) {
     // a 1x1 / 2 projection touches only the (even, even) class: the other three are zero (or just the addend)
     bool launched = false;

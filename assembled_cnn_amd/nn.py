@@ -593,7 +593,7 @@ class ConvKernel(object):
       return None
     if not need_dx:
       return None
-    if addend_mask is not None and (d.stride != 1 or d.C % 8):
+    if addend_mask is not None and (d.stride != 1 or d.C % 8) and not ops.dgrad_s2_ok(d):
       addend, addend_mask = ops.mask_apply(addend, addend_mask), None     # the strided forms take a plain addend
     if self.kpad != self.cout:  # dy carries kpad channels (zero padded)
       dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, self.kpad, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo)

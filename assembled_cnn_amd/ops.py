@@ -289,6 +289,14 @@ def dgrad_pool_ok(d: ConvDesc) -> bool:
           and knob('ASM_IGEMM_MODE', '0') in ('', '0'))
 
 
+def dgrad_s2_ok(d: ConvDesc) -> bool:
+  """does the one-launch 3x3 / stride-2 input gradient (csrc/conv_dgrad_s2.hip) take this layer?  It adds a MASKED fan-in
+  addend in its copy-out, so the caller need not materialise the masked gradient first.  ASM_DGRAD_S2=0: never"""
+  return (knob('ASM_DGRAD_S2', '1') != '0' and knob('ASM_IGEMM_MODE', '0') in ('', '0') and d.R == 3 and d.S == 3
+          and d.stride == 2 and d.pad == 1 and d.C == 64 and d.K == 64 and d.H == 2 * d.Ho and d.W == 2 * d.Wo
+          and d.Ho % 8 == 0 and d.Wo % 8 == 0)
+
+
 def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional[torch.Tensor] = None,
                addend_mask: Optional[torch.Tensor] = None, pool=None) -> torch.Tensor:
   """dx = conv_transpose(dy, w) [+ addend [where addend_mask]] [+ avgpool_bwd(pool)];

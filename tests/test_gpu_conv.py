@@ -439,3 +439,33 @@ def test_igemm3_is_igemm2_bit_for_bit(hip_lib, shape, monkeypatch):
     outs[knob] = (y, st, y2, dx, dxa, dxm)
   for a, b, name in zip(outs['2'], outs['0'], ('fprop', 'stats', 'fprop-nostats', 'dgrad', 'dgrad+addend', 'dgrad+masked')):
     assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16), (3, 32, 48), (1, 112, 112)], ids=lambda s: 'x'.join(map(str, s)))
+def test_one_launch_stride2_dgrad_is_the_parity_class_launches_bit_for_bit(hip_lib, shape, monkeypatch):
+  """dgrad_s2_kernel (3x3 / stride 2, 64 -> 64: filter slice in registers, the four parity classes of dx side by side,
+  fan-in addend / masked addend in the copy-out) accumulates in the order of the four parity-class launches it replaces,
+  so every output must be IDENTICAL to theirs; and both must match the oracle's autograd."""
+  from assembled_cnn_amd import ops
+  from oracle import assembled_oracle as O
+  N, H, W = shape
+  Cn = K = 64
+  d = ops.make_conv_desc(N, H, W, Cn, K, 3, 3, 2)
+  w = _rand((K, 3, 3, Cn), 21, scale=(1.0 / (9 * Cn)) ** 0.5)
+  dy = _rand((N, d.Ho, d.Wo, K), 22)
+  addend = _rand((N, H, W, Cn), 23).cuda()
+  mask = torch.randint(0, 256, (N, H, W, Cn // 8), dtype=torch.uint8, generator=torch.Generator().manual_seed(24)).cuda()
+  wt = torch.zeros((Cn, 3, 3, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w.cuda(), wt, K, 3, 3, Cn)
+  outs = {}
+  for knob in ('1', '0'):
+    util.set_knob(monkeypatch, 'ASM_DGRAD_S2', knob)
+    assert ops.dgrad_s2_ok(d) == (knob == '1')
+    outs[knob] = (ops.conv_dgrad(d, dy.cuda(), wt), ops.conv_dgrad(d, dy.cuda(), wt, addend=addend),
+                  ops.conv_dgrad(d, dy.cuda(), wt, addend=addend, addend_mask=mask))
+  for a, b, name in zip(outs['1'], outs['0'], ('plain', 'addend', 'masked addend')):
+    assert torch.equal(a, b), name
+  xr = torch.zeros((N, Cn, H, W), requires_grad=True)
+  yr = O._conv_raw(xr, w.float().permute(1, 2, 3, 0), 3, 2)
+  (gx,) = torch.autograd.grad(yr, [xr], dy.float().permute(0, 3, 1, 2))
+  _check(outs['1'][0], gx.permute(0, 2, 3, 1), name='stride-2 dgrad vs oracle')
