@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_kernel(Args p) {
 // ---- halo form ------------------------------------------------------------------------------------------------------
 // LDS: halo[2][HR][128 B] (double-buffered over channel chunks), filter ring[NS][BN][128 B].
 // HRMAX: compile-time bound of the halo rows (BM + 2W + 2 rounded up to the pass height).
-template <int BM, int BN, int WGM, int WGN, int NS, int HRMAX, int DMASK>
+template <int BM, int BN, int WGM, int WGN, int NS, int HRMAX, int DMASK, int NHB = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void halo_kernel(Args p) {
   constexpr int NT = 64 * WGM * WGN, RPP = NT / 8, WP = BN / RPP, ROWB = 128;
   constexpr int HP = HRMAX / RPP;                 // halo passes (pieces per wave and chunk)
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void halo_kernel(Args p) {
   constexpr int HQ = (HP + HT - 1) / HT;
   static_assert(WP >= 1 && HRMAX % RPP == 0 && NS >= 2 && HT >= 1, "cfg");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const wring = smem + 2 * HALO;
+  unsigned char* const wring = smem + NHB * HALO;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   int logical;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void halo_kernel(Args p) {
       for (int j = 1; j <= NS - 2; ++j) {
         const int tj = t - j;
         int hq = 0;
-        if (tj >= 0 && has_next && tj < HT) {
+        if (NHB == 2 && tj >= 0 && has_next && tj < HT) {
           const int lo = tj * HQ, hi = (tj + 1) * HQ < HP ? (tj + 1) * HQ : HP;
           hq = hi > lo ? hi - lo : 0;
         }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void halo_kernel(Args p) {
       if (started) mma((KK - 1) & 1);
       started = true;
       // this step's issues: halo part of the next chunk first, then the filter tile of step k + NS - 1
-      if (has_next && t < HT) issue_halo(hb ^ 1, kcb + 128u, t * HQ, (t + 1) * HQ < HP ? (t + 1) * HQ : HP, false);
+      if (NHB == 2 && has_next && t < HT) issue_halo(hb ^ 1, kcb + 128u, t * HQ, (t + 1) * HQ < HP ? (t + 1) * HQ : HP, false);
       {
         const int tn = (t + NS - 1) % NTAP;
         const int carry = (t + NS - 1) / NTAP;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void halo_kernel(Args p) {
       cur = cur + 1 == NS ? 0 : cur + 1;
     }
     kcb += 128u;
-    hb ^= 1;
+    if (NHB == 2) hb ^= 1;
   };
 #pragma unroll 1
   for (int kc = 0; kc + 1 < p.kchunks; ++kc) chunk_body(std::true_type{});
@@ -443,13 +443,13 @@ Variant mk_gather(const char* nm) {
   v.hrmax = 0;
   return v;
 }
-template <int BM, int BN, int WGM, int WGN, int NS, int HRMAX, int DMASK>
+template <int BM, int BN, int WGM, int WGN, int NS, int HRMAX, int DMASK, int NHB = 2>
 Variant mk_halo(const char* nm) {
   Variant v;
   v.name = nm;
-  v.kern = halo_kernel<BM, BN, WGM, WGN, NS, HRMAX, DMASK>;
+  v.kern = halo_kernel<BM, BN, WGM, WGN, NS, HRMAX, DMASK, NHB>;
   v.BM = BM; v.BN = BN; v.NT = 64 * WGM * WGN;
-  v.lds = 2 * HRMAX * 128 + NS * BN * 128;
+  v.lds = NHB * HRMAX * 128 + NS * BN * 128;
   v.hrmax = HRMAX;
   return v;
 }
@@ -500,22 +500,19 @@ int main(int argc, char** argv) {
       {"7x7    M12544 N512 C256 W7", 12544, 512, 256, 7},
       {"28x28  M200704 N256 C128 W28", 200704, 256, 128, 28},
       {"14x14b M50176 N512 C256 W14", 50176, 512, 256, 14},
+      {"56x56d M802816 N64 C128 W56", 802816, 64, 128, 56},
+      {"28x28s M200704 N128 C64 W28", 200704, 128, 64, 28},
   };
   std::vector<Variant> vars;
-  // round 2 of the probe: halo-form configurations against the two gather-form baselines
+  // round 3 of the probe: single-chunk layers (C = 64: one halo buffer, nothing to double-buffer) at two workgroups per CU
   vars.push_back(mk_gather<128, 128, 2, 2, 2, 0>("g128 ns2"));
-  vars.push_back(mk_gather<256, 256, 4, 2, 2, 0>("g256 ns2"));
-  vars.push_back(mk_halo<128, 128, 2, 2, 2, 160, 0>("h128 ns2 hr160"));       // 72 KB: two workgroups per CU (W <= 15)
-  vars.push_back(mk_halo<128, 128, 2, 2, 2, 192, 0>("h128 ns2 hr192"));       // 80 KB: two per CU (W <= 31)
-  vars.push_back(mk_halo<128, 128, 2, 2, 3, 160, 0>("h128 ns3 hr160"));       // 88 KB: one per CU
-  vars.push_back(mk_halo<256, 128, 4, 2, 2, 320, 0>("h256x128 ns2 hr320"));
-  vars.push_back(mk_halo<256, 128, 4, 2, 3, 320, 0>("h256x128 ns3 hr320"));
-  vars.push_back(mk_halo<256, 128, 4, 2, 4, 320, 0>("h256x128 ns4 hr320"));
-  vars.push_back(mk_halo<256, 128, 2, 4, 3, 320, 0>("h256x128 ns3 w2x4"));
-  vars.push_back(mk_halo<256, 128, 4, 2, 3, 320, 3>("h256x128 ns3 noDMA"));
-  vars.push_back(mk_halo<256, 128, 4, 2, 3, 320, 4>("h256x128 ns3 noMMA"));
-  vars.push_back(mk_halo<256, 256, 4, 2, 2, 320, 0>("h256 ns2 hr320"));
-  vars.push_back(mk_halo<256, 128, 4, 2, 3, 384, 0>("h256x128 ns3 hr384"));
+  vars.push_back(mk_gather<128, 64, 2, 2, 2, 0>("g128x64 ns2"));
+  vars.push_back(mk_halo<128, 128, 2, 2, 2, 256, 0, 1>("h128 ns2 hr256 1buf"));     // 64 KB: two per CU
+  vars.push_back(mk_halo<128, 128, 2, 2, 3, 256, 0, 1>("h128 ns3 hr256 1buf"));     // 80 KB: two per CU
+  vars.push_back(mk_halo<128, 64, 2, 2, 2, 256, 0, 1>("h128x64 ns2 hr256 1buf"));   // 48 KB: three per CU
+  vars.push_back(mk_halo<128, 64, 2, 2, 3, 256, 0, 1>("h128x64 ns3 hr256 1buf"));
+  vars.push_back(mk_halo<128, 64, 2, 2, 2, 256, 0, 2>("h128x64 ns2 hr256 2buf"));   // 80 KB
+  vars.push_back(mk_halo<128, 128, 2, 2, 2, 192, 0>("h128 ns2 hr192"));
 
   int dev = 0;
   hipDeviceProp_t prop;

@@ -3,7 +3,7 @@
 #   stats    rocprofv3 --kernel-trace --stats of bench.py (3 warm-up + 5 timed steps) -> gpurun_out/TAG_kernel_stats.md
 #   traffic  two --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain) -> gpurun_out/TAG_step_hbm_traffic.md
 #   dominant FETCH_SIZE / WRITE_SIZE of the layer bench.py's roofline object names -> gpurun_out/TAG_pmc_traffic.json
-#   sq       one --pmc pass of SQ occupancy / MFMA-busy counters -> gpurun_out/TAG_sq_counters.txt
+#   sq       one --pmc pass of SQ occupancy / MFMA-busy counters -> gpurun_out/TAG_sq_counters.md
 TAG=$1; shift
 WHAT="${*:-stats}"
 REPO=$(pwd)
@@ -33,7 +33,7 @@ for w in $WHAT; do
     sq)
       rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
         -d $REPO/gpurun_out/pmc_${TAG}_sq -o p --output-format csv -- $BENCH --steps 2 --warmup 1 > $REPO/gpurun_out/pmc_${TAG}_sq.log 2>&1
-      python $REPO/tools/pmc_summary.py $REPO/gpurun_out/pmc_${TAG}_sq > $REPO/gpurun_out/${TAG}_sq_counters.txt
+      python $REPO/tools/pmc_summary.py $REPO/gpurun_out/pmc_${TAG}_sq --md "$TAG: bench.py --steps 2 --warmup 1" > $REPO/gpurun_out/${TAG}_sq_counters.md
       ;;
   esac
 done
