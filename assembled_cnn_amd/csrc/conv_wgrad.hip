@@ -37,7 +37,10 @@ struct WgradArgs {
   int HoWo, Wo;
 };
 
-constexpr int WPX = 64;   // pixels per step
+#ifndef WG_WPX
+#define WG_WPX 64
+#endif
+constexpr int WPX = WG_WPX;   // pixels per step
 
 __device__ __forceinline__ bf16x4 ds_read_tr(const unsigned char* p) {
   typedef __attribute__((ext_vector_type(4))) short s4;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs
   constexpr int XP = WPX / XRP;             // x passes (4)
   constexpr int CY = BNW / 8;               // 16-byte chunks per dy row
   constexpr int YRP = NTHR / CY;            // dy rows staged per pass
-  constexpr int YP = WPX / YRP;             // dy passes (4 / 2 / 1)
+  constexpr int YP = WPX / YRP > 0 ? WPX / YRP : 1;             // dy passes (4 / 2 / 1)
   constexpr bool BIG = BCW == 256;
   constexpr int NT = BNW >= 64 ? 2 : 1;     // 32-row dy tiles per wave
   constexpr int CT = BIG ? 4 : (BNW == 128 ? 2 : 1);    // 32-col x tiles per wave
@@ -468,7 +471,7 @@ Plan make_plan(const asm_conv_desc* d) {
   Plan pl;
   const int M = d->N * d->Ho * d->Wo;
   const int cols = d->R * d->S * d->C;
-  pl.bnw = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);
+  pl.bnw = (d->K <= 32 && WPX == 64) ? 32 : (d->K <= 64 ? 64 : 128);
   pl.bcw = 128;
   // 256 x 256 / 8 waves when dW tiles exactly (no padded MFMAs) and there is enough of it; ASM_WGRAD_BIG=0/1 forces
   const int big_env = asm_tune().wgrad_big;
@@ -492,15 +495,18 @@ Plan make_plan(const asm_conv_desc* d) {
   const double flops = 2.0 * (double)M * d->K * cols;
   const double io_bytes = 2.0 * ((double)M * d->C + (double)M * d->K);
   const double work_us = fmax(flops / 6.0e8, io_bytes / 4.0e6);      // ~600 TFLOP/s or ~4 TB/s
-  const int slots = 256 * (pl.bnw == 256 ? 1 : (pl.bnw == 128 ? 2 : (pl.bnw == 64 ? 3 : 4)));
+  const int slots = 256 * (pl.bnw == 256 ? 1 : (pl.bnw == 128 ? 2 : (pl.bnw == 64 ? 3 : 4))) * (64 / WPX);
   const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;            // at least 4 steps per block
+  // asm_tuning.wgrad_slab_pct: weight of the slab term in percent (100 = the stand-alone optimum; beside other streams' work
+  // an under-filled launch costs less than the model assumes and slab traffic costs everyone)
+  const double slab_w = asm_tune().wgrad_slab_pct > 0 ? asm_tune().wgrad_slab_pct / 100.0 : 1.0;
   int splits = 1;
   double best = 1e30;
   for (int sp = 1; sp <= 256 && sp <= max_splits; ++sp) {
     const double blocks = (double)tiles * sp;
     const double fill = ceil(blocks / slots) / (blocks / slots);      // >= 1: quantisation of the last round
     const double under = blocks < slots ? (double)slots / blocks * 0.5 + 0.5 : 1.0;  // too few blocks: less overlap
-    const double slab = sp > 1 ? (double)(sp + 1) * wbytes / 4.0e6 + 4.0 : 0.0;
+    const double slab = sp > 1 ? ((double)(sp + 1) * wbytes / 4.0e6 + 4.0) * slab_w : 0.0;
     const double est = work_us * (blocks < slots ? under : fill) + slab;
     if (est < best) {
       best = est;

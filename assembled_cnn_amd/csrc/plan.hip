@@ -313,7 +313,7 @@ asm_tuning make_default_tuning() {
   asm_tuning t = {};
   t.igemm_mode = 0; t.igemm_tile = 0; t.igemm_v2 = 1; t.conv_halo = 1; t.igemm_smallm = 0; t.igemm_pfa = -1;
   t.igemm_bk64_1x1 = 4000; t.dgrad_parity = 1; t.wgrad_halo = 1; t.wgrad_big = -1; t.wgrad_splits = 0; t.wgrad_linear = 1;
-  t.bn_rows = 1024; t.conv_sched = 0; t.igemm3 = 1; t.bn_slices = 0; t.bn_rev = 0; t.dgrad_s2 = 1;
+  t.bn_rows = 1024; t.conv_sched = 0; t.igemm3 = 1; t.bn_slices = 0; t.bn_rev = 0; t.dgrad_s2 = 1; t.wgrad_slab_pct = 100;
   return t;
 }
 asm_tuning g_tuning = make_default_tuning();

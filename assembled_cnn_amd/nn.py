@@ -125,7 +125,16 @@ class ParamArena(object):
       for off in deferred:
         self.on_grad(off)
 
-  def enable_side_stream(self):
+  def enable_side_stream(self, fresh: bool = False):
+    """``fresh``: drop parked streams and create new ones (Trainer.calibrate_streams: how the runtime places a stream on
+    the hardware queues is decided when the stream is created, and some placements are pathological for this step)."""
+    if fresh:
+      self._parked = []
+    if self.w32 is not None and self.w32.is_cuda and self.side_stream is None and getattr(self, '_parked', None):
+      self._sides, self._parked = self._parked, []       # the very streams that were switched off: same placement
+      self._side_rr = 0
+      self.side_stream = self._sides[0]
+      return
     if self.w32 is not None and self.w32.is_cuda and self.side_stream is None:
       # ASM_WGRAD_STREAMS=n: n side streams taken round robin, so that consecutive weight gradients (leaves of the
       # backward graph, independent of each other) may also overlap each other.  Same box, ms per step: 1 stream 27.09 /
@@ -151,7 +160,11 @@ class ParamArena(object):
         torch.cuda.current_stream().wait_stream(s)
 
   def disable_side_stream(self):
+    """Weight gradients back onto the compute stream.  The stream objects are parked, not dropped: switching the side
+    streams on again reuses them (and their hardware-queue placement)."""
     self.join_side_stream()
+    if self._sides:
+      self._parked = list(self._sides)
     self.side_stream, self._sides = None, []
 
   def join_all_streams(self, into=None):

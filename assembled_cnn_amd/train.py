@@ -179,10 +179,11 @@ class Trainer(object):
     self._graph = self._static = self._graph_out = None
 
   # -----------------------------------------------------------------------------------------------
-  def set_streams(self, on: bool):
+  def set_streams(self, on: bool, fresh: bool = False):
     """Side streams on (the default: weight gradients on two streams beside the input-gradient chain, the big branch of
     every BigLittle stage beside the little one) or off (every kernel on the compute stream).  Results are bit-identical
-    either way (tests/test_gpu_model.py); only the overlap changes."""
+    either way (tests/test_gpu_model.py); only the overlap changes.  Switching off parks the stream objects and switching
+    on again reuses them; ``fresh`` creates new ones instead."""
     import os
     os.environ['ASM_WGRAD_STREAM'] = '1' if on else '0'
     os.environ['ASM_BL_STREAMS'] = '1' if on else '0'
@@ -190,32 +191,47 @@ class Trainer(object):
     a = self.model.arena
     if a.finalized:
       if on:
-        a.enable_side_stream()
+        if fresh:
+          a.disable_side_stream()
+          old = self.model._bl_stream
+          if old is not None:
+            torch.cuda.current_stream().wait_stream(old)
+            a.extra_streams = [s_ for s_ in a.extra_streams if s_ is not old]
+          self.model._bl_stream = None
+        a.enable_side_stream(fresh=fresh)
       else:
         a.disable_side_stream()
 
-  def calibrate_streams(self, step_fn, steps: int = 3, margin: float = 0.03):
+  def calibrate_streams(self, step_fn, steps: int = 3, margin: float = 0.03, redraws: int = 2):
     """Time ``steps`` training steps with the side streams on and off and keep the faster setting.
 
-    Why this exists (round 4): how the HIP runtime maps this process's four streams onto hardware queues is not under the
-    program's control, and one mapping is pathological for this step -- the one-workgroup-per-CU 256 x 256 tiles of kernels
-    running on three or four TRULY concurrent hardware queues evict each other (37 - 57 ms per step
-    instead of 26; seen on some boxes for every process started right after another GPU process exited).  The side streams
-    are worth ~1.5 ms per step when the mapping is the usual one and cost 20 - 30 ms when it is not, so the trainer
-    measures instead of assuming: streams stay on unless they are more than ``margin`` SLOWER than one stream.
-    ``step_fn()`` runs one real training step (the steps taken here are ordinary steps).  Returns the measurements."""
+    Why this exists (round 4): where the HIP runtime places a stream on the hardware queues is decided when the stream is
+    created and is not under the program's control, and some placements are pathological for this step -- the
+    one-workgroup-per-CU 256 x 256 tiles of kernels on truly concurrent hardware queues evict each other (DESIGN.md
+    section 5: 37 - 100 ms per step instead of 26, seen for whole processes on some boxes).  The side streams are worth
+    ~1 ms per step when the placement is the usual one and cost 20 - 70 ms when it is not, so the trainer measures
+    instead of assuming: the streams it measured stay on (the SAME stream objects: switching off only parks them) unless
+    they are more than ``margin`` slower than one stream; then up to ``redraws`` freshly created sets are tried before
+    the step falls back to one stream.  ``step_fn()`` runs one real training step (the steps taken here are ordinary
+    steps).  Returns the measurements."""
     import time
-    res = {}
-    for on in (True, False):
-      self.set_streams(on)
-      step_fn()                               # the first step after a switch re-creates streams / warms the allocator
+
+    def timed(on, fresh=False):
+      self.set_streams(on, fresh=fresh)
+      step_fn()                               # the first step after a switch warms the allocator on the new streams
       torch.cuda.synchronize()
       t0 = time.time()
       for _ in range(steps):
         step_fn()
       torch.cuda.synchronize()
-      res['side_streams_ms' if on else 'single_stream_ms'] = round(1000.0 * (time.time() - t0) / steps, 3)
+      return round(1000.0 * (time.time() - t0) / steps, 3)
+
+    res = {'side_streams_ms': timed(True), 'single_stream_ms': timed(False), 'redraws': 0}
     keep = res['side_streams_ms'] <= res['single_stream_ms'] * (1.0 + margin)
+    while not keep and res['redraws'] < redraws:
+      res['redraws'] += 1
+      res['side_streams_ms'] = timed(True, fresh=True)
+      keep = res['side_streams_ms'] <= res['single_stream_ms'] * (1.0 + margin)
     self.set_streams(keep)
     res['chosen'] = 'side streams' if keep else 'single stream'
     return res

@@ -73,7 +73,9 @@ typedef struct asm_tuning {
   int32_t bn_rev;          /* 1: the batch-norm reducers walk their tensors back to front (measured neutral); 0: front to back */
   int32_t dgrad_s2;        /* 1: 3x3 stride-2 input gradients with 64 -> 64 channels in one launch (filter slice in registers,
                               the four parity classes side by side: dgrad_s2_kernel); 0: four parity-class launches       */
-  int32_t reserved[2];
+  int32_t wgrad_slab_pct;  /* weight (percent) of the fp32 slab traffic in the weight gradient's split cost model: 100 = as
+                              measured stand-alone; larger = fewer pixel splits                                          */
+  int32_t reserved[1];
 } asm_tuning;
 void asm_tuning_defaults(asm_tuning* t);
 int asm_set_tuning(const asm_tuning* t);
