@@ -26,7 +26,7 @@ struct RowTiling {
   int blocks;     // row blocks = partial rows per channel
   int slices;     // channel slices: a workgroup reduces rows_per_block rows of ONE slice (grid = blocks * slices)
   int vc_slice;   // vector columns per slice
-  int rev;        // 1: the first workgroups take the LAST row blocks (see make_tiling)
+  int order;      // 0: row tiles interleaved over the workgroups, 1: one contiguous row block each, 2: that, back to front
 };
 
 RowTiling make_tiling(int M, int C) {
@@ -53,11 +53,14 @@ RowTiling make_tiling(int M, int C) {
   if (rows < t.rpb * 4) rows = t.rpb * 4;
   t.rows_per_block = rows;
   t.blocks = cdiv(M, rows);
-  // Back to front (asm_tuning.bn_rev, off): the apply pass behind a reducer streams the same tensors FRONT to back, so a
-  // reducer that ends at the front should leave the bytes the apply pass asks for first in L2 / the memory-side cache.
-  // Measured neutral on the whole step (same box, 4 rounds: 25.36 vs 25.33 ms): kept as a knob only.  Partial row b still
-  // holds row block b: same sums, same bits.
-  t.rev = asm_tune().bn_rev != 0;
+  // Which rows a workgroup takes (asm_tuning.bn_order).  1 = one contiguous block of rows each (rounds 1-3): ~1000 streams
+  // that start M / blocks rows apart -- 1.6 MB for the 56 x 56 x 256 tensor, a multiple of 32 KB, so in lock step they
+  // ask the same HBM channels for different DRAM pages -- 4.3 - 4.5 TB/s in the training step where the apply passes, whose
+  // grid-stride loops sweep ONE compact window over the tensor, reach 6.2.  0 (default, round 4) = the reducers sweep the
+  // same way: workgroup b takes the row tiles b, b + blocks, b + 2 blocks, ... (a tile = rpb x 2 rows).  Partial row b then
+  // holds the sum over those tiles: other bits than the blocked order, still a fixed order.  2 = blocked, back to front
+  // (measured neutral against 1: 25.36 vs 25.33 ms per step).
+  t.order = asm_tune().bn_order;
   return t;
 }
 
@@ -76,10 +79,12 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
   const int rr = tid / t.vcb;
   const bool active = rr < t.rpb;
   const int rdisp = blockIdx.x / t.slices, slice = blockIdx.x - rdisp * t.slices;
-  const int rblk = t.rev ? t.blocks - 1 - rdisp : rdisp;
+  const int rblk = t.order == 2 ? t.blocks - 1 - rdisp : rdisp;
   const int vc_lo = slice * t.vc_slice, vc_hi = min(t.vcols, vc_lo + t.vc_slice);
-  const int row_begin = rblk * t.rows_per_block;
-  const int row_end = min(M, row_begin + t.rows_per_block);
+  constexpr int U = 2;
+  const int row_begin = t.order ? rblk * t.rows_per_block : rblk * (U * t.rpb);
+  const int row_end = t.order ? min(M, row_begin + t.rows_per_block) : M;
+  const int row_step = t.order ? U * t.rpb : t.blocks * (U * t.rpb);
   for (int vcbase = vc_lo; vcbase < vc_hi; vcbase += t.vcb) {
     const int vc = vcbase + vc0;
     float s[8], ss[8];
@@ -96,8 +101,7 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
       }
       // 2 rows per trip (4 was ~5 % slower, 8 ~35 %: registers cost occupancy): all loads of a trip are issued before any is consumed (the reduction is
       // bandwidth-bound only if enough bytes are in flight per CU)
-      constexpr int U = 2;
-      for (int row = row_begin + rr; row < row_end; row += U * t.rpb) {
+      for (int row = row_begin + rr; row < row_end; row += row_step) {
         u32x4 va[U], vb[U], vy[U];
         unsigned mk[U];
 #pragma unroll
@@ -476,10 +480,12 @@ __global__ __launch_bounds__(256) void rowreduce2_kernel(const bf16_t* __restric
   const int rr = tid / t.vcb;
   const bool active = rr < t.rpb;
   const int rdisp = blockIdx.x / t.slices, slice = blockIdx.x - rdisp * t.slices;
-  const int rblk = t.rev ? t.blocks - 1 - rdisp : rdisp;
+  const int rblk = t.order == 2 ? t.blocks - 1 - rdisp : rdisp;
   const int vc_lo = slice * t.vc_slice, vc_hi = min(t.vcols, vc_lo + t.vc_slice);
-  const int row_begin = rblk * t.rows_per_block;
-  const int row_end = min(M, row_begin + t.rows_per_block);
+  constexpr int U = 2;
+  const int row_begin = t.order ? rblk * t.rows_per_block : rblk * (U * t.rpb);
+  const int row_end = t.order ? min(M, row_begin + t.rows_per_block) : M;
+  const int row_step = t.order ? U * t.rpb : t.blocks * (U * t.rpb);
   for (int vcbase = vc_lo; vcbase < vc_hi; vcbase += t.vcb) {
     const int vc = vcbase + vc0;
     float s[8], sa[8], sb[8];
@@ -494,8 +500,7 @@ __global__ __launch_bounds__(256) void rowreduce2_kernel(const bf16_t* __restric
         mb[e] = mean_b[vc * 8 + e];
         ib[e] = invstd_b[vc * 8 + e];
       }
-      constexpr int U = 2;
-      for (int row = row_begin + rr; row < row_end; row += U * t.rpb) {
+      for (int row = row_begin + rr; row < row_end; row += row_step) {
         u32x4 vg[U], va[U], vb[U];
         unsigned mk[U];
 #pragma unroll

@@ -320,6 +320,63 @@ __global__ __launch_bounds__(256) void blur_bwd_kernel(const bf16_t* __restrict_
   *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(acc);
 }
 
+// The workload's case -- 3 taps (1 2 1) / 4, stride 2, even H and W -- without the generic kernel's nest of tap loops and
+// divisibility tests (2.3 TB/s: 27 mostly-failing predicate evaluations per 16 bytes stored): one thread owns a 2 x 2
+// quad of dx, which draws on the 2 x 2 neighbourhood dy[i..i+1][j..j+1] only.  Per dimension (h = 2i + u):
+//   u = 0: tap 1 of output i                                      -> 1/2 g[i]
+//   u = 1: tap 0 of output i + 1 (if it exists), tap 2 of output i -> 1/4 g[i+1] + 1/4 g[i]
+//          h = 1 is also what the REFLECT pad shows at padded position 0 (tap 0 of output 0) -> + 1/4 g[0]
+// (the far-end reflection lands on tap positions no stride-2 output uses when the extent is even).  The terms are
+// added in the generic kernel's order, so the result is the same bits.
+__global__ __launch_bounds__(256) void blur3s2_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N,
+                                                          int Hh, int Wh, int C, float a0, float a1, float a2) {
+  const int vcols = C >> 3;
+  const size_t nq = (size_t)N * Hh * Wh * vcols;
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const Pix p = decode(q, Hh, Wh, vcols);       // p.h, p.w: the quad = the dy pixel (i, j)
+  const bool hv = p.h + 1 < Hh, wv = p.w + 1 < Wh;
+  float g[2][2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const bool ok = (a == 0 || hv) && (b == 0 || wv);
+      const size_t off = (((size_t)p.n * Hh + p.h + (ok ? a : 0)) * Wh + p.w + (ok ? b : 0)) * C + p.vc * 8;
+      unpack8(ldv(dy, off), g[a][b]);
+    }
+  // per dimension and parity: up to three (source, weight) terms in the generic kernel's order
+  const int src_odd[3] = {1, 0, 0};
+  const float wgt_odd[3] = {a0, a2, a0};
+  const bool okh[3] = {hv, true, p.h == 0}, okw[3] = {wv, true, p.w == 0};
+  const int W2 = 2 * Wh;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int th = 0; th < (u ? 3 : 1); ++th) {
+        const int sh = u ? src_odd[th] : 0;
+        const float wh = u ? wgt_odd[th] : a1;
+        if (u && !okh[th]) continue;
+#pragma unroll
+        for (int tw = 0; tw < (v ? 3 : 1); ++tw) {
+          const int sw = v ? src_odd[tw] : 0;
+          const float ww = v ? wgt_odd[tw] : a1;
+          if (v && !okw[tw]) continue;
+          const float wgt = wh * ww;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += g[sh][sw][e] * wgt;
+        }
+      }
+      const size_t off = (((size_t)p.n * 2 * Hh + 2 * p.h + u) * W2 + 2 * p.w + v) * C + p.vc * 8;
+      *reinterpret_cast<u32x4*>(dx + off) = pack8(acc);
+    }
+}
+
 // ---- global average pool: [N, HW, C] -> [N, C]; one block per (n, group of <=32 vector columns) -----
 // NT threads = (NT / vcb) row-lanes x vcb vector columns, vcb = min(C/8, 32).  One block per (image, 32 vector
 // columns): with 3136 rows per image the 256-thread form walked ~100 dependent trips per lane on 4 waves per CU
@@ -517,8 +574,14 @@ extern "C" int asm_blurpool_bwd(const void* dy, void* dx, int N, int H, int W, i
   const int Ho = blur_out(H, k, stride), Wo = blur_out(W, k, stride);
   const size_t nvec = (size_t)N * H * W * (C / 8);
   ASM_REQUIRE(nvec < 0x7fffffffull, "pool: tensor too large for 32-bit indexing");
-  ASM_LAUNCH(blur_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                     (bf16_t*)dx, N, H, W, C, k, stride, Ho, Wo, blur_coef(k));
+  if (k == 3 && stride == 2 && H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 4) {
+    const BlurCoef cf = blur_coef(3);
+    ASM_LAUNCH(blur3s2_bwd_kernel, dim3(grid_for(nvec / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (bf16_t*)dx, N, H / 2, W / 2, C, cf.a[0], cf.a[1], cf.a[2]);
+  } else {
+    ASM_LAUNCH(blur_bwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (bf16_t*)dx, N, H, W, C, k, stride, Ho, Wo, blur_coef(k));
+  }
   ASM_CHECK_LAUNCH("blurpool_bwd");
   return ASM_OK;
 }

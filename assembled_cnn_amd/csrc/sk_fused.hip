@@ -48,9 +48,38 @@ __device__ __forceinline__ void gate8(const float* __restrict__ att, int n, int 
   }
 }
 
-// Cross-row-lane sum of 8 per-thread values: red[thread][0..7] -> `out` in the rl == 0 thread of each vector column.
+// Cross-row-lane sum of 8 per-thread values -> `out` in the rl == 0 thread of each vector column.  Two levels (round 4):
+// the row lanes that share a wave are summed by xor-shuffles (lanes vcb, 2 vcb, ... apart hold the same vector column),
+// then one row of LDS per wave and a 16-term sum.  The one-level form had the vcb leader lanes walk all NT / vcb row lanes:
+// 1024 LDS reads on 8 lanes for the 56 x 56 maps, ~10 % of the kernel -- and five such sums in the statistics variants.
 template <int NT>
 __device__ __forceinline__ void lane_sum8(float (*red)[9], const float* v, float* out, int vcb, int vcl, int nrl, bool leader) {
+  if ((vcb & (vcb - 1)) == 0 && vcb <= 64) {
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = v[e];
+    for (int off = vcb; off < 64; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] += __shfl_xor(w[e], off, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane < vcb) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave * vcb + lane][e] = w[e];
+    }
+    __syncthreads();
+    if (leader) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < NT / 64; ++r) t += red[r * vcb + vcl][e];
+        out[e] = t;
+      }
+    }
+    return;
+  }
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = v[e];
@@ -161,29 +190,46 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void sk_gap_bn_kernel(const 
 }
 
 // ---- V = a0 f0 + a1 f1 -----------------------------------------------------------------------------------------------
+// grid (chunks, N); block = F/8 vector columns x rpb row lanes: a thread keeps its 8 channels of one image, so the two
+// coefficient vectors and the gates (8 exponentials) are derived ONCE and the loop streams y -> V.  (Round 4: the
+// one-vector-per-thread form re-derived 48 scalars and 8 exponentials for every 48 bytes moved: 4.9 TB/s.)
 __global__ __launch_bounds__(256) void sk_select_bn_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ att, bf16_t* __restrict__ v,
-                                                               int N, int HW, int F) {
-  const int vcols = F >> 3;
-  const size_t nvec = (size_t)N * HW * vcols;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nvec) return;
-  const unsigned iu = (unsigned)i;
-  const unsigned mu = iu / (unsigned)vcols;
-  const int vc = (int)(iu - mu * (unsigned)vcols);
-  const size_t m = mu;
-  const int n = (int)(mu / (unsigned)HW);
+                                                               int HW, int F, int rpb, int rows_per_chunk) {
+  const int fv = F >> 3;
+  const int vc = threadIdx.x % fv, rr = threadIdx.x / fv;
+  if (rr >= rpb) return;
+  const int n = blockIdx.y;
   Coef8 k0, k1;
   load_coef(scale, shift, vc * 8, k0);
   load_coef(scale, shift, F + vc * 8, k1);
-  float a0[8], f0[8], f1[8], o[8];
+  float a0[8];
   gate8(att, n, F, vc * 8, a0);
-  bnrelu8(ldv(y, m * 2 * F + vc * 8), k0, f0);
-  bnrelu8(ldv(y, m * 2 * F + F + vc * 8), k1, f1);
+  const int r_begin = blockIdx.x * rows_per_chunk;
+  const int r_end = min(HW, r_begin + rows_per_chunk);
+  constexpr int U = 2;
+  for (int r = r_begin + rr; r < r_end; r += U * rpb) {
+    u32x4 y0[U], y1[U];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = a0[e] * f0[e] + (1.0f - a0[e]) * f1[e];
-  *reinterpret_cast<u32x4*>(v + i * 8) = pack8(o);
+    for (int q = 0; q < U; ++q) {
+      const int rq = r + q * rpb;
+      const size_t m = (size_t)n * HW + (rq < r_end ? rq : r);
+      y0[q] = ldv(y, m * 2 * F + vc * 8);
+      y1[q] = ldv(y, m * 2 * F + F + vc * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int rq = r + q * rpb;
+      if (rq >= r_end) break;
+      float f0[8], f1[8], o[8];
+      bnrelu8(y0[q], k0, f0);
+      bnrelu8(y1[q], k1, f1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = a0[e] * f0[e] + (1.0f - a0[e]) * f1[e];
+      *reinterpret_cast<u32x4*>(v + ((size_t)n * HW + rq) * F + vc * 8) = pack8(o);
+    }
+  }
 }
 
 // ---- datt[n][c] = a0 a1 sum_hw (f0 - f1) dV ;  datt[n][F + c] = -that ----------------------------------------------------
@@ -542,9 +588,15 @@ extern "C" int asm_sk_select_bn_fwd(const void* y, const float* scale, const flo
                                     int N, int HW, int F, void* stream) {
   SKF_OK("sk_select_bn_fwd");
   ASM_REQUIRE(y && scale && shift && att && v, "sk_select_bn_fwd: null pointer");
-  const size_t nvec = (size_t)N * HW * (F / 8);
-  ASM_LAUNCH(sk_select_bn_fwd_kernel, dim3((unsigned)cdivz(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)y, scale, shift, att, (bf16_t*)v, N, HW, F);
+  // the (chunk, image) decomposition of the backward passes (make_geom) over the F / 8 vector columns of V
+  const int fv = F / 8, rpb = 256 / fv;
+  int chunks = 2048 / N;
+  if (chunks < 1) chunks = 1;
+  int rows = cdiv(HW, chunks);
+  rows = cdiv(rows, rpb) * rpb;
+  if (rows < rpb * 4) rows = rpb * 4;
+  ASM_LAUNCH(sk_select_bn_fwd_kernel, dim3(cdiv(HW, rows), N), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)y, scale, shift, att, (bf16_t*)v, HW, F, rpb, rows);
   ASM_CHECK_LAUNCH("sk_select_bn_fwd");
   return ASM_OK;
 }

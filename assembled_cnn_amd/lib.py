@@ -63,7 +63,7 @@ class Tuning(C.Structure):
   """struct asm_tuning: the kernel-selection overrides (the library itself reads no environment variable)"""
   _fields_ = [(n, C.c_int32) for n in (
       'igemm_mode', 'igemm_tile', 'igemm_v2', 'conv_halo', 'igemm_smallm', 'igemm_pfa', 'igemm_bk64_1x1', 'dgrad_parity',
-      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched', 'igemm3', 'bn_slices', 'bn_rev', 'dgrad_s2', 'wgrad_slab_pct')] + [('reserved', C.c_int32 * 1)]
+      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched', 'igemm3', 'bn_slices', 'bn_order', 'dgrad_s2', 'wgrad_slab_pct')] + [('reserved', C.c_int32 * 1)]
 
 
 # environment variable of the HOST -> asm_tuning field (same-box A/B runs, tests); unset = the library's default
@@ -71,7 +71,7 @@ TUNING_ENV = {'ASM_IGEMM_MODE': 'igemm_mode', 'ASM_IGEMM_TILE': 'igemm_tile', 'A
               'ASM_CONV_HALO': 'conv_halo', 'ASM_IGEMM_SMALLM': 'igemm_smallm', 'ASM_IGEMM_PFA': 'igemm_pfa',
               'ASM_IGEMM_BK64_1X1': 'igemm_bk64_1x1', 'ASM_DGRAD_PARITY': 'dgrad_parity', 'ASM_WGRAD_HALO': 'wgrad_halo',
               'ASM_WGRAD_BIG': 'wgrad_big', 'ASM_WGRAD_SPLITS': 'wgrad_splits', 'ASM_WGRAD_LINEAR': 'wgrad_linear',
-              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched', 'ASM_IGEMM3': 'igemm3', 'ASM_BN_SLICES': 'bn_slices', 'ASM_BN_REV': 'bn_rev', 'ASM_DGRAD_S2': 'dgrad_s2', 'ASM_WGRAD_SLAB_PCT': 'wgrad_slab_pct'}
+              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched', 'ASM_IGEMM3': 'igemm3', 'ASM_BN_SLICES': 'bn_slices', 'ASM_BN_ORDER': 'bn_order', 'ASM_DGRAD_S2': 'dgrad_s2', 'ASM_WGRAD_SLAB_PCT': 'wgrad_slab_pct'}
 
 
 def apply_env_tuning(lib) -> 'Tuning':
@@ -147,6 +147,9 @@ SIGNATURES = {
     'asm_sk_bn_bwd_blocks': (_I, [_I, _I, _I]),
     'asm_sk_bn_bwd_reduce': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'asm_sk_bn_bwd_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_gap_bn_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_select_bn_bwd_att_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'asm_sk_bn_bwd_finalize': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_se_scale_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'asm_se_scale_bwd_e': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'asm_se_scale_bwd_x': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
@@ -193,13 +196,10 @@ DEBUG_SIGNATURES = {
     'asm_conv2d_wgrad_naive': (_I, [_D, _P, _P, _P, _P]),
     'asm_debug_tr_probe': (_I, [_P, _P]),
     'asm_conv2d_wgrad_plan': (_I, [_D, C.POINTER(C.c_int32 * 6)]),
-    # measured-slower variants (opt-in: ASM_DENSE_BN=1, ASM_SK_FACTOR=1)
+    # measured-slower variants (opt-in: ASM_DENSE_BN=1)
     'asm_dense_bn_max_rows': (_I, []),
     'asm_dense_bn_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asm_dense_dgrad_bn_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'asm_sk_gap_bn_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'asm_sk_select_bn_bwd_att_stats': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'asm_sk_bn_bwd_finalize': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

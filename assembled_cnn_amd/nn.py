@@ -876,11 +876,11 @@ class SKUnit(object):
     mean, invstd, scale, shift = ops.bn_finalize(part, M, C2, gamma, beta, BN_EPS, ctx.bn_momentum, a.st(bn.mm),
                                                  a.st(bn.mv))
     # Factorised BN backward (csrc/sk_fused.hip): the pooled-sum pass and the gate-gradient pass also emit per-image
-    # statistics, from which the batch-norm reduction follows without another pass over y and dV.  Exact and tested, but
-    # OFF by default: the two per-image passes are latency-bound (one workgroup per image, 3.4 TB/s), the 32 extra
-    # accumulators slow them by more than the removed reduce pass costs (28.98 vs 28.37 ms per step, same box).
-    # ASM_SK_FACTOR=1 turns it on.
-    factor = ctx.tape is not None and ops.knob('ASM_SK_FACTOR', '0') == '1'
+    # statistics, from which the batch-norm reduction follows without another pass over y and dV (1.8 GB of HBM reads per
+    # step).  Exact and tested.  Rounds 2-3 kept it off: the two per-image passes run one workgroup per image, and their
+    # five cross-lane sums (1024 LDS reads on 8 lanes each) cost more than the removed pass.  With the two-level lane sum
+    # of round 4 it wins: 25.73 -> 25.57 ms per step (same box, two rounds each).  ASM_SK_FACTOR=0 turns it off.
+    factor = ctx.tape is not None and ops.knob('ASM_SK_FACTOR', '1') == '1'
     if factor:
       s_t, mask_stats = ops.sk_gap_bn(y, scale, shift, F_, mean, invstd)
       s = Var(s_t)

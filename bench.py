@@ -389,9 +389,19 @@ def main():
   sync()
   calls0 = ops.abi_calls()
   kern0 = ops.L().asm_launch_count() if not dry else 0
+  # per-step diagnostics that cost two clock reads and one event record per step: how long the HOST took to enqueue each
+  # step and when the GPU finished it -- a timed region that is slow because the host fell behind (a busy box) reads
+  # differently from one where the GPU ran slowly, and either shows as its first / last steps
+  step_host, step_ev = [], []
   t0 = time.time()
   for _ in range(args.steps):
+    h0 = time.perf_counter()
     rows = step()
+    if not dry:
+      ev = torch.cuda.Event(enable_timing=True)
+      ev.record()
+      step_ev.append(ev)
+    step_host.append(time.perf_counter() - h0)
   sync()
   el = time.time() - t0
   abi_calls = (ops.abi_calls() - calls0) / max(args.steps, 1)
@@ -546,6 +556,16 @@ def main():
       out['step'] = {'error': repr(e)}
     out['streams'] = ('single (ASM_WGRAD_STREAM=0 ASM_BL_STREAMS=0)' if args.single_stream else
                       'product default: the weight gradients and the big branch of each BigLittle stage on side streams')
+    if len(step_ev) >= 2:
+      gaps = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(len(step_ev) - 1))
+      hs = sorted(1000.0 * h for h in step_host)
+      out['step_detail'] = {'gpu_ms_between_step_ends': {'min': round(gaps[0], 3), 'median': round(gaps[len(gaps) // 2], 3),
+                                                         'max': round(gaps[-1], 3)},
+                            'host_enqueue_ms': {'min': round(hs[0], 3), 'median': round(hs[len(hs) // 2], 3),
+                                                'max': round(hs[-1], 3)},
+                            'host': {'cpus': os.cpu_count(), 'loadavg_1min': round(os.getloadavg()[0], 2)},
+                            'what': 'per timed step: time between consecutive end-of-step events on the compute stream, and '
+                                    'host time to enqueue the step (the host runs ahead of the GPU when its median is the smaller)'}
     if stream_cal is not None:
       out['streams_autotune'] = dict(stream_cal, what='Trainer.calibrate_streams after the warm-up, 3 untimed steps per setting: '
                                      'the timed region runs the chosen one (side streams unless > 3 % slower than one stream)')

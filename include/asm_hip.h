@@ -70,7 +70,7 @@ typedef struct asm_tuning {
                               tile for the layer; 2: wherever the shape allows; 0: never                                */
   int32_t bn_slices;       /* channel slices of the batch-norm reducers (fewer partial rows per channel for the finalize
                               kernels): 0: C / 64 capped at 8; n: capped at n (1: every workgroup covers all channels)   */
-  int32_t bn_rev;          /* 1: the batch-norm reducers walk their tensors back to front (measured neutral); 0: front to back */
+  int32_t bn_order;        /* rows of a batch-norm reducer workgroup: 0 tiles interleaved over the workgroups, 1 one contiguous block, 2 that, back to front */
   int32_t dgrad_s2;        /* 1: 3x3 stride-2 input gradients with 64 -> 64 channels in one launch (filter slice in registers,
                               the four parity classes side by side: dgrad_s2_kernel); 0: four parity-class launches       */
   int32_t wgrad_slab_pct;  /* weight (percent) of the fp32 slab traffic in the weight gradient's split cost model: 100 = as
@@ -321,6 +321,21 @@ int asm_sk_bn_bwd_reduce(const void* dv, const float* att, const void* ds, const
 int asm_sk_bn_bwd_apply(const void* dv, const float* att, const void* ds, const void* y, const float* scale,
                         const float* shift, const float* coefA, const float* coefB, const float* coefC, void* dy,
                         int N, int HW, int F, void* stream);
+/* Factorised form of that reduce (the training path's default since round 4; the reduce pass above stays for
+ * ASM_SK_FACTOR=0): a_b and ds are constant over an image, so
+ *   sum dz = sum_n a_b[n] G0[n] + (ds[n]/HW) M0[n],  sum dz*y = sum_n a_b[n] G1[n] + (ds[n]/HW) M1[n]
+ * with per-image statistics [N][2][2F] (fp32): mask_stats = (sum_hw [f>0], sum_hw [f>0] y) out of the pooled-sum pass
+ * (asm_sk_gap_bn_stats) and grad_stats = (sum_hw [f>0] dV, sum_hw [f>0] dV y) out of the gate-gradient pass
+ * (asm_sk_select_bn_bwd_att_stats), both of which read y (and dV) anyway.  asm_sk_bn_bwd_finalize turns them into
+ * dgamma, dbeta and the apply coefficients (xhat is affine in y): the reduce pass over the whole tensor disappears. */
+int asm_sk_gap_bn_stats(const void* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                        void* s, float* mask_stats, int N, int HW, int F, void* stream);
+int asm_sk_select_bn_bwd_att_stats(const void* y, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const void* dv, const float* att, void* datt, float* grad_stats,
+                                   int N, int HW, int F, void* stream);
+int asm_sk_bn_bwd_finalize(const float* grad_stats, const float* mask_stats, const float* att, const void* ds, int N,
+                           int HW, int F, const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                           float* dbeta, float* coefA, float* coefB, float* coefC, void* stream);
 /* SE: y = x * sigmoid(e[n][c]);  e float32 [N, C] (pre-sigmoid) */
 int asm_se_scale_fwd(const void* x, const float* e, void* y, int N, int HW, int C, void* stream);
 /* de[n][c] = sigmoid'(e) * sum_hw x*dy (bf16 out) */

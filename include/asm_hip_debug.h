@@ -27,9 +27,9 @@ int asm_debug_tr_probe(void* out256_i16, void* stream);
 int asm_conv2d_wgrad_plan(const asm_conv_desc* d, int32_t plan[6]);
 
 
-/* ---- measured-slower variants, kept for A/B runs (opt-in on the host: ASM_DENSE_BN=1, ASM_SK_FACTOR=1) ------------------
+/* ---- measured-slower variant, kept for A/B runs (opt-in on the host: ASM_DENSE_BN=1) -------------------------------------
  * Not part of the drop-in boundary; DESIGN.md section 5.1 has the numbers (dense + BN in one launch: 27.61 vs 27.40 ms per
- * step; factorised SK batch-norm reduction: +0.6 ms per step).
+ * step).  (The factorised SK batch-norm reduction that lived here until round 3 is the default now: asm_hip.h.)
  *   asm_dense_bn_fwd:       ypre = bf16(x . w^T) [M][N]; training-mode batch norm of ypre over the M rows (statistics of
  *                           the bf16-rounded values, moving-statistics update, mean / invstd out), z = bn(ypre) [relu],
  *                           optional packed ReLU mask [M][N/8] -- one launch (== asm_dense_small + asm_bn_small_fwd).
@@ -45,21 +45,6 @@ int asm_dense_bn_fwd(const void* x, int ldx, const void* w, int ldw, int M, int 
 int asm_dense_dgrad_bn_bwd(const void* dy, int lddy, const void* wt, int ldwt, int M, int K, int N, const void* ypre,
                            const uint8_t* relu_mask, const float* gamma, const float* mean, const float* invstd,
                            float* dgamma, float* dbeta, void* dx, void* stream);
-/* Factorised form of that reduce: a_b and ds are constant over an image, so
- *   sum dz = sum_n a_b[n] G0[n] + (ds[n]/HW) M0[n],  sum dz*y = sum_n a_b[n] G1[n] + (ds[n]/HW) M1[n]
- * with per-image statistics [N][2][2F] (fp32): mask_stats = (sum_hw [f>0], sum_hw [f>0] y) out of the pooled-sum pass
- * (asm_sk_gap_bn_stats) and grad_stats = (sum_hw [f>0] dV, sum_hw [f>0] dV y) out of the gate-gradient pass
- * (asm_sk_select_bn_bwd_att_stats), both of which read y (and dV) anyway.  asm_sk_bn_bwd_finalize turns them into
- * dgamma, dbeta and the apply coefficients (xhat is affine in y): the reduce pass over the whole tensor disappears. */
-int asm_sk_gap_bn_stats(const void* y, const float* scale, const float* shift, const float* mean, const float* invstd,
-                        void* s, float* mask_stats, int N, int HW, int F, void* stream);
-int asm_sk_select_bn_bwd_att_stats(const void* y, const float* scale, const float* shift, const float* mean,
-                                   const float* invstd, const void* dv, const float* att, void* datt, float* grad_stats,
-                                   int N, int HW, int F, void* stream);
-int asm_sk_bn_bwd_finalize(const float* grad_stats, const float* mask_stats, const float* att, const void* ds, int N,
-                           int HW, int F, const float* gamma, const float* mean, const float* invstd, float* dgamma,
-                           float* dbeta, float* coefA, float* coefB, float* coefC, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -172,7 +172,7 @@ def test_avgpool(hip_lib, shape, k, stride, pad, cv):
 
 
 @pytest.mark.parametrize('k', [3, 5, 2])
-@pytest.mark.parametrize('shape', [(2, 14, 14, 64), (1, 7, 9, 8)])
+@pytest.mark.parametrize('shape', [(2, 14, 14, 64), (1, 7, 9, 8), (3, 4, 6, 16), (2, 8, 4, 8)])
 def test_blurpool(hip_lib, shape, k):
   from assembled_cnn_amd import ops
   from oracle import assembled_oracle as O
