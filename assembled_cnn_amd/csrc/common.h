@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <tuple>
+#include <utility>
 #include "../../include/asm_hip.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
@@ -33,11 +35,34 @@ inline thread_local int asm_unchecked_launches = 0;
 // launch of its own waiting for its ASM_CHECK_LAUNCH (asm_unchecked_launches, counted by ASM_LAUNCH): an ASM_REQUIRE that
 // a later edit places after a launch can therefore never swallow that launch's error.
 void asm_count_launch();             // plan.hip: process-wide kernel-launch counter (asm_launch_count)
+// tape.hip: while THIS host thread records a launch tape (asm_tape_begin .. asm_tape_end) every launch is also written
+// down -- kernel, geometry, stream and a copy of its arguments converted to the kernel's parameter types -- so that
+// asm_tape_replay can issue the same launches again without the host code that derived them.
+inline thread_local bool asm_tape_on = false;
+void asm_tape_add_launch(const void* fn, dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, void** args,
+                         const size_t* sizes, const size_t* aligns, int nargs);
+// device-to-device copy (from != nullptr) or byte fill, seen by a tape that is being recorded
+hipError_t asm_fill_async(void* dst, const void* from, int value, size_t bytes, hipStream_t stream);
+template <typename... P, typename... A>
+inline void asm_launch(void (*kernel)(P...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, A&&... a) {
+  static_assert(sizeof...(P) == sizeof...(A), "ASM_LAUNCH: argument count differs from the kernel's parameter count");
+  if (asm_tape_on) {
+    auto params = std::tuple<P...>{static_cast<P>(a)...};      // exactly what the launch below converts them to
+    std::apply(
+        [&](auto&... p) {
+          void* ptrs[] = {(void*)&p..., nullptr};
+          const size_t sizes[] = {sizeof(p)..., 0}, aligns[] = {alignof(decltype(p))..., 0};
+          asm_tape_add_launch((const void*)kernel, grid, block, shmem, stream, ptrs, sizes, aligns, (int)sizeof...(P));
+        },
+        params);
+  }
+  hipLaunchKernelGGL(kernel, grid, block, shmem, stream, static_cast<P>(a)...);
+}
 #define ASM_LAUNCH(...)             \
   do {                              \
     ++asm_unchecked_launches;       \
     asm_count_launch();             \
-    hipLaunchKernelGGL(__VA_ARGS__); \
+    asm_launch(__VA_ARGS__);        \
   } while (0)
 #define ASM_REQUIRE(cond, ...)                               \
   do {                                                       \

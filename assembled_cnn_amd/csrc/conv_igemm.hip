@@ -1591,9 +1591,9 @@ static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, co
         ASM_FAIL(ASM_ENOTSUP, "conv dgrad_masked: a masked addend is not supported for the 1x1 stride-2 input gradient");
       if (!launched && k1) {   // fill the untouched classes before the one launch that overwrites its own pixels
         const size_t bytes = (size_t)a.M * d->C * 2;
-        hipError_t e = (addend && addend != dx) ? hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream)
+        hipError_t e = (addend && addend != dx) ? asm_fill_async(dx, addend, 0, bytes, (hipStream_t)stream)
                      : addend ? hipSuccess
-                              : hipMemsetAsync(dx, 0, bytes, (hipStream_t)stream);
+                              : asm_fill_async(dx, nullptr, 0, bytes, (hipStream_t)stream);
         if (e != hipSuccess) ASM_FAIL(ASM_EHIP, "conv dgrad: fill: %s", hipGetErrorString(e));
       }
       const int rc = launch(c, false, false, (hipStream_t)stream, /*igemm2_only=*/true);

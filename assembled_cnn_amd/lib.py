@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ASM_HIP_LIB') or os.path.join(HERE, 'libasm_hip.so')
 
 ASM_OK, ASM_EINVAL, ASM_ENOTSUP, ASM_EHIP = 0, -1, -2, -3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class AsmError(RuntimeError):
@@ -102,6 +102,13 @@ SIGNATURES = {
     'asm_last_error': (C.c_char_p, []),
     'asm_abi_version': (_I, []),
     'asm_launch_count': (C.c_ulonglong, []),
+    'asm_stream_join': (_I, [_P, _P]),
+    'asm_tape_begin': (_I, []),
+    'asm_tape_mark': (_I, []),
+    'asm_tape_end': (_I, []),
+    'asm_tape_info': (_I, [_I, C.POINTER(C.c_int64 * 6)]),
+    'asm_tape_replay': (_I, [_I, _I]),
+    'asm_tape_free': (_I, [_I]),
     'asm_tuning_defaults': (None, [C.POINTER(Tuning)]),
     'asm_set_tuning': (_I, [C.POINTER(Tuning)]),
     'asm_get_tuning': (None, [C.POINTER(Tuning)]),

@@ -204,7 +204,7 @@ class Model(object):
       # the branch stream; its consumer drops it while the little branch keeps allocating on the compute stream, and the
       # caching allocator would hand the block out again while the branch stream still reads it.  Kept alive until the join.
       keep = (big_out._grad, big_out.grad_mask, big_out.pre_dy, big_out.pool_grad, big_out.pending)
-      side.wait_stream(main)            # the merge's backward produced both branches' output gradients on the compute stream
+      ops.stream_join(side, main)       # the merge's backward produced both branches' output gradients on the compute stream
       bi = li = 0
       try:
         while bi < len(big) or li < len(lit):
@@ -223,7 +223,7 @@ class Model(object):
       finally:
         arena.compute_stream = main
         arena.defer_grads(False)
-      main.wait_stream(side)
+      ops.stream_join(main, side)
       del keep
       arena.flush_deferred()
       for fn in reversed(big_first):
@@ -417,7 +417,7 @@ class Model(object):
         side = self._branch_stream(ctx, x)
         tb0 = len(ctx.tape) if ctx.tape is not None else None
         if side is not None:
-          side.wait_stream(_current_stream())
+          ops.stream_join(side, _current_stream())
           with _stream_ctx(side):
             big = self._block_layer(ctx, x, num_filters, num_blocks - 1, 2, 'big{}'.format(i + 1),
                                     use_bl=True, last_relu=False, db_gamma_scale=dbs)
@@ -434,7 +434,7 @@ class Model(object):
         be = L(lambda: BatchNorm(ctx, num_filters * 4))
         ctx.pop_scope()
         if side is not None:
-          _current_stream().wait_stream(side)
+          ops.stream_join(_current_stream(), side)
           if tb0 is not None and tb1 > tbf and ops.knob('ASM_BL_BWD', '1') != '0':
             tape = ctx.tape
             tape[tb0:] = [self._bl_backward(ctx, side, big, tape[tb0:tbf], tape[tbf:tb1], tape[tb1:])]

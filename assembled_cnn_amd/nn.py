@@ -157,7 +157,7 @@ class ParamArena(object):
     """Make the compute stream wait for every weight gradient enqueued so far."""
     if self.side_stream is not None:
       for s in self._sides:
-        torch.cuda.current_stream().wait_stream(s)
+        ops.stream_join(torch.cuda.current_stream(), s)
 
   def disable_side_stream(self):
     """Weight gradients back onto the compute stream.  The stream objects are parked, not dropped: switching the side
@@ -181,7 +181,7 @@ class ParamArena(object):
       srcs.append(cur)
     for s in srcs:
       if s is not None and s != dst:
-        dst.wait_stream(s)
+        ops.stream_join(dst, s)
 
   def register(self, name, shape, decay, init) -> ParamSpec:
     if self.finalized:
@@ -580,7 +580,7 @@ class ConvKernel(object):
     a = self.arena
     side = a.pick_side_stream()
     if side is not None:
-      side.wait_stream(a.compute_stream or torch.cuda.current_stream())     # x and dy were produced on the compute stream
+      ops.stream_join(side, a.compute_stream or torch.cuda.current_stream())     # x and dy were produced on the compute stream
       if self.stem or ops.timer_on():                    # these allocate / record events through torch: its own context
         with torch.cuda.stream(side):
           self._wgrad(d, x, dy)

@@ -103,6 +103,54 @@ def _stream() -> int:
   return torch.cuda.current_stream().cuda_stream
 
 
+def stream_join(dst: "torch.cuda.Stream", src: "torch.cuda.Stream"):
+  """``dst`` waits for everything enqueued on ``src`` so far (== dst.wait_stream(src)), through the library: every
+  cross-stream edge of a training step goes through here so that a launch tape that is being recorded sees it
+  (csrc/tape.hip)."""
+  if dst is src:
+    return
+  if _IS_DOUBLE:            # the CPU test double has no streams; its tests pass stand-ins that log who waited for whom
+    dst.wait_stream(src)
+    return
+  check(L().asm_stream_join(dst.cuda_stream, src.cuda_stream), 'stream_join')
+
+
+def tape_begin() -> int:
+  rc = L().asm_tape_begin()
+  if rc <= 0:
+    check(rc, 'tape_begin')
+  return rc
+
+
+def tape_mark() -> int:
+  rc = L().asm_tape_mark()
+  if rc <= 0:
+    check(rc, 'tape_mark')
+  return rc
+
+
+def tape_end() -> int:
+  rc = L().asm_tape_end()
+  if rc <= 0:
+    check(rc, 'tape_end')
+  return rc
+
+
+def tape_info(tape: int) -> dict:
+  import ctypes
+  info = (ctypes.c_int64 * 6)()
+  check(L().asm_tape_info(tape, ctypes.byref(info)), 'tape_info')
+  return dict(zip(('nodes', 'launches', 'joins', 'fills', 'segments', 'arg_bytes'), [int(v) for v in info]))
+
+
+def tape_replay(tape: int, segment: int = -1):
+  check(L().asm_tape_replay(tape, segment), 'tape_replay')
+
+
+def tape_free(tape: int):
+  check(L().asm_tape_free(tape), 'tape_free')
+
+
 def empty(shape, dtype, like: torch.Tensor) -> torch.Tensor:
   return torch.empty(shape, dtype=dtype, device=like.device)
 

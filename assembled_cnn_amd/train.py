@@ -177,6 +177,17 @@ class Trainer(object):
     self.world_size = world_size
     self.last = {}
     self._graph = self._static = self._graph_out = None
+    self._tape = self._cap_stream = None
+    # the stream a captured step is recorded and replayed on: taken from the pool BEFORE the model takes its side streams
+    dev = torch.device(device)
+    self._step_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+
+  @property
+  def stream(self):
+    """The HIP stream captured steps are recorded and replayed on (None on the CPU test double).  A training loop that
+    runs under ``with torch.cuda.stream(trainer.stream)`` keeps the default stream out of the step entirely, which is
+    the fastest arrangement measured (see _replay)."""
+    return self._step_stream
 
   # -----------------------------------------------------------------------------------------------
   def set_streams(self, on: bool, fresh: bool = False):
@@ -195,7 +206,7 @@ class Trainer(object):
           a.disable_side_stream()
           old = self.model._bl_stream
           if old is not None:
-            torch.cuda.current_stream().wait_stream(old)
+            ops.stream_join(torch.cuda.current_stream(), old)
             a.extra_streams = [s_ for s_ in a.extra_streams if s_ is not old]
           self.model._bl_stream = None
         a.enable_side_stream(fresh=fresh)
@@ -330,47 +341,110 @@ class Trainer(object):
     self.last = {'loss_rows': loss_rows, 'lr': lr, 'keep_prob': keep_prob}
     return loss_rows
 
-  # ---- the step as ONE HIP graph -------------------------------------------------------------------------------------
-  def capture(self, images, labels, lam1=None, lam2=None, warmup: int = 2, capture_error_mode: str = 'global'):
-    """Record inputs -> forward -> loss -> backward (every launch of it, side streams included) into a HIP graph over
-    static input buffers; train_step then copies its arguments into those buffers, replays the graph (one host call
-    instead of ~850) and runs the exchange + optimiser as usual.  The step enqueues in ~18 ms of host time against ~27 ms of
-    GPU time on a 5 GHz host: a slower host, or eight ranks sharing one, makes the eager step host-bound.
-    Not available with DropBlock (its keep_prob and random draws change per step) or an attached gradient exchange
-    (bucket launches are interleaved with the backward by the host).  ``warmup`` real training steps run first (one-time
-    initialisation must not be recorded).  The graph keeps every activation of a step in its private memory pool until
-    release_graph(); ``capture_error_mode='thread_local'`` if other threads (an input pipeline) touch the device while
-    capturing.  ASM_* switches are frozen into the recording."""
+  # ---- the step as a recorded launch sequence ---------------------------------------------------------------------------
+  def capture(self, images, labels, lam1=None, lam2=None, warmup: int = 2, capture_error_mode: str = 'global',
+              replay: str = 'tape'):
+    """Record inputs -> forward -> loss -> backward (every launch of it, side streams included) over static input buffers;
+    train_step then copies its arguments into those buffers, replays the recording with ONE host call instead of ~930
+    launches' worth of Python, and runs the exchange + optimiser as usual (their learning rate is a host scalar).
+
+    Why: the eager step enqueues in 14 - 15 ms of host time against 25 ms of GPU time.  On a busy host -- the GPU boxes this
+    was developed on are shared: 256 hardware threads, load averages of 40 - 65 -- that head-room goes: with one competitor
+    on the Python thread's core the step is host-bound at 30 ms, with two at 48 (tools/debug/host_contention.sh).
+
+    ``replay='tape'`` (default): the library writes the launches down while they are captured (csrc/tape.hip) and
+    ``asm_tape_replay`` issues them again through hipLaunchKernel on the recorded streams: ~2 - 3 ms of host time per step.
+    The HIP graph of the capture is never launched; it is kept for its private memory pool, which is what holds every
+    buffer of the step at its recorded address (and never hands a block to another stream).
+    ``replay='graph'``: hipGraphLaunch of the captured graph; ROCm 7 spends 11.5 - 22 ms of host time per launch on the
+    step's nodes, so this only pays where the eager step is host-bound anyway.
+
+    Both replays are bit-identical to the eager step (tests/test_gpu_model.py).  Not available with DropBlock (its
+    keep_prob and random draws change per step) or an attached gradient exchange (bucket launches are interleaved with the
+    backward by the host).  ``warmup`` real training steps run first (one-time initialisation must not be recorded).
+    Every activation of a step stays allocated until release_graph(); ``capture_error_mode='thread_local'`` if other
+    threads (an input pipeline) touch the device while capturing.  ASM_* switches are frozen into the recording."""
     if self._graph is not None:
-      raise RuntimeError('a step graph is already captured: release_graph() first')
+      raise RuntimeError('a step is already captured: release_graph() first')
+    if replay not in ('tape', 'graph'):
+      raise ValueError("replay must be 'tape' or 'graph'")
     if self.keep_prob_fn is not None:
-      raise NotImplementedError('DropBlock changes keep_prob and its draws every step: the step cannot be one static graph')
+      raise NotImplementedError('DropBlock changes keep_prob and its draws every step: the step cannot be one static recording')
     if self.grad_sync is not None:
       raise NotImplementedError('with a gradient exchange attached the bucket launches are host-driven: eager steps only')
     if not images.is_cuda:
       raise RuntimeError('capture needs device tensors')
+    if labels.dim() == 1 and labels.dtype != torch.int32:
+      labels = labels.to(torch.int32)        # the conversion is a torch kernel: it must not be part of the recorded step
     static = [t.clone() if t is not None else None for t in (images, labels, lam1, lam2)]
-    for _ in range(warmup):     # one-time initialisation (workspaces, kernel attributes, side streams) stays out of the graph
-      self.train_step(images, labels, lam1, lam2)
+    cur = torch.cuda.current_stream(images.device)
+    if cur != torch.cuda.default_stream(images.device):
+      cap = cur           # already on a stream of the caller's: record there (a capture cannot run on the default stream)
+    elif self._step_stream is not None:
+      cap = self._step_stream
+    else:   # ASM_TAPE_PRIO: HIP priority of the stream the recorded compute chain runs on (-1 high, 0 normal)
+      cap = torch.cuda.Stream(device=images.device, priority=int(ops.knob('ASM_TAPE_PRIO', '0')))
+    if cap != cur:
+      ops.stream_join(cap, cur)
+    with torch.cuda.stream(cap):
+      for _ in range(warmup):     # one-time initialisation (workspaces, kernel attributes, side streams) stays out of the recording
+        self.train_step(images, labels, lam1, lam2)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode=capture_error_mode):
-      out = self._forward_backward(*static)
+    tape = None
+    with torch.cuda.graph(g, stream=cap, capture_error_mode=capture_error_mode):
+      if replay == 'tape':
+        tape = ops.tape_begin()
+      try:
+        out = self._forward_backward(*static)
+      finally:
+        if tape is not None:
+          ops.tape_end()
     self._graph, self._static, self._graph_out = g, static, out
+    self._tape, self._cap_stream = tape, cap
     return self
 
   def release_graph(self):
+    if getattr(self, '_tape', None) is not None:
+      torch.cuda.synchronize()
+      ops.tape_free(self._tape)
     self._graph = self._static = self._graph_out = None
+    self._tape = self._cap_stream = None
 
   def _replay(self, images, labels, lam1, lam2, lr):
+    srcs = []
     for dst, src in zip(self._static, (images, labels, lam1, lam2)):
+      if dst is not None and src is not None and dst.dtype == torch.int32 and src.dtype != torch.int32 and src.dim() == 1:
+        src = src.to(torch.int32)
       if (dst is None) != (src is None) or (dst is not None and (dst.shape != src.shape or dst.dtype != src.dtype)):
         raise ValueError('the captured step takes inputs of the shapes / dtypes it was captured with')
-      if dst is not None and dst.data_ptr() != src.data_ptr():
-        dst.copy_(src, non_blocking=True)
-    self._graph.replay()
-    loss_rows, loss_scale, keep_prob = self._graph_out
-    return self._apply(loss_rows, loss_scale, keep_prob, lr)
+      srcs.append(src)
+    # The whole step -- input copies, the recording, the optimiser -- runs on the stream the recording was made on, between
+    # two joins with the caller's stream.  Measured (same box, ms per step): everything on that one stream 25.08; recording
+    # on it but input copies and optimiser on the default stream 26.2 - 26.5 (the eager step: 25.3 on the default stream,
+    # 25.7 - 26.0 on another).
+    cur = torch.cuda.current_stream()
+    cap = self._cap_stream
+    same = cap == cur
+    if not same:
+      ops.stream_join(cap, cur)
+      torch.cuda.set_stream(cap)
+    try:
+      for dst, src in zip(self._static, srcs):
+        if dst is not None and dst.data_ptr() != src.data_ptr():
+          dst.copy_(src, non_blocking=True)
+      if self._tape is not None:
+        ops.tape_replay(self._tape)       # (the recording ends with its side streams joined into the capture stream)
+      else:
+        self._graph.replay()
+      loss_rows, loss_scale, keep_prob = self._graph_out
+      out = self._apply(loss_rows, loss_scale, keep_prob, lr)
+    finally:
+      if not same:
+        torch.cuda.set_stream(cur)
+    if not same:
+      ops.stream_join(cur, cap)
+    return out
 
   def cross_entropy(self) -> torch.Tensor:
     """mean over the batch of (CE + KD) of the last step (device scalar)."""

@@ -239,6 +239,15 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
     if os.environ.get('NCCL_DEBUG', '').upper() in ('', 'VERSION'):
       os.environ['NCCL_DEBUG'] = 'WARN'     # no version banner on stdout next to the one JSON line
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    eager_ms = None
+    if plain_ms is None:      # the timed region replayed a launch tape: the exchange leg is eager, so is its reference
+      step()
+      sync()
+      t1 = time.time()
+      for _ in range(args.steps):
+        step()
+      sync()
+      plain_ms = eager_ms = 1000.0 * (time.time() - t1) / args.steps
     gs = dp.GradSync(tr.model.arena, comm_dtype=args.comm_dtype)
     tr.grad_sync = gs
     for _ in range(2):
@@ -253,6 +262,8 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
     info.update({'ms_per_step_with_exchange': round(ms, 3), 'exchange_ms_exposed': round(ms - plain_ms, 3),
                  'what': 'RCCL group of ONE rank on this GPU (bucket launches, waits and casts are real, xGMI traffic is '
                          'not); NO N > 1 number exists in this repository until the driver\'s SCALE run'})
+    if eager_ms is not None:
+      info['eager_ms_per_step_without_exchange'] = round(eager_ms, 3)
     tr.grad_sync = None
     tr.model.arena.on_grad = None
     dist.destroy_process_group()
@@ -280,6 +291,9 @@ def main():
                        'timed region is the product default (weight gradients and the big branch of a BigLittle '
                        'stage on side streams) and the single-stream rate is reported as an extra')
   ap.add_argument('--dump-convs', default='', help='write the per-conv-shape HIP-event times of the instrumented step here (markdown)')
+  ap.add_argument('--eager', action='store_true',
+                  help='N = 1: time the eager step (~930 launches enqueued by Python) instead of the recorded one '
+                       '(Trainer.capture: the same launches replayed from a launch tape by one C call)')
   ap.add_argument('--no-gradsync', action='store_true', help='N = 1: skip the extra leg with the gradient exchange attached')
   ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='precision of the exchanged gradient buckets')
   ap.add_argument('--dry-run-cpu', action='store_true',
@@ -370,6 +384,17 @@ def main():
     summ = t.summary()
     return max(summ, key=lambda k: summ[k][1]) if summ else None
 
+  # N = 1, product default: the step as a launch tape (Trainer.capture) -- bit-identical to the eager step, ~3 ms of host
+  # time per step instead of ~14, so a busy host cannot make the step host-bound.  (N > 1: eager, the gradient buckets are
+  # handed to RCCL by the host between launches.  --single-stream: eager, its HIP-event instrumentation wraps launches.)
+  taped = not dry and world == 1 and not args.eager and not args.single_stream and os.environ.get('ASM_STEP_TAPE', '1') != '0'
+  on_stream = (taped and os.environ.get('ASM_BENCH_STREAM', '1') != '0') or (not dry and os.environ.get('ASM_BENCH_STREAM', '') == '1')
+  if on_stream:
+    # The loop itself runs on the trainer's stream (`with torch.cuda.stream(trainer.stream)` in a training script): a
+    # recorded step replayed from the default stream joins that stream with its own at both ends of every step, which
+    # measured 25.9 ms per step against 24.65 with the default stream out of the loop (same box, same recording).
+    tr.stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(tr.stream)
   dominant = None
   for i in range(args.warmup):
     if i == args.warmup - 1 and not args.no_roofline and args.single_stream:
@@ -379,8 +404,13 @@ def main():
   # stream calibration (untimed, after the warm-up): Trainer.calibrate_streams keeps the side streams unless this process's
   # stream -> hardware-queue mapping makes them slower than one stream; ASM_STREAM_AUTOTUNE=0 skips it
   stream_cal = None
-  if not dry and not args.single_stream and os.environ.get('ASM_STREAM_AUTOTUNE', '1') != '0':
+  if not dry and not args.single_stream and not taped and os.environ.get('ASM_STREAM_AUTOTUNE', '1') != '0':
     stream_cal = tr.calibrate_streams(step)
+  tape_info = None
+  if taped:
+    tr.capture(images, labels, lam1, warmup=0, replay=os.environ.get('ASM_STEP_REPLAY', 'tape'))
+    tape_info = ops.tape_info(tr._tape) if tr._tape is not None else {'launches': 0, 'joins': 0}
+    step()                      # first replay (untimed)
   timer = None
   if dominant is not None and args.single_stream:
     timer = ops.ConvTimer(only=dominant)
@@ -407,12 +437,17 @@ def main():
   abi_calls = (ops.abi_calls() - calls0) / max(args.steps, 1)
   kernels_per_step = ((ops.L().asm_launch_count() - kern0) / max(args.steps, 1)) if not dry else None
   ops.set_conv_timer(None)
+  if taped:
+    tr.release_graph()          # the legs below instrument or re-wire the eager step
+  if on_stream:
+    torch.cuda.default_stream().wait_stream(tr.stream)
+    torch.cuda.set_stream(torch.cuda.default_stream())
   if world > 1:
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
   if world == 1 and not args.no_gradsync and not dry:   # same streams as the timed region, plus the exchange
-    dp_info = _gradsync_leg(tr, step, sync, args, 1000.0 * el / args.steps)
+    dp_info = _gradsync_leg(tr, step, sync, args, None if taped else 1000.0 * el / args.steps)
   class_sum = None
   INSTR = 3
   single = None
@@ -566,6 +601,9 @@ def main():
                             'host': {'cpus': os.cpu_count(), 'loadavg_1min': round(os.getloadavg()[0], 2)},
                             'what': 'per timed step: time between consecutive end-of-step events on the compute stream, and '
                                     'host time to enqueue the step (the host runs ahead of the GPU when its median is the smaller)'}
+    out['step_mode'] = ('launch tape: the step recorded once by Trainer.capture and replayed by asm_tape_replay (%d kernel launches, '
+                        '%d cross-stream joins per step; bit-identical to the eager step, tests/test_gpu_model.py)'
+                        % (tape_info['launches'], tape_info['joins'])) if tape_info else 'eager: every launch enqueued by the Python host code'
     if stream_cal is not None:
       out['streams_autotune'] = dict(stream_cal, what='Trainer.calibrate_streams after the warm-up, 3 untimed steps per setting: '
                                      'the timed region runs the chosen one (side streams unless > 3 % slower than one stream)')

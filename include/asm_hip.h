@@ -35,13 +35,38 @@ extern "C" {
 #define ASM_ENOTSUP (-2)
 #define ASM_EHIP (-3)
 
-#define ASM_ABI_VERSION 2
+#define ASM_ABI_VERSION 3
 
 const char* asm_last_error(void);
 int asm_abi_version(void);
 /* kernels this library has launched so far in this process (every stream, every thread): a training step's launch count is
  * the difference across it.  hipMemcpyAsync / hipMemsetAsync fills of the strided 1x1 input gradient are not kernels. */
 unsigned long long asm_launch_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Launch tape: a sequence of this library's device operations recorded once and issued again by one call.
+ * Between asm_tape_begin and asm_tape_end every kernel launch THIS host thread makes through the library is also written
+ * down (kernel, geometry, stream, a copy of the arguments), and so is every asm_stream_join; the operations execute as
+ * usual while they are recorded (or are captured, when the streams are in HIP stream capture -- which is how
+ * train.Trainer.capture records a training step: the capture's private memory pool keeps every buffer of the step at its
+ * address, the tape replays the launches without hipGraphLaunch's per-node host cost).  asm_tape_replay issues the recorded
+ * operations again, on the recorded streams, with the recorded arguments: the caller guarantees that every pointer in them
+ * is still what it was.  asm_tape_mark closes a segment and opens the next; asm_tape_replay(tape, s) replays segment s
+ * only (s = -1: all of them), so that the host can act between segments (hand a gradient bucket to RCCL).
+ *   asm_tape_begin   -> tape id (> 0); one recording per thread at a time
+ *   asm_tape_mark    -> index of the segment that starts here (1, 2, ...)
+ *   asm_tape_end     -> tape id; the tape can be replayed from now on
+ *   asm_tape_info    -> info = {nodes, kernel launches, joins, fills, segments, argument bytes}
+ *   asm_tape_free    -> drops the tape and its events
+ * asm_stream_join(dst, src): dst waits for everything enqueued on src so far (event record + stream wait; raw
+ * hipStream_t handles).  The host layer uses it for every cross-stream edge of a step so that a tape sees them. */
+int asm_stream_join(void* dst_stream, void* src_stream);
+int asm_tape_begin(void);
+int asm_tape_mark(void);
+int asm_tape_end(void);
+int asm_tape_info(int tape, int64_t info[6]);
+int asm_tape_replay(int tape, int segment);
+int asm_tape_free(int tape);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel-selection overrides (tests, same-box A/B runs, tuning).  The defaults are the heuristics the

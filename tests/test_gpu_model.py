@@ -225,40 +225,106 @@ def test_side_streams_change_no_bit_over_several_steps(hip_lib, monkeypatch, siz
     assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
 
 
-def test_the_step_as_one_hip_graph_is_the_same_step(hip_lib):
-  """Trainer.capture: inputs -> forward -> loss -> backward recorded into a HIP graph (side streams included), replayed
-  over static input buffers with the optimiser outside.  Two eager steps + four replays on alternating batches against six
-  eager steps: identical losses, weights, momentum and moving statistics, bit for bit.  And what it refuses."""
+@pytest.mark.parametrize('mixup', [0, 1])
+def test_the_step_as_one_hip_graph_is_the_same_step(hip_lib, mixup):
+  """Trainer.capture: inputs -> forward -> loss -> backward recorded (side streams included) and replayed over static input
+  buffers with the optimiser outside -- as a launch tape (the library re-issues the recorded launches: csrc/tape.hip) and as
+  a HIP graph.  Two eager steps + four replays on alternating batches against six eager steps: identical losses, weights,
+  momentum and moving statistics, bit for bit.  And what it refuses."""
+  from assembled_cnn_amd import ops
   from assembled_cnn_amd.train import HParams, Trainer
   hp = dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
-            zero_gamma=True, learning_rate_decay_type='cosine', base_learning_rate=0.01, batch_size=8, label_smoothing=0.1)
-  batches = [mp.inputs(8, 64, seed=s) for s in (1, 2)]
-  batches = [(b[0].cuda(), b[2].cuda()) for b in batches]
+            zero_gamma=True, learning_rate_decay_type='cosine', base_learning_rate=0.01, batch_size=8, label_smoothing=0.1,
+            mixup_type=mixup)
+  nin = 16 if mixup else 8
+  batches = [mp.inputs(nin, 64, seed=s) for s in (1, 2)]
+  lams = [torch.rand(nin // 2, generator=torch.Generator().manual_seed(s)).cuda() if mixup else None for s in (3, 4)]
+  batches = [(b[0].cuda(), b[2].cuda(), l) for b, l in zip(batches, lams)]
   runs = []
-  for graphed in (False, True):
+  for mode in (None, 'tape', 'graph'):
     tr = Trainer(HParams(**hp), seed=0, device='cuda')
     losses = []
     for s in range(6):
-      if graphed and s == 2:
-        tr.capture(batches[0][0], batches[0][1], warmup=0)
+      if mode and s == 2:
+        tr.capture(*batches[0], warmup=0, replay=mode)
+        if mode == 'tape':
+          info = ops.tape_info(tr._tape)
+          assert info['launches'] > 300 and info['joins'] > 20 and info['segments'] == 1, info
       tr.train_step(*batches[s % 2])
       losses.append(float(tr.cross_entropy()))
     torch.cuda.synchronize()
     a = tr.model.arena
     runs.append((losses, a.w32.clone(), a.m32.clone(), a.state.clone()))
-    if graphed:
+    if mode:
       with pytest.raises(RuntimeError):
         tr.capture(*batches[0])                                   # already captured
       with pytest.raises(ValueError):
         tr.train_step(batches[0][0][:4], batches[0][1][:4])     # not the captured shapes
       tr.release_graph()
-      tr.train_step(batches[0][0][:4].contiguous(), batches[0][1][:4].contiguous())   # eager again
-  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
-  for p, q in zip(runs[0][1:], runs[1][1:]):
-    assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
+      small = (batches[0][0][:nin // 2].contiguous(), batches[0][1][:nin // 2].contiguous(),
+               lams[0][:nin // 4].contiguous() if mixup else None)
+      tr.train_step(*small)   # eager again
+  for r in runs[1:]:
+    assert runs[0][0] == r[0], (runs[0][0], r[0])
+    for p, q in zip(runs[0][1:], r[1:]):
+      assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
   db = Trainer(HParams(**dict(hp, use_dropblock=True)), seed=0, device='cuda')
   with pytest.raises(NotImplementedError):
     db.capture(*batches[0])
+
+
+def test_a_tape_replays_what_was_recorded(hip_lib):
+  """The launch tape on its own: three launches on two streams with a join between them, recorded while they run, replayed
+  twice after the inputs changed; segments replay separately; what the entry points refuse."""
+  from assembled_cnn_amd import lib, ops
+  L = ops.L()
+  x = torch.randn(4096, device='cuda').to(torch.bfloat16)
+  s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+  torch.cuda.synchronize()
+
+  def body(mark):
+    with torch.cuda.stream(s1):
+      a = ops.relu_fwd(x)
+    if mark:
+      assert ops.tape_mark() == 1
+    ops.stream_join(s2, s1)
+    with torch.cuda.stream(s2):
+      b = ops.relu_fwd(a)
+      c = torch.empty(4096, device='cuda')
+      ops.cast_bf16_to_f32(b, c)
+    ops.stream_join(torch.cuda.current_stream(), s2)
+    return a, b, c
+
+  t = ops.tape_begin()
+  with pytest.raises(ValueError):
+    ops.tape_begin()
+  a, b, c = body(True)      # (every buffer of the recording stays alive: a replay writes to the recorded addresses)
+  assert ops.tape_end() == t
+  with pytest.raises(ValueError):
+    ops.tape_end()
+  info = ops.tape_info(t)
+  assert (info['launches'], info['joins'], info['fills'], info['segments']) == (3, 2, 0, 2), info
+  torch.cuda.synchronize()
+  assert torch.equal(c, x.float().clamp_min(0))
+  for seed in (1, 2):
+    x.copy_(torch.randn(4096, generator=torch.Generator().manual_seed(seed)).to(torch.bfloat16))
+    c.zero_()
+    n0 = L.asm_launch_count()
+    if seed == 1:
+      ops.tape_replay(t)
+    else:
+      ops.tape_replay(t, 0)
+      ops.tape_replay(t, 1)
+    assert L.asm_launch_count() - n0 == 3
+    torch.cuda.synchronize()
+    assert torch.equal(c, x.float().clamp_min(0))
+  with pytest.raises(ValueError):
+    ops.tape_replay(t, 2)
+  ops.tape_free(t)
+  with pytest.raises(ValueError):
+    ops.tape_replay(t)
+  with pytest.raises(ValueError):
+    ops.tape_mark()
 
 
 @pytest.mark.parametrize('name,size', [('r101v1-gem-emb', 64), ('r50v1-nodown-flatten-sigmoid', 32)])
