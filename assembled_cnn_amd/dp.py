@@ -87,6 +87,11 @@ class GradSync(object):
       if ops.knob('ASM_DP_LAUNCH_STREAM', '1') != '0':
         self._launch_stream = torch.cuda.Stream(device=arena.g32.device)
 
+    # Trainer.capture with an exchange attached: while the step is being RECORDED a bucket launch only cuts the launch tape
+    # (ops.tape_mark) and is written down; the replayed step hands bucket k to RCCL after tape segment k (launch_recorded)
+    self.recording = False
+    self.recorded: List[Tuple[int, int]] = []
+
   def _reset(self):
     self._next = [0 for _ in self.segments]     # next bucket (index) to launch per segment
     self._work = []
@@ -109,7 +114,28 @@ class GradSync(object):
       self._launch(s, self._next[s])
       self._next[s] += 1
 
+  def begin_recording(self):
+    self._reset()
+    self.recording, self.recorded = True, []
+
+  def end_recording(self):
+    self.recording = False
+    self._reset()
+
+  def launch_recorded(self, k: int):
+    """Replay: hand over the bucket whose launch closed tape segment ``k`` of the recorded step."""
+    s, i = self.recorded[k]
+    if self._next[s] != i:
+      raise RuntimeError('recorded bucket launches replayed out of order (segment %d bucket %d, expected %d)' % (s, i, self._next[s]))
+    self._launch(s, i)
+    self._next[s] = i + 1
+
   def _launch(self, s: int, i: int):
+    if self.recording:
+      from . import ops
+      ops.tape_mark()
+      self.recorded.append((s, i))
+      return
     lo, hi = self.segments[s][i]
     self._reduced += hi - lo
     # RCCL's stream is ordered against the CURRENT stream only; the gradients of this bucket were written on the compute

@@ -360,8 +360,10 @@ class Trainer(object):
     step's nodes, so this only pays where the eager step is host-bound anyway.
 
     Both replays are bit-identical to the eager step (tests/test_gpu_model.py).  Not available with DropBlock (its
-    keep_prob and random draws change per step) or an attached gradient exchange (bucket launches are interleaved with the
-    backward by the host).  ``warmup`` real training steps run first (one-time initialisation must not be recorded).
+    keep_prob and random draws change per step).  With a gradient exchange attached (dp.GradSync) only the tape works: the
+    bucket launches the host interleaves with the backward pass become segment boundaries of the tape, and the replayed
+    step hands bucket k to RCCL after segment k (tests/test_gpu_dp_rccl.py).  ``warmup`` real training steps run first
+    (one-time initialisation must not be recorded).
     Every activation of a step stays allocated until release_graph(); ``capture_error_mode='thread_local'`` if other
     threads (an input pipeline) touch the device while capturing.  ASM_* switches are frozen into the recording."""
     if self._graph is not None:
@@ -370,8 +372,11 @@ class Trainer(object):
       raise ValueError("replay must be 'tape' or 'graph'")
     if self.keep_prob_fn is not None:
       raise NotImplementedError('DropBlock changes keep_prob and its draws every step: the step cannot be one static recording')
-    if self.grad_sync is not None:
-      raise NotImplementedError('with a gradient exchange attached the bucket launches are host-driven: eager steps only')
+    if self.grad_sync is not None and replay != 'tape':
+      raise NotImplementedError('with a gradient exchange attached the bucket launches are host-driven: a HIP graph cannot '
+                                'hold them; the launch tape is cut into segments at the bucket launches instead')
+    if self.grad_sync is not None and not hasattr(self.grad_sync, 'launch_recorded'):
+      raise NotImplementedError('capture needs a dp.GradSync as the gradient exchange (segmented replay)')
     if not images.is_cuda:
       raise RuntimeError('capture needs device tensors')
     if labels.dim() == 1 and labels.dtype != torch.int32:
@@ -392,14 +397,23 @@ class Trainer(object):
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     tape = None
+    gs = self.grad_sync
+    if gs is not None and capture_error_mode == 'global':
+      capture_error_mode = 'thread_local'      # the collective library's watchdog thread queries events while we capture
     with torch.cuda.graph(g, stream=cap, capture_error_mode=capture_error_mode):
       if replay == 'tape':
         tape = ops.tape_begin()
+      if gs is not None:
+        gs.begin_recording()      # bucket launches of the recorded backward pass become segment boundaries of the tape
       try:
         out = self._forward_backward(*static)
       finally:
+        if gs is not None:
+          gs.end_recording()
         if tape is not None:
           ops.tape_end()
+    if gs is not None and ops.tape_info(tape)['segments'] != len(gs.recorded) + 1:
+      raise RuntimeError('tape segments and recorded bucket launches disagree')
     self._graph, self._static, self._graph_out = g, static, out
     self._tape, self._cap_stream = tape, cap
     return self
@@ -433,7 +447,13 @@ class Trainer(object):
       for dst, src in zip(self._static, srcs):
         if dst is not None and dst.data_ptr() != src.data_ptr():
           dst.copy_(src, non_blocking=True)
-      if self._tape is not None:
+      gs = self.grad_sync
+      if self._tape is not None and gs is not None:
+        for k in range(len(gs.recorded)):   # segment k, then the bucket that became ready at its end goes to RCCL
+          ops.tape_replay(self._tape, k)
+          gs.launch_recorded(k)
+        ops.tape_replay(self._tape, len(gs.recorded))
+      elif self._tape is not None:
         ops.tape_replay(self._tape)       # (the recording ends with its side streams joined into the capture stream)
       else:
         self._graph.replay()

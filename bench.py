@@ -225,7 +225,7 @@ def _dp_plan(gs, world):
           'overlap': 'buckets are launched as the backward watermark passes them; the optimiser waits for the last one'}
 
 
-def _gradsync_leg(tr, step, sync, args, plain_ms):
+def _gradsync_leg(tr, step, sync, args, plain_ms, capture=None):
   """N = 1: the same steps with dp.GradSync attached to an RCCL group of ONE rank: every bucket launch, stream wait and
   (bf16) cast is real, only the link traffic is missing.  exchange_ms_exposed = step with the exchange - step without."""
   import socket
@@ -239,17 +239,10 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
     if os.environ.get('NCCL_DEBUG', '').upper() in ('', 'VERSION'):
       os.environ['NCCL_DEBUG'] = 'WARN'     # no version banner on stdout next to the one JSON line
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
-    eager_ms = None
-    if plain_ms is None:      # the timed region replayed a launch tape: the exchange leg is eager, so is its reference
-      step()
-      sync()
-      t1 = time.time()
-      for _ in range(args.steps):
-        step()
-      sync()
-      plain_ms = eager_ms = 1000.0 * (time.time() - t1) / args.steps
     gs = dp.GradSync(tr.model.arena, comm_dtype=args.comm_dtype)
     tr.grad_sync = gs
+    if capture is not None:   # the timed region replayed a recorded step: so does this leg (the tape cut at the bucket launches)
+      capture()
     for _ in range(2):
       step()
     sync()
@@ -262,8 +255,9 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
     info.update({'ms_per_step_with_exchange': round(ms, 3), 'exchange_ms_exposed': round(ms - plain_ms, 3),
                  'what': 'RCCL group of ONE rank on this GPU (bucket launches, waits and casts are real, xGMI traffic is '
                          'not); NO N > 1 number exists in this repository until the driver\'s SCALE run'})
-    if eager_ms is not None:
-      info['eager_ms_per_step_without_exchange'] = round(eager_ms, 3)
+    if capture is not None:
+      info['step_mode'] = 'launch tape in %d segments, one bucket handed to RCCL after each but the last' % (len(gs.recorded) + 1)
+      tr.release_graph()
     tr.grad_sync = None
     tr.model.arena.on_grad = None
     dist.destroy_process_group()
@@ -271,6 +265,10 @@ def _gradsync_leg(tr, step, sync, args, plain_ms):
   except Exception as e:   # a reported extra must never lose the measured number
     tr.grad_sync = None
     tr.model.arena.on_grad = None
+    try:
+      tr.release_graph()
+    except Exception:
+      pass
     return {'world': 1, 'error': repr(e)}
 
 
@@ -385,9 +383,9 @@ def main():
     return max(summ, key=lambda k: summ[k][1]) if summ else None
 
   # N = 1, product default: the step as a launch tape (Trainer.capture) -- bit-identical to the eager step, ~3 ms of host
-  # time per step instead of ~14, so a busy host cannot make the step host-bound.  (N > 1: eager, the gradient buckets are
-  # handed to RCCL by the host between launches.  --single-stream: eager, its HIP-event instrumentation wraps launches.)
-  taped = not dry and world == 1 and not args.eager and not args.single_stream and os.environ.get('ASM_STEP_TAPE', '1') != '0'
+  # time per step instead of ~14, so a busy host cannot make the step host-bound.  (N > 1: the tape is cut where the host
+  # hands a gradient bucket to RCCL.  --single-stream: eager, its HIP-event instrumentation wraps launches.)
+  taped = not dry and not args.eager and not args.single_stream and os.environ.get('ASM_STEP_TAPE', '1') != '0'
   on_stream = (taped and os.environ.get('ASM_BENCH_STREAM', '1') != '0') or (not dry and os.environ.get('ASM_BENCH_STREAM', '') == '1')
   if on_stream:
     # The loop itself runs on the trainer's stream (`with torch.cuda.stream(trainer.stream)` in a training script): a
@@ -406,11 +404,24 @@ def main():
   stream_cal = None
   if not dry and not args.single_stream and not taped and os.environ.get('ASM_STREAM_AUTOTUNE', '1') != '0':
     stream_cal = tr.calibrate_streams(step)
-  tape_info = None
-  if taped:
+  tape_info = tape_error = None
+
+  def capture_step():
     tr.capture(images, labels, lam1, warmup=0, replay=os.environ.get('ASM_STEP_REPLAY', 'tape'))
-    tape_info = ops.tape_info(tr._tape) if tr._tape is not None else {'launches': 0, 'joins': 0}
-    step()                      # first replay (untimed)
+
+  if taped:
+    try:
+      capture_step()
+      tape_info = ops.tape_info(tr._tape) if tr._tape is not None else {'launches': 0, 'joins': 0, 'segments': 1}
+      step()                      # first replay (untimed)
+    except Exception as e:        # the number must not depend on the recording: fall back to the eager step, and say so
+      tape_error = repr(e)
+      taped = False
+      try:
+        tr.release_graph()
+      except Exception:
+        pass
+      torch.cuda.synchronize()
   timer = None
   if dominant is not None and args.single_stream:
     timer = ops.ConvTimer(only=dominant)
@@ -439,15 +450,15 @@ def main():
   ops.set_conv_timer(None)
   if taped:
     tr.release_graph()          # the legs below instrument or re-wire the eager step
-  if on_stream:
-    torch.cuda.default_stream().wait_stream(tr.stream)
-    torch.cuda.set_stream(torch.cuda.default_stream())
   if world > 1:
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
   if world == 1 and not args.no_gradsync and not dry:   # same streams as the timed region, plus the exchange
-    dp_info = _gradsync_leg(tr, step, sync, args, None if taped else 1000.0 * el / args.steps)
+    dp_info = _gradsync_leg(tr, step, sync, args, 1000.0 * el / args.steps, capture_step if taped else None)
+  if on_stream:
+    torch.cuda.default_stream().wait_stream(tr.stream)
+    torch.cuda.set_stream(torch.cuda.default_stream())
   class_sum = None
   INSTR = 3
   single = None
@@ -604,6 +615,10 @@ def main():
     out['step_mode'] = ('launch tape: the step recorded once by Trainer.capture and replayed by asm_tape_replay (%d kernel launches, '
                         '%d cross-stream joins per step; bit-identical to the eager step, tests/test_gpu_model.py)'
                         % (tape_info['launches'], tape_info['joins'])) if tape_info else 'eager: every launch enqueued by the Python host code'
+    if tape_info and tape_info.get('segments', 1) > 1:
+      out['step_mode'] += '; %d segments, a gradient bucket handed to RCCL after each but the last' % tape_info['segments']
+    if tape_error:
+      out['step_mode'] += ' (recording the step failed: %s)' % tape_error
     if stream_cal is not None:
       out['streams_autotune'] = dict(stream_cal, what='Trainer.calibrate_streams after the warm-up, 3 untimed steps per setting: '
                                      'the timed region runs the chosen one (side streams unless > 3 % slower than one stream)')

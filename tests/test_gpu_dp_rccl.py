@@ -125,3 +125,50 @@ def test_buckets_wait_for_every_stream_that_writes_gradients(hip_lib):
     tr.model.arena.on_grad = None
   finally:
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_recorded_step_hands_buckets_to_rccl_between_tape_segments(hip_lib):
+  """Trainer.capture with the exchange attached: the bucket launches of the recorded backward pass cut the launch tape into
+  segments, and the replayed step hands bucket k to RCCL after segment k.  bf16 exchange (see the test above: a bucket
+  launched before its gradients arrived would come back as bf16(stale value)), 4 MiB buckets, side streams on: two eager
+  steps + four replayed steps on alternating batches must leave the same weights, momentum and moving statistics, bit for
+  bit, as six eager steps with the same exchange."""
+  import torch.distributed as dist
+  from assembled_cnn_amd import dp, ops
+  from assembled_cnn_amd.train import HParams, Trainer
+  from tests import model_parity as mpar
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  assert not dist.is_initialized()
+  dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1)
+  try:
+    hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
+                 use_resnet_d=True, zero_gamma=True, learning_rate_decay_type='cosine', base_learning_rate=0.01,
+                 weight_decay=1e-4, batch_size=32)
+    batches = [mpar.inputs(32, 128, seed=s) for s in (1, 2)]
+    batches = [(b[0].cuda(), b[2].cuda()) for b in batches]
+    runs = []
+    for taped in (False, True):
+      tr = Trainer(hp, seed=0, device='cuda', world_size=1)
+      tr.model.build((128, 128), use_resnet_d=True)
+      tr.grad_sync = dp.GradSync(tr.model.arena, bucket_bytes=4 << 20, comm_dtype='bf16')
+      for s in range(6):
+        if taped and s == 2:
+          with pytest.raises(NotImplementedError):
+            tr.capture(*batches[0], warmup=0, replay='graph')
+          tr.capture(*batches[0], warmup=0)
+          info = ops.tape_info(tr._tape)
+          assert info['segments'] == len(tr.grad_sync.recorded) + 1 and len(tr.grad_sync.recorded) >= 8, info
+        tr.train_step(*batches[s % 2])
+      torch.cuda.synchronize()
+      a = tr.model.arena
+      runs.append((a.w32.clone(), a.m32.clone(), a.state.clone()))
+      if taped:
+        tr.release_graph()
+        tr.train_step(*batches[0])      # eager again, exchange still attached
+        torch.cuda.synchronize()
+      a.on_grad = None
+    for p, q in zip(*runs):
+      assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
+  finally:
+    dist.destroy_process_group()
