@@ -126,8 +126,7 @@ class ParamArena(object):
         self.on_grad(off)
 
   def enable_side_stream(self, fresh: bool = False):
-    """``fresh``: drop parked streams and create new ones (Trainer.calibrate_streams: how the runtime places a stream on
-    the hardware queues is decided when the stream is created, and some placements are pathological for this step)."""
+    """``fresh``: drop parked streams and create new ones instead of reusing them."""
     if fresh:
       self._parked = []
     if self.w32 is not None and self.w32.is_cuda and self.side_stream is None and getattr(self, '_parked', None):
@@ -161,7 +160,7 @@ class ParamArena(object):
 
   def disable_side_stream(self):
     """Weight gradients back onto the compute stream.  The stream objects are parked, not dropped: switching the side
-    streams on again reuses them (and their hardware-queue placement)."""
+    streams on again reuses them."""
     self.join_side_stream()
     if self._sides:
       self._parked = list(self._sides)

@@ -213,18 +213,21 @@ class Trainer(object):
       else:
         a.disable_side_stream()
 
-  def calibrate_streams(self, step_fn, steps: int = 3, margin: float = 0.03, redraws: int = 2):
-    """Time ``steps`` training steps with the side streams on and off and keep the faster setting.
+  def calibrate_streams(self, step_fn, steps: int = 3, margin: float = 0.03, redraws: int = 0):
+    """Time ``steps`` EAGER training steps with the side streams on and off and keep the faster setting.
 
-    Why this exists (round 4): where the HIP runtime places a stream on the hardware queues is decided when the stream is
-    created and is not under the program's control, and some placements are pathological for this step -- the
-    one-workgroup-per-CU 256 x 256 tiles of kernels on truly concurrent hardware queues evict each other (DESIGN.md
-    section 5: 37 - 100 ms per step instead of 26, seen for whole processes on some boxes).  The side streams are worth
-    ~1 ms per step when the placement is the usual one and cost 20 - 70 ms when it is not, so the trainer measures
-    instead of assuming: the streams it measured stay on (the SAME stream objects: switching off only parks them) unless
-    they are more than ``margin`` slower than one stream; then up to ``redraws`` freshly created sets are tried before
-    the step falls back to one stream.  ``step_fn()`` runs one real training step (the steps taken here are ordinary
-    steps).  Returns the measurements."""
+    Why this exists (round 4): the side streams are worth ~1 ms per step, but they also make the eager step more expensive
+    to ENQUEUE (an event record + a stream wait per weight gradient), and the eager step has little host head-room: ~14.5 ms
+    of Python per step against ~25 ms of GPU time.  On a busy host the step becomes host-bound, and the side-stream form
+    degrades first: with one busy loop beside the Python thread 30.2 ms per step against 26.7 on one stream, with two 48.5
+    against 33.3 (tools/debug/host_contention.sh; the GPU boxes this was developed on are shared, 256 hardware threads at
+    load averages of 40 - 65).  Rounds 3 - 4 first read those runs as a problem of where the runtime places streams on the
+    hardware queues; ``redraws`` (fresh stream objects when the side streams lose) is what is left of that reading and is
+    off by default.  The measurement itself stays: an eager trainer keeps the side streams unless they are more than
+    ``margin`` slower than one stream in THIS process on THIS host.  The real remedy for a busy host is to take the host
+    out of the step -- Trainer.capture replays the recorded launches in ~3 ms of host time per step and needs no
+    calibration.  ``step_fn()`` runs one real training step (the steps taken here are ordinary steps).  Returns the
+    measurements."""
     import time
 
     def timed(on, fresh=False):
