@@ -365,17 +365,19 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
                                                   float lr, float mom, float wd, float gs) {
   const size_t nv = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
-    f32x4 wv = *reinterpret_cast<const f32x4*>(w + i * 4);
-    f32x4 av = *reinterpret_cast<const f32x4*>(a + i * 4);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+    // fp32 master weights, momentum and gradients are touched once per step, here: streamed past the caches (the bf16
+    // shadow below is what the next forward pass reads)
+    f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + i * 4));
+    f32x4 av = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + i * 4));
+    const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i * 4));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float gg = gv[e] * gs + wd * wv[e];
       av[e] = mom * av[e] + gg;
       wv[e] = wv[e] - lr * av[e];
     }
-    *reinterpret_cast<f32x4*>(w + i * 4) = wv;
-    *reinterpret_cast<f32x4*>(a + i * 4) = av;
+    __builtin_nontemporal_store(wv, reinterpret_cast<f32x4*>(w + i * 4));
+    __builtin_nontemporal_store(av, reinterpret_cast<f32x4*>(a + i * 4));
     if (wb) {
       u32x2 o = {pack2bf(wv[0], wv[1]), pack2bf(wv[2], wv[3])};
       *reinterpret_cast<u32x2*>(wb + i * 4) = o;

@@ -68,3 +68,36 @@ def test_product_never_imports_oracle():
         src = open(os.path.join(dirpath, f)).read()
         assert 'import oracle' not in src and 'from oracle' not in src and 'cpu_double' not in src.replace(
             'double lives under tests/', ''), f
+
+
+def test_launch_tape_bookkeeping_needs_no_gpu():
+  """asm_tape_begin / mark / end / info / replay / free on an EMPTY recording: pure host code (csrc/tape.hip), so the
+  segment bookkeeping and the error returns are checked here; recordings with launches are GPU tests."""
+  from assembled_cnn_amd import lib
+  L = lib.load()
+  info = (ctypes.c_int64 * 6)()
+  assert L.asm_tape_mark() < 0                       # nothing is being recorded
+  assert L.asm_tape_end() < 0
+  t = L.asm_tape_begin()
+  assert t > 0
+  assert L.asm_tape_begin() < 0, 'one recording per thread'
+  assert b'already recording' in L.asm_last_error()
+  assert L.asm_tape_replay(t, -1) < 0, 'a tape that is being recorded cannot be replayed'
+  assert L.asm_tape_mark() == 1 and L.asm_tape_mark() == 2
+  assert L.asm_tape_end() == t
+  assert L.asm_tape_info(t, ctypes.byref(info)) == 0
+  assert list(info) == [0, 0, 0, 0, 3, 0]            # no nodes; three (empty) segments
+  for seg in (-1, 0, 1, 2):
+    assert L.asm_tape_replay(t, seg) == 0
+  assert L.asm_tape_replay(t, 3) < 0
+  t2 = L.asm_tape_begin()
+  assert t2 == t + 1 and L.asm_tape_end() == t2
+  assert L.asm_tape_free(t) == 0 and L.asm_tape_free(t) < 0
+  assert L.asm_tape_replay(t, -1) < 0 and L.asm_tape_info(t, ctypes.byref(info)) < 0
+  assert L.asm_tape_free(t2) == 0
+  # a recording abandoned by freeing it stops recording
+  t3 = L.asm_tape_begin()
+  assert L.asm_tape_free(t3) == 0
+  assert L.asm_tape_end() < 0
+  t4 = L.asm_tape_begin()
+  assert t4 > 0 and L.asm_tape_end() == t4 and L.asm_tape_free(t4) == 0
