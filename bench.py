@@ -46,8 +46,8 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
-PMC_FILE = 'round4_b_pmc_traffic.json'        # dominant layer, tools/conv_bench.py in isolation (round 4, tools/profile_round.sh dominant)
-CLASS_TRAFFIC_FILE = 'round4_b_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
+PMC_FILE = 'round4_c_pmc_traffic.json'        # dominant layer, tools/conv_bench.py in isolation (round 4, tools/profile_round.sh dominant)
+CLASS_TRAFFIC_FILE = 'round4_c_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
 HBM_PEAK_GBS = 8000.0            # spec; MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {
@@ -629,7 +629,8 @@ def main():
                        'note': 'kernels_per_step: the library\'s own launch counter (asm_launch_count) across the timed region, '
                                'every stream; torch launches nothing inside a step.  abi_calls_per_step: C-ABI calls (one launch '
                                'each, except: strided input gradients = one per parity class, weight gradients = kernel + slab '
-                               'reduce); the rocprofv3 kernel count per step is in profiles/'}
+                               'reduce); the rocprofv3 kernel count per step is in profiles/.  With the recorded step the host makes a '
+                               'handful of calls per step (stream joins, asm_tape_replay, the optimiser): the launches are the tape\'s'}
     if dp_info is not None:
       out['dp'] = dp_info
     if dry:
