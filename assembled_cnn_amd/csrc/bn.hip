@@ -678,7 +678,30 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const bf16_t* __restr
   float s[8], ss[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
-  if (live)
+  // M <= 256 rows (the workload: one row per image): a lane's 8 rows are loaded in ONE batch and stay in registers for the
+  // apply pass.  (Round 4.  The plain loops below issue a load, wait, accumulate -- 8 + 8 dependent round trips to L2 for a
+  // kernel that moves 64 KB: 9 us.)  Same accumulation order, same bits.
+  constexpr int KU = 8;
+  const bool keep = M <= 32 * KU;
+  u32x4 kv[KU];
+  if (live && keep) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int r = rl + 32 * u;
+      kv[u] = *reinterpret_cast<const u32x4*>(x + (size_t)(r < M ? r : 0) * C + vc * 8);   // (row 0 always exists)
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (rl + 32 * u >= M) break;
+      float f[8];
+      unpack8(kv[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[e] += f[e];
+        ss[e] += f[e] * f[e];
+      }
+    }
+  } else if (live)
     for (int r = rl; r < M; r += 32) {
       float f[8];
       unpack8(*reinterpret_cast<const u32x4*>(x + (size_t)r * C + vc * 8), f);
@@ -719,23 +742,31 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const bf16_t* __restr
     }
   }
   __syncthreads();
-  if (live)
-    for (int r = rl; r < M; r += 32) {
-      const size_t i = (size_t)r * vcols + vc;
-      float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), f);
-      unsigned mk = 0;
+  auto apply_row = [&](int r, const u32x4& vx) {
+    const size_t i = (size_t)r * vcols + vc;
+    float f[8];
+    unpack8(vx, f);
+    unsigned mk = 0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        f[e] = f[e] * coef[0][vcl * 8 + e] + coef[1][vcl * 8 + e];
-        if (RELU) {
-          mk |= (f[e] > 0.f ? 1u : 0u) << e;
-          f[e] = fmaxf(f[e], 0.f);
-        }
+    for (int e = 0; e < 8; ++e) {
+      f[e] = f[e] * coef[0][vcl * 8 + e] + coef[1][vcl * 8 + e];
+      if (RELU) {
+        mk |= (f[e] > 0.f ? 1u : 0u) << e;
+        f[e] = fmaxf(f[e], 0.f);
       }
-      if (RELU && mask) mask[i] = (uint8_t)mk;
-      *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
     }
+    if (RELU && mask) mask[i] = (uint8_t)mk;
+    *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+  };
+  if (live && keep) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (rl + 32 * u >= M) break;
+      apply_row(rl + 32 * u, kv[u]);
+    }
+  } else if (live) {
+    for (int r = rl; r < M; r += 32) apply_row(r, *reinterpret_cast<const u32x4*>(x + ((size_t)r * vcols + vc) * 8));
+  }
 }
 
 template <int RELU>   // 0 none, 2 packed bitmask
@@ -758,23 +789,49 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const bf16_t* __restr
     mu[e] = live ? mean[vc * 8 + e] : 0.f;
     is[e] = live ? invstd[vc * 8 + e] : 0.f;
   }
-  if (live)
+  // as in bn_small_fwd_kernel: M <= 256 -> one batch of loads, rows kept in registers for the apply pass
+  constexpr int KU = 8;
+  const bool keep = M <= 32 * KU;
+  u32x4 kg[KU], kx[KU];
+  unsigned km[KU];
+  auto masked = [&](const u32x4& vg, unsigned mk, float* g) {
+    unpack8(vg, g);
+    if (RELU == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
+    }
+  };
+  auto reduce_row = [&](const u32x4& vg, const u32x4& vx, unsigned mk) {
+    float g[8], fx[8];
+    masked(vg, mk, g);
+    unpack8(vx, fx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] += g[e];
+      ss[e] += g[e] * ((fx[e] - mu[e]) * is[e]);
+    }
+  };
+  if (live && keep) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int r = rl + 32 * u;
+      const size_t i = (size_t)(r < M ? r : 0) * vcols + vc;
+      kg[u] = *reinterpret_cast<const u32x4*>(dy + i * 8);
+      kx[u] = *reinterpret_cast<const u32x4*>(x + i * 8);
+      km[u] = RELU == 2 ? mask[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (rl + 32 * u >= M) break;
+      reduce_row(kg[u], kx[u], km[u]);
+    }
+  } else if (live) {
     for (int r = rl; r < M; r += 32) {
       const size_t i = (size_t)r * vcols + vc;
-      float g[8], fx[8];
-      unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
-      unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), fx);
-      if (RELU == 2) {
-        const unsigned mk = mask[i];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        s[e] += g[e];
-        ss[e] += g[e] * ((fx[e] - mu[e]) * is[e]);
-      }
+      reduce_row(*reinterpret_cast<const u32x4*>(dy + i * 8), *reinterpret_cast<const u32x4*>(x + i * 8),
+                 RELU == 2 ? mask[i] : 0u);
     }
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     red[0][vcl * 8 + e][rl] = s[e];
@@ -800,21 +857,27 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const bf16_t* __restr
     }
   }
   __syncthreads();
-  if (live)
+  auto apply_row = [&](int r, const u32x4& vg, const u32x4& vx, unsigned mk) {
+    float g[8], fx[8], o[8];
+    masked(vg, mk, g);
+    unpack8(vx, fx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = coef[0][vcl * 8 + e] * g[e] + coef[1][vcl * 8 + e] * fx[e] + coef[2][vcl * 8 + e];
+    *reinterpret_cast<u32x4*>(dx + ((size_t)r * vcols + vc) * 8) = pack8(o);
+  };
+  if (live && keep) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (rl + 32 * u >= M) break;
+      apply_row(rl + 32 * u, kg[u], kx[u], km[u]);
+    }
+  } else if (live) {
     for (int r = rl; r < M; r += 32) {
       const size_t i = (size_t)r * vcols + vc;
-      float g[8], fx[8], o[8];
-      unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
-      unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), fx);
-      if (RELU == 2) {
-        const unsigned mk = mask[i];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = ((mk >> e) & 1u) ? g[e] : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = coef[0][vcl * 8 + e] * g[e] + coef[1][vcl * 8 + e] * fx[e] + coef[2][vcl * 8 + e];
-      *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(o);
+      apply_row(r, *reinterpret_cast<const u32x4*>(dy + i * 8), *reinterpret_cast<const u32x4*>(x + i * 8),
+                RELU == 2 ? mask[i] : 0u);
     }
+  }
 }
 
 inline unsigned ew_grid(size_t nvec) {
