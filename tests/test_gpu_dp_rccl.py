@@ -172,3 +172,58 @@ def test_recorded_step_hands_buckets_to_rccl_between_tape_segments(hip_lib):
       assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
   finally:
     dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+  """one rank of test_two_ranks_replay_the_recorded_step_with_the_same_exchange (both ranks share the one GPU)"""
+  import torch.distributed as dist
+  from assembled_cnn_amd import dp, ops
+  from assembled_cnn_amd.train import HParams, Trainer
+  from tests import model_parity as mpar
+  dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+  try:
+    hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
+                 use_resnet_d=True, zero_gamma=True, learning_rate_decay_type='cosine', base_learning_rate=0.01,
+                 weight_decay=1e-4, batch_size=8 * world)
+    batches = [mpar.inputs(8, 64, seed=10 * rank + s) for s in (1, 2)]          # every rank its own shard
+    batches = [(b[0].cuda(), b[2].cuda()) for b in batches]
+    res = {}
+    for taped in (False, True):
+      tr = Trainer(hp, seed=0, device='cuda', world_size=world)
+      tr.model.build((64, 64), use_resnet_d=True)
+      tr.grad_sync = dp.GradSync(tr.model.arena, bucket_bytes=4 << 20)
+      for s in range(5):
+        if taped and s == 2:
+          tr.capture(*batches[0], warmup=0)
+          assert ops.tape_info(tr._tape)['segments'] == len(tr.grad_sync.recorded) + 1 >= 4
+        tr.train_step(*batches[s % 2])
+      torch.cuda.synchronize()
+      a = tr.model.arena
+      res['taped' if taped else 'eager'] = (a.w32.cpu().clone(), a.m32.cpu().clone(), a.state.cpu().clone())
+      if taped:
+        tr.release_graph()
+      a.on_grad = None
+    torch.save(res, os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_replay_the_recorded_step_with_the_same_exchange(hip_lib, tmp_path):
+  """N > 1 for real, as far as one GPU allows: two processes on the same MI355X, each with its own shard, a gloo group
+  between them (RCCL refuses two ranks on one device; the exchange logic above the backend is the same).  Each rank runs
+  five steps eagerly and again as two eager + three replayed steps of a recording cut at the bucket launches: weights,
+  momentum and moving statistics after the replayed run equal the eager run's bit for bit on each rank, the weights of the
+  two ranks equal each other (the gradients were summed over the ranks), and they differ from a single-rank run (the
+  exchange did something)."""
+  import torch.multiprocessing as mp
+  port = _free_port()
+  mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
+  r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
+  for r in (r0, r1):
+    for p, q in zip(r['eager'], r['taped']):
+      assert bool(torch.isfinite(p).all()) and torch.equal(p, q), 'replayed run differs from the eager run'
+  assert torch.equal(r0['eager'][0], r1['eager'][0]) and torch.equal(r0['eager'][1], r1['eager'][1]), 'ranks drifted apart'
+  assert not torch.equal(r0['eager'][2], r1['eager'][2]), 'moving statistics are per replica: the shards differ'
