@@ -61,8 +61,8 @@ extern "C" int asm_resize_crop_flip(const uint8_t* src, int64_t src_bytes, const
   if (N == 0) return ASM_OK;
   ASM_REQUIRE(src && descs && out, "resize_crop_flip: null pointer");
   dim3 grid((out_h * out_w + 255) / 256, N);
-  resize_crop_flip_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, src_bytes, descs, out_h, out_w,
-                                                                 subtract_mean ? 1 : 0, out);
+  ASM_LAUNCH(resize_crop_flip_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_bytes, descs, out_h, out_w,
+             subtract_mean ? 1 : 0, out);
   ASM_CHECK_LAUNCH("resize_crop_flip");
   return ASM_OK;
 }
