@@ -51,14 +51,19 @@ struct Tape {
   std::vector<size_t> seg;       // seg[s] = first node of segment s; seg.back() = nodes.size() once closed
   size_t launches = 0, joins = 0, fills = 0;
   bool closed = false;
-  ~Tape() {
+  void destroy_events() {     // asm_tape_free only: never from a static destructor, where the HIP runtime may be gone already
     for (Node& n : nodes)
-      if (n.kind == N_JOIN && n.ev) (void)hipEventDestroy(n.ev);
+      if (n.kind == N_JOIN && n.ev) {
+        (void)hipEventDestroy(n.ev);
+        n.ev = nullptr;
+      }
   }
 };
 
 std::mutex g_mu;
-std::vector<std::unique_ptr<Tape>> g_tapes;      // tape id = index + 1; a freed slot holds nullptr
+// tape id = index + 1; a freed slot holds nullptr.  Heap-allocated and never destroyed: tapes that are still alive at
+// process exit are simply abandoned.
+std::vector<std::unique_ptr<Tape>>& g_tapes = *new std::vector<std::unique_ptr<Tape>>();
 thread_local Tape* t_rec = nullptr;
 
 // events of the eager asm_stream_join (outside a recording): a wait refers to the record that precedes it, so re-recording
@@ -225,6 +230,7 @@ extern "C" int asm_tape_free(int tape) {
     t_rec = nullptr;
     asm_tape_on = false;
   }
+  g_tapes[tape - 1]->destroy_events();
   g_tapes[tape - 1].reset();
   return ASM_OK;
 }

@@ -57,7 +57,8 @@ unsigned long long asm_launch_count(void);
  *   asm_tape_mark    -> index of the segment that starts here (1, 2, ...)
  *   asm_tape_end     -> tape id; the tape can be replayed from now on
  *   asm_tape_info    -> info = {nodes, kernel launches, joins, fills, segments, argument bytes}
- *   asm_tape_free    -> drops the tape and its events
+ *   asm_tape_free    -> drops the tape and its events (not while another thread replays it; tapes alive at process exit are
+ *                       abandoned, not torn down)
  * asm_stream_join(dst, src): dst waits for everything enqueued on src so far (event record + stream wait; raw
  * hipStream_t handles).  The host layer uses it for every cross-stream edge of a step so that a tape sees them. */
 int asm_stream_join(void* dst_stream, void* src_stream);
