@@ -10,9 +10,14 @@ mean-subtract(+mixup) -> forward -> softmax-CE(+label smoothing) -> backward -> 
 -> momentum-SGD.  Weak scaling: the per-GPU batch is fixed as N grows.  Rank 0 prints ONE JSON line.
 
 The timed region is the product as it ships: the weight gradients run beside the input-gradient chain and the big branch of
-each BigLittle stage beside the little one, on side streams.  Kernels then share the CUs, so the per-class
-figures below come from instrumented single-stream steps run after the timed region; `single_stream` is the rate of the same
-steps with every kernel on one stream (--single-stream times that instead).
+each BigLittle stage beside the little one, on side streams; and the step is RECORDED once after the warm-up
+(Trainer.capture) and replayed from the library's launch tape -- the same ~910 kernel launches on the same streams, issued
+by one C call in 3 - 4 ms of host time instead of ~14.5 ms of Python per step, bit-identical results (tests/test_gpu_model.py,
+tests/test_gpu_dp_rccl.py) -- with the loop on the trainer's stream.  `--eager` times the eager step instead (`step_mode`
+says which ran; if recording fails the bench falls back to eager and says so).  Kernels of different streams share the CUs,
+so the per-class figures below come from instrumented eager single-stream steps run after the timed region; `single_stream`
+is the rate of the same steps with every kernel on one stream (--single-stream times that instead).  `step_detail` gives, per
+timed step, the GPU time between step ends and the host time spent enqueueing the step.
 
 Extra objects on the line:
   roofline      what BASELINE.json's north_star names: the 3x3-convolution CLASS (every 3x3 fprop, input-gradient and
