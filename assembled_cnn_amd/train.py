@@ -398,7 +398,8 @@ class Trainer(object):
       for _ in range(warmup):     # one-time initialisation (workspaces, kernel attributes, side streams) stays out of the recording
         self.train_step(images, labels, lam1, lam2)
     torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
+    # tape replay never launches the captured graph: it is not even instantiated (keep_graph), only kept for its memory pool
+    g = torch.cuda.CUDAGraph(keep_graph=(replay == 'tape'))
     tape = None
     gs = self.grad_sync
     if gs is not None and capture_error_mode == 'global':
