@@ -74,6 +74,46 @@ class CpuDouble(object):
   def asm_launch_count(self):
     return 0
 
+  # launch tape: the double records nothing (it has no launches to replay); it keeps the SEGMENT bookkeeping, which is
+  # what the host logic above it depends on (dp.GradSync cuts a recording at its bucket launches)
+  def asm_stream_join(self, dst, src):
+    return 0
+
+  def asm_tape_begin(self):
+    if getattr(self, '_tape_open', False):
+      self._err = b'tape_begin: this thread is already recording a tape'
+      return -1
+    self._tape_open, self._tape_marks = True, 0
+    self._tapes = getattr(self, '_tapes', 0) + 1
+    return self._tapes
+
+  def asm_tape_mark(self):
+    if not getattr(self, '_tape_open', False):
+      self._err = b'tape_mark: no tape is being recorded by this thread'
+      return -1
+    self._tape_marks += 1
+    return self._tape_marks
+
+  def asm_tape_end(self):
+    if not getattr(self, '_tape_open', False):
+      self._err = b'tape_end: no tape is being recorded by this thread'
+      return -1
+    self._tape_open = False
+    return self._tapes
+
+  def asm_tape_info(self, tape, info):
+    arr = info._obj if hasattr(info, '_obj') else info
+    for i, v in enumerate((0, 0, 0, 0, self._tape_marks + 1, 0)):
+      arr[i] = v
+    return 0
+
+  def asm_tape_replay(self, tape, segment):
+    self._err = b'tape_replay: the CPU test double records no launches'
+    return -2
+
+  def asm_tape_free(self, tape):
+    return 0
+
   def asm_abi_version(self):
     return 1
 

@@ -102,6 +102,28 @@ def _worker(rank, world, port, out_dir, two_stream_tape=False):
   exp[:nd] -= 0.01 * (g[:nd] + 1e-4 * w0[:nd])
   exp[nd:] -= 0.01 * g[nd:]
   assert torch.allclose(tr.model.arena.w32, exp, rtol=1e-5, atol=1e-7)
+  # the recorded step's bookkeeping (Trainer.capture with the exchange attached): while the backward pass is being
+  # RECORDED the bucket launches only cut the tape and are written down, in the eager step's order; replayed one by one
+  # behind their segments they exchange the same buckets, and finish() hands over the rest: the same summed gradient
+  rec = Trainer(hp, seed=0, device='cpu', world_size=world)
+  rec.model.build((S, S))
+  rsync = dp.GradSync(rec.model.arena, bucket_bytes=8 << 20)
+  rec.grad_sync = rsync
+  tape = ops.tape_begin()
+  rsync.begin_recording()
+  rec._forward_backward(img[rank * B:(rank + 1) * B], labels[rank * B:(rank + 1) * B], None, None)
+  rsync.end_recording()
+  assert ops.tape_end() == tape and ops.tape_info(tape)['segments'] == len(rsync.recorded) + 1
+  assert rsync.recorded == [(s_, i_) for (s_, i_, _) in launched], 'recorded bucket order == the eager step\'s launch order'
+  assert torch.equal(rec.model.arena.g32, shard_grads[rank]), 'nothing is exchanged while recording'
+  for k in range(len(rsync.recorded)):
+    rsync.launch_recorded(k)
+  rsync.finish()
+  assert torch.equal(rec.model.arena.g32, g_sum)
+  late = next(k for k, (_, i_) in enumerate(rsync.recorded) if i_ > 0)     # a segment's second bucket, before its first:
+  with pytest.raises(RuntimeError):                                         # refused (no collective is issued)
+    rsync.launch_recorded(late)
+  rec.model.arena.on_grad = None
   # evaluation metrics: each rank scores its own shard, eval_result() all-reduces the 33 running sums
   # (metric/ece_metric.py:281-298) and equals a single-process evaluation of the whole batch
   from oracle import assembled_oracle as O
