@@ -130,7 +130,7 @@ class ParamArena(object):
     if fresh:
       self._parked = []
     if self.w32 is not None and self.w32.is_cuda and self.side_stream is None and getattr(self, '_parked', None):
-      self._sides, self._parked = self._parked, []       # the very streams that were switched off: same placement
+      self._sides, self._parked = self._parked, []       # the very streams that were switched off
       self._side_rr = 0
       self.side_stream = self._sides[0]
       return

@@ -404,8 +404,8 @@ def main():
       dominant = pick_dominant()
     else:
       step()
-  # stream calibration (untimed, after the warm-up): Trainer.calibrate_streams keeps the side streams unless this process's
-  # stream -> hardware-queue mapping makes them slower than one stream; ASM_STREAM_AUTOTUNE=0 skips it
+  # eager step only: stream calibration (untimed, after the warm-up): Trainer.calibrate_streams keeps the side streams unless
+  # they are slower than one stream in this process (a busy host: they cost more host calls); ASM_STREAM_AUTOTUNE=0 skips it
   stream_cal = None
   if not dry and not args.single_stream and not taped and os.environ.get('ASM_STREAM_AUTOTUNE', '1') != '0':
     stream_cal = tr.calibrate_streams(step)
@@ -626,7 +626,7 @@ def main():
       out['step_mode'] += ' (recording the step failed: %s)' % tape_error
     if stream_cal is not None:
       out['streams_autotune'] = dict(stream_cal, what='Trainer.calibrate_streams after the warm-up, 3 untimed steps per setting: '
-                                     'the timed region runs the chosen one (side streams unless > 3 % slower than one stream)')
+                                     'the timed region runs the chosen one (side streams unless > 3 % slower than one stream, which happens when the host is busy)')
       if stream_cal['chosen'] != 'side streams':
         out['streams'] = 'single stream (chosen by Trainer.calibrate_streams: the side streams measured slower in this process)' 
     out['launches'] = {'kernels_per_step': None if kernels_per_step is None else round(kernels_per_step, 1),
