@@ -404,20 +404,25 @@ class Trainer(object):
     gs = self.grad_sync
     if gs is not None and capture_error_mode == 'global':
       capture_error_mode = 'thread_local'      # the collective library's watchdog thread queries events while we capture
-    with torch.cuda.graph(g, stream=cap, capture_error_mode=capture_error_mode):
-      if replay == 'tape':
-        tape = ops.tape_begin()
-      if gs is not None:
-        gs.begin_recording()      # bucket launches of the recorded backward pass become segment boundaries of the tape
-      try:
-        out = self._forward_backward(*static)
-      finally:
+    try:
+      with torch.cuda.graph(g, stream=cap, capture_error_mode=capture_error_mode):
+        if replay == 'tape':
+          tape = ops.tape_begin()
         if gs is not None:
-          gs.end_recording()
-        if tape is not None:
-          ops.tape_end()
-    if gs is not None and ops.tape_info(tape)['segments'] != len(gs.recorded) + 1:
-      raise RuntimeError('tape segments and recorded bucket launches disagree')
+          gs.begin_recording()      # bucket launches of the recorded backward pass become segment boundaries of the tape
+        try:
+          out = self._forward_backward(*static)
+        finally:
+          if gs is not None:
+            gs.end_recording()
+          if tape is not None:
+            ops.tape_end()
+      if gs is not None and ops.tape_info(tape)['segments'] != len(gs.recorded) + 1:
+        raise RuntimeError('tape segments and recorded bucket launches disagree')
+    except BaseException:
+      if tape is not None:        # a recording that failed half-way is dropped, the trainer stays eager
+        ops.tape_free(tape)
+      raise
     self._graph, self._static, self._graph_out = g, static, out
     self._tape, self._cap_stream = tape, cap
     return self
