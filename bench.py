@@ -453,8 +453,21 @@ def main():
   abi_calls = (ops.abi_calls() - calls0) / max(args.steps, 1)
   kernels_per_step = ((ops.L().asm_launch_count() - kern0) / max(args.steps, 1)) if not dry else None
   ops.set_conv_timer(None)
+  eager_leg = None
   if taped:
     tr.release_graph()          # the legs below instrument or re-wire the eager step
+    if world == 1:              # the same K steps enqueued launch by launch by the Python host code, same streams: for the record
+      step()
+      sync()
+      t1 = time.time()
+      for _ in range(args.steps):
+        step()
+      sync()
+      el_e = time.time() - t1
+      eager_leg = {'value': round(B * world * args.steps / el_e, 2), 'ms_per_step': round(1000.0 * el_e / args.steps, 3),
+                   'what': 'the same %d steps as EAGER steps (every launch enqueued by Python, ~14.5 ms of host time per step), '
+                           'same streams, right after the timed region: the recorded step launches the same kernels, so the two '
+                           'agree when the host keeps up and part ways when it does not' % args.steps}
   if world > 1:
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -624,6 +637,8 @@ def main():
       out['step_mode'] += '; %d segments, a gradient bucket handed to RCCL after each but the last' % tape_info['segments']
     if tape_error:
       out['step_mode'] += ' (recording the step failed: %s)' % tape_error
+    if eager_leg is not None:
+      out['eager_step'] = eager_leg
     if stream_cal is not None:
       out['streams_autotune'] = dict(stream_cal, what='Trainer.calibrate_streams after the warm-up, 3 untimed steps per setting: '
                                      'the timed region runs the chosen one (side streams unless > 3 % slower than one stream, which happens when the host is busy)')
