@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/profile_round.sh TAG [stats|traffic|sq ...]
-#   stats    rocprofv3 --kernel-trace --stats of bench.py (3 warm-up + 5 timed steps) -> gpurun_out/TAG_kernel_stats.md
+#   stats    rocprofv3 --kernel-trace --stats of bench.py --single-stream (3 warm-up + 5 timed steps) -> gpurun_out/TAG_kernel_stats.md
+#   stats_default  the same of the default command (recorded step, side streams) -> gpurun_out/TAG_kernel_stats_default.md
 #   traffic  two --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain) -> gpurun_out/TAG_step_hbm_traffic.md
 #   dominant FETCH_SIZE / WRITE_SIZE of the layer bench.py's roofline object names -> gpurun_out/TAG_pmc_traffic.json
 #   sq       one --pmc pass of SQ occupancy / MFMA-busy counters -> gpurun_out/TAG_sq_counters.md
@@ -17,6 +18,11 @@ for w in $WHAT; do
       rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_$TAG -o r -- $BENCH --steps 5 --warmup 3 > $REPO/gpurun_out/prof_$TAG.log 2>&1
       DB=$(find $REPO/gpurun_out/prof_$TAG -name '*results.db' | head -1)
       python $REPO/tools/rocpd_summary.py $DB $REPO/gpurun_out/${TAG}_kernel_stats.md "$TAG: bench.py --steps 5 --warmup 3 (8 steps profiled)"
+      ;;
+    stats_default)   # the DEFAULT command (recorded step replayed from the launch tape, side streams): the same kernels, counted
+      rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/profd_$TAG -o r -- python $REPO/bench.py --no-cpu-baseline --no-roofline --no-gradsync --steps 5 --warmup 3 > $REPO/gpurun_out/profd_$TAG.log 2>&1
+      DB=$(find $REPO/gpurun_out/profd_$TAG -name '*results.db' | head -1)
+      python $REPO/tools/rocpd_summary.py $DB $REPO/gpurun_out/${TAG}_kernel_stats_default.md "$TAG: bench.py --steps 5 --warmup 3, DEFAULT mode = 3 eager warm-up steps + 1 + 5 replays of the recorded step + 1 + 5 eager steps (eager_step leg): 15 executed steps; kernels share the CUs across 4 streams, so durations are not the kernels' own"
       ;;
     traffic)
       for c in FETCH_SIZE WRITE_SIZE; do
