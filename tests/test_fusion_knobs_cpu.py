@@ -126,3 +126,78 @@ def test_biglittle_backward_on_two_streams_is_the_same_backward(cpu_double, monk
   waits = [e for e in log2 if e[0] == 'wait']
   assert waits.count(('wait', 'side', 'main')) == joins and waits.count(('wait', 'main', 'side')) == joins
   assert sum(1 for e in log2 if e == ('enter', 'side')) >= 3 + 3
+
+
+def test_projection_shortcut_on_its_own_stream_forks_and_joins_per_block(cpu_double, monkeypatch):
+  """ASM_SC_STREAM=1 (model._shortcut_stream): the forward pass of a projection shortcut runs inside a stream context of its
+  own, forked from the block's stream before it and joined back before the block-final batch norm that adds the two -- but
+  NOT for blocks that already run on the BigLittle branch stream (a fork off a forked stream, recorded in the forward pass,
+  crashes hipStreamEndCapture on ROCm 7.0).  On the CPU double with stand-in streams: identical logits and gradients, one
+  fork + one join per projection block on the main stream, none from the branch stream."""
+  import contextlib
+  from assembled_cnn_amd import model as pmodel
+
+  def run(sc):
+    log = []
+    main, side, scs = _FakeStream('main', log), _FakeStream('side', log), _FakeStream('sc', log)
+    cur = [main]
+
+    @contextlib.contextmanager
+    def ctx(s):
+      log.append(('enter', s.name))
+      cur.append(s)
+      try:
+        yield
+      finally:
+        cur.pop()
+    monkeypatch.setattr(pmodel, '_current_stream', lambda: cur[-1])
+    monkeypatch.setattr(pmodel, '_stream_ctx', ctx)
+    monkeypatch.setattr(pmodel.Model, '_branch_stream', lambda self, c, x: None if c.dry else side)
+    if sc:
+      def shortcut_stream(self, c, x, db):
+        return None if (c.dry or not c.training or cur[-1] is side) else scs
+      monkeypatch.setattr(pmodel.Model, '_shortcut_stream', shortcut_stream)
+    _, pm = MP.make_pair('a-r50-d', 'cpu', 2, 64)
+    _, x, _ = MP.inputs(2, 64)
+    lp = pm(x, True, use_resnet_d=True)
+    dl = torch.zeros((2, 1, 1, pm.ldc), dtype=torch.bfloat16)
+    dl[:, 0, 0, :1001] = (torch.softmax(lp.float(), 1) / 2).to(torch.bfloat16)
+    pm.backward(dl)
+    monkeypatch.undo()
+    return lp.clone(), pm.arena.g32.clone(), log
+
+  l0, g0, log0 = run(False)
+  l1, g1, log1 = run(True)
+  assert torch.equal(l0, l1) and torch.equal(g0, g1)
+  assert not [e for e in log0 if 'sc' in e]
+  forks = log1.count(('wait', 'sc', 'main'))
+  assert forks >= 3 and log1.count(('wait', 'main', 'sc')) == forks and log1.count(('enter', 'sc')) == forks
+  assert not [e for e in log1 if e[0] == 'wait' and set(e[1:]) == {'sc', 'side'}], 'no fork off the branch stream'
+  # every fork is closed before the next one opens
+  depth = 0
+  for e in log1:
+    if e == ('wait', 'sc', 'main'):
+      depth += 1
+      assert depth == 1
+    elif e == ('wait', 'main', 'sc'):
+      depth -= 1
+  assert depth == 0
+
+
+def test_capture_refuses_what_it_cannot_record(cpu_double):
+  """Trainer.capture argument checks that need no GPU: host tensors, an unknown replay mode, DropBlock."""
+  from assembled_cnn_amd.train import HParams, Trainer
+  hp = dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
+            batch_size=2)
+  tr = Trainer(HParams(**hp), seed=0, device='cpu')
+  img, _, labels = MP.inputs(2, 64)
+  assert tr.stream is None
+  with pytest.raises(RuntimeError):
+    tr.capture(img, labels)                     # device tensors only: there is no CPU path to record
+  with pytest.raises(ValueError):
+    tr.capture(img, labels, replay='magic')
+  db = Trainer(HParams(**dict(hp, use_dropblock=True)), seed=0, device='cpu')
+  with pytest.raises(NotImplementedError):
+    db.capture(img, labels)
+  tr.release_graph()                            # nothing captured: a no-op
+  tr.train_step(img, labels)                    # and the trainer is an ordinary eager trainer
