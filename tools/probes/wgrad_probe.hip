@@ -1,0 +1,286 @@
+// Probe (round 4, for round 5): the 256 x 256 / 8-wave weight-gradient tile with its operands staged by LDS-DMA through a
+// ring of four 32-pixel stages, against the library's register-staged form (one register tile set, two 64-pixel stages:
+// the loads of step k + 1 have one step's MFMAs to land in; SQ counters: 41 % MFMA busy, 39 % issue-stalled).
+//
+// Problem (the workload's heaviest 3x3 layer, 14 x 14 x 512 -> 1024 at batch 256), borders left out as in conv_probe.hip:
+//     dW[n][t][c] = sum_m dY[m][n] * X[m + r W + s][c]        t = (r, s), X front-padded by W + 1 pixel rows
+// i.e. a GEMM [N x M] . [M x 9C] whose right operand is nine linear row shifts of one matrix.  One workgroup owns a
+// 256 (n) x 256 (tap, channel) tile over a pixel range and writes an fp32 slab; the transposing LDS reads
+// (ds_read_b64_tr_b16) and the bank swizzle are the library kernel's (csrc/conv_wgrad.hip), the swizzle moved to the SOURCE
+// side of the DMA (a lane's LDS destination is fixed: base + 16 lane).
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/wgrad_probe.hip -o tools/probes/bin/wgrad_probe
+// run:   tools/probes/bin/wgrad_probe [splits] [iters]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                 \
+    }                                                                          \
+  } while (0)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x4 ds_read_tr(const unsigned char* p) {
+  typedef __attribute__((ext_vector_type(4))) short s4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(const_cast<unsigned char*>(p)));
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct Args {
+  const void* x;    // [(M + 2W + 2)][C] bf16
+  const void* dy;   // [M][N] bf16
+  float* out;       // [splits][N][9C] fp32
+  unsigned x_bytes, dy_bytes;
+  int M, N, C, W, cols, tiles_n, tiles_c, splits, m_per_split;
+};
+
+constexpr int ROWB = 512;                 // 256 bf16 per tile row
+constexpr unsigned OOB = 0x7fffff00u;     // beyond any buffer: the DMA writes zeros
+
+__device__ __forceinline__ int tr_swz(int row) { return (row & 3) << 2; }   // conv_wgrad.hip tr_swz<512>
+
+// WPX pixels per stage, NS stages, loads of step k + NS - 1 issued while step k is multiplied
+template <int WPX, int NS>
+__global__ __launch_bounds__(512) void wgrad_dma_kernel(Args p) {
+  constexpr int YT = WPX * ROWB, STAGE = 2 * YT;
+  constexpr int PASSES = WPX / 16;          // 8 waves x 2 rows per DMA instruction
+  constexpr int PER_STEP = 2 * PASSES;      // DMA instructions per lane and step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int nbase = wn * 64, cbase = wc * 128;
+
+  int bid;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles = p.tiles_n * p.tiles_c;
+  const int split = bid / tiles;
+  bid -= split * tiles;
+  const int tile_n = bid / p.tiles_c, tile_c = bid - tile_n * p.tiles_c;
+
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+
+  // DMA geometry: in pass j this lane fills row (16 j + 2 wave + (lane >> 5)), 16-byte slot (lane & 31) of the tile; the slot
+  // holds source chunk slot ^ swz(row), and row & 3 does not depend on j
+  const int rloc = 2 * wave + (lane >> 5);
+  const int slot = lane & 31;
+  const int csrc = slot ^ tr_swz(rloc);
+  const int n0 = tile_n * 256 + csrc * 8;
+  const int j0 = tile_c * 256 + csrc * 8;
+  const bool col_ok = j0 < p.cols;
+  const int tap = col_ok ? j0 / p.C : 0;
+  const int tap_c = j0 - tap * p.C;
+  const int shift = (tap / 3) * p.W + (tap % 3);
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int steps = (m_end - m_begin + WPX - 1) / WPX;
+
+  auto issue = [&](int step) {
+    unsigned char* ys = smem + (step % NS) * STAGE;
+    unsigned char* xs = ys + YT;
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+      const int m = m_begin + step * WPX + 16 * j + rloc;
+      const bool ok = m < m_end && step < steps;
+      const unsigned offy = ((unsigned)m * (unsigned)p.N + (unsigned)n0) * 2u;
+      const unsigned offx = ((unsigned)(m + shift) * (unsigned)p.C + (unsigned)tap_c) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lptr_t)(ys + (16 * j + 2 * wave) * ROWB), 16, (int)(ok ? offy : OOB), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (16 * j + 2 * wave) * ROWB), 16,
+                                               (int)((ok && col_ok) ? offx : OOB), 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  const int t16 = lane & 15, g = lane >> 4;
+  const int colsel = (g & 1) * 16, pgrp = (g >> 1) * 8, trow = t16 >> 2, tcol = (t16 & 3) * 4;
+
+  auto compute = [&](int step) {
+    const unsigned char* ys = smem + (step % NS) * STAGE;
+    const unsigned char* xs = ys + YT;
+#pragma unroll
+    for (int kk = 0; kk < WPX / 16; ++kk) {
+      const int row = kk * 16 + pgrp + trow, row2 = row + 4;
+      bf16x8 fy[2], fx[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int cy = nbase + a * 32 + colsel + tcol;
+        const int o = ((cy & 4) << 1);
+        const bf16x4 y0 = ds_read_tr(ys + row * ROWB + ((((cy >> 3) ^ tr_swz(row)) << 4) | o));
+        const bf16x4 y1 = ds_read_tr(ys + row2 * ROWB + ((((cy >> 3) ^ tr_swz(row2)) << 4) | o));
+        fy[a] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int cx = cbase + b * 32 + colsel + tcol;
+        const int o = ((cx & 4) << 1);
+        const bf16x4 x0 = ds_read_tr(xs + row * ROWB + ((((cx >> 3) ^ tr_swz(row)) << 4) | o));
+        const bf16x4 x1 = ds_read_tr(xs + row2 * ROWB + ((((cx >> 3) ^ tr_swz(row2)) << 4) | o));
+        fx[b] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // prologue: steps 0 .. NS - 2 in flight
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+#pragma unroll 1
+  for (int step = 0; step < steps; ++step) {
+    wait_vm<(NS - 2) * PER_STEP>();      // this lane's part of step `step` has landed ...
+    __syncthreads();                     // ... so has everybody's; and everybody is through with step - 1's stage
+    issue(step + NS - 1);                // refill the stage step - 1 used
+    compute(step);
+  }
+
+  float* out = p.out + (size_t)split * p.N * p.cols;
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = tile_c * 256 + cbase + b * 32 + l31;
+      if (col < p.cols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = tile_n * 256 + nbase + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (n < p.N) out[(size_t)n * p.cols + col] = acc[a][b][r];
+        }
+      }
+    }
+}
+
+// reference for sampled (n, col) pairs: fp64 sum over all pixels
+__global__ void ref_kernel(const bf16_t* x, const bf16_t* dy, const int* samples, int ns, int M, int N, int C, int W,
+                           double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const int n = samples[2 * i], col = samples[2 * i + 1];
+  const int tap = col / C, c = col - tap * C;
+  const int shift = (tap / 3) * W + (tap % 3);
+  double s = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const float a = __uint_as_float(((unsigned)dy[(size_t)m * N + n]) << 16);
+    const float b = __uint_as_float(((unsigned)x[(size_t)(m + shift) * C + c]) << 16);
+    s += (double)a * (double)b;
+  }
+  out[i] = s;
+}
+
+__global__ void fill_kernel(bf16_t* p, size_t n, unsigned seed) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = (unsigned)i * 2654435761u + seed;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  const float f = ((float)(h & 0xffff) / 65536.0f - 0.5f);      // uniform in [-0.5, 0.5)
+  __bf16 b = (__bf16)f;
+  p[i] = __builtin_bit_cast(unsigned short, b);
+}
+
+template <int WPX, int NS>
+static void run(const char* name, Args a, int iters, const int* d_samples, int ns, const double* h_ref) {
+  const int lds = NS * 2 * WPX * ROWB;
+  CK(hipFuncSetAttribute((const void*)wgrad_dma_kernel<WPX, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const int grid = a.tiles_n * a.tiles_c * a.splits;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wgrad_dma_kernel<WPX, NS>), dim3(grid), dim3(512), lds, 0, a);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wgrad_dma_kernel<WPX, NS>), dim3(grid), dim3(512), lds, 0, a);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  // check the samples: sum of the slabs against the fp64 reference
+  std::vector<int> hs(2 * ns);
+  CK(hipMemcpy(hs.data(), d_samples, sizeof(int) * 2 * ns, hipMemcpyDeviceToHost));
+  double worst = 0.0;
+  for (int i = 0; i < ns; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < a.splits; ++k) {
+      float v;
+      CK(hipMemcpy(&v, a.out + ((size_t)k * a.N + hs[2 * i]) * a.cols + hs[2 * i + 1], sizeof(float), hipMemcpyDeviceToHost));
+      s += v;
+    }
+    const double err = fabs(s - h_ref[i]) / (fabs(h_ref[i]) + 1.0);
+    if (err > worst) worst = err;
+  }
+  const double us = 1000.0 * ms / iters;
+  const double flops = 2.0 * a.M * (double)a.N * a.cols;
+  printf("%-28s grid %4d  LDS %3d KB  %8.1f us  %7.1f TFLOP/s  worst rel err %.2e %s\n", name, grid, lds >> 10, us,
+         flops / us * 1e-6, worst, worst < 2e-3 ? "ok" : "WRONG");
+}
+
+int main(int argc, char** argv) {
+  const int splits = argc > 1 ? atoi(argv[1]) : 7;
+  const int iters = argc > 2 ? atoi(argv[2]) : 20;
+  const int NB = 256, H = 14, W = 14, C = 512, N = 1024;
+  const int M = NB * H * W;
+  Args a = {};
+  a.M = M; a.N = N; a.C = C; a.W = W; a.cols = 9 * C;
+  a.tiles_n = N / 256; a.tiles_c = (a.cols + 255) / 256; a.splits = splits;
+  a.m_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
+  const size_t xn = (size_t)(M + 2 * W + 2) * C, yn = (size_t)M * N;
+  bf16_t *x, *dy;
+  CK(hipMalloc(&x, xn * 2));
+  CK(hipMalloc(&dy, yn * 2));
+  CK(hipMalloc(&a.out, (size_t)splits * N * a.cols * sizeof(float)));
+  a.x = x; a.dy = dy; a.x_bytes = (unsigned)(xn * 2); a.dy_bytes = (unsigned)(yn * 2);
+  fill_kernel<<<(unsigned)((xn + 255) / 256), 256>>>(x, xn, 1u);
+  fill_kernel<<<(unsigned)((yn + 255) / 256), 256>>>(dy, yn, 7u);
+  const int ns = 96;
+  std::vector<int> hs(2 * ns);
+  for (int i = 0; i < ns; ++i) {
+    hs[2 * i] = (i * 131 + 17) % N;
+    hs[2 * i + 1] = (i * 977 + (i % 9) * C + 5) % a.cols;
+  }
+  int* d_samples;
+  double* d_ref;
+  CK(hipMalloc(&d_samples, sizeof(int) * 2 * ns));
+  CK(hipMalloc(&d_ref, sizeof(double) * ns));
+  CK(hipMemcpy(d_samples, hs.data(), sizeof(int) * 2 * ns, hipMemcpyHostToDevice));
+  ref_kernel<<<(ns + 63) / 64, 64>>>(x, dy, d_samples, ns, M, N, C, W, d_ref);
+  std::vector<double> href(ns);
+  CK(hipMemcpy(href.data(), d_ref, sizeof(double) * ns, hipMemcpyDeviceToHost));
+  printf("wgrad 3x3 N%d %dx%dx%d -> %d, 256 x 256 tiles, %d x %d tiles x %d splits, %d pixels per split\n", NB, H, W, C, N,
+         a.tiles_n, a.tiles_c, splits, a.m_per_split);
+  run<64, 2>("DMA, 2 x 64-pixel stages", a, iters, d_samples, ns, href.data());
+  run<32, 4>("DMA, 4 x 32-pixel stages", a, iters, d_samples, ns, href.data());
+  run<32, 3>("DMA, 3 x 32-pixel stages", a, iters, d_samples, ns, href.data());
+  run<16, 8>("DMA, 8 x 16-pixel stages", a, iters, d_samples, ns, href.data());
+  return 0;
+}
