@@ -182,6 +182,128 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(Args p) {
     }
 }
 
+// The same tile on FOUR waves, each 128 (n) x 128 (columns): 256 accumulator registers per lane (one wave per SIMD may hold
+// 512), half the fragment bytes per MFMA of the 64 x 128 form; fragments of kk + 1 are read while kk is multiplied.
+template <int WPX, int NS>
+__global__ __launch_bounds__(256) void wgrad_dma4_kernel(Args p) {
+  constexpr int YT = WPX * ROWB, STAGE = 2 * YT;
+  constexpr int PASSES = WPX / 8;           // 4 waves x 2 rows per DMA instruction
+  constexpr int PER_STEP = 2 * PASSES;
+  constexpr int KK = WPX / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nbase = (wave >> 1) * 128, cbase = (wave & 1) * 128;
+  int bid;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles = p.tiles_n * p.tiles_c;
+  const int split = bid / tiles;
+  bid -= split * tiles;
+  const int tile_n = bid / p.tiles_c, tile_c = bid - tile_n * p.tiles_c;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+  const int rloc = 2 * wave + (lane >> 5);
+  const int slot = lane & 31;
+  const int csrc = slot ^ tr_swz(rloc);
+  const int n0 = tile_n * 256 + csrc * 8;
+  const int j0 = tile_c * 256 + csrc * 8;
+  const bool col_ok = j0 < p.cols;
+  const int tap = col_ok ? j0 / p.C : 0;
+  const int tap_c = j0 - tap * p.C;
+  const int shift = (tap / 3) * p.W + (tap % 3);
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int steps = (m_end - m_begin + WPX - 1) / WPX;
+
+  auto issue = [&](int step) {
+    unsigned char* ys = smem + (step % NS) * STAGE;
+    unsigned char* xs = ys + YT;
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+      const int m = m_begin + step * WPX + 8 * j + rloc;
+      const bool ok = m < m_end && step < steps;
+      const unsigned offy = ((unsigned)m * (unsigned)p.N + (unsigned)n0) * 2u;
+      const unsigned offx = ((unsigned)(m + shift) * (unsigned)p.C + (unsigned)tap_c) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lptr_t)(ys + (8 * j + 2 * wave) * ROWB), 16, (int)(ok ? offy : OOB), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (8 * j + 2 * wave) * ROWB), 16,
+                                               (int)((ok && col_ok) ? offx : OOB), 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  const int t16 = lane & 15, g = lane >> 4;
+  const int colsel = (g & 1) * 16, pgrp = (g >> 1) * 8, trow = t16 >> 2, tcol = (t16 & 3) * 4;
+
+  bf16x8 fy[2][4], fx[2][4];
+  auto frags = [&](int step, const int kk, const int buf) {
+    const unsigned char* ys = smem + (step % NS) * STAGE;
+    const unsigned char* xs = ys + YT;
+    const int row = kk * 16 + pgrp + trow, row2 = row + 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int cy = nbase + a * 32 + colsel + tcol;
+      const int o = ((cy & 4) << 1);
+      const bf16x4 y0 = ds_read_tr(ys + row * ROWB + ((((cy >> 3) ^ tr_swz(row)) << 4) | o));
+      const bf16x4 y1 = ds_read_tr(ys + row2 * ROWB + ((((cy >> 3) ^ tr_swz(row2)) << 4) | o));
+      fy[buf][a] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int cx = cbase + b * 32 + colsel + tcol;
+      const int o = ((cx & 4) << 1);
+      const bf16x4 x0 = ds_read_tr(xs + row * ROWB + ((((cx >> 3) ^ tr_swz(row)) << 4) | o));
+      const bf16x4 x1 = ds_read_tr(xs + row2 * ROWB + ((((cx >> 3) ^ tr_swz(row2)) << 4) | o));
+      fx[buf][b] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto mma = [&](const int buf) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[buf][a], fx[buf][b], acc[a][b], 0, 0, 0);
+  };
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+#pragma unroll 1
+  for (int step = 0; step < steps; ++step) {
+    wait_vm<(NS - 2) * PER_STEP>();
+    __syncthreads();
+    issue(step + NS - 1);
+    frags(step, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (kk + 1 < KK) frags(step, kk + 1, (kk + 1) & 1);
+      mma(kk & 1);
+    }
+  }
+
+  float* out = p.out + (size_t)split * p.N * p.cols;
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = tile_c * 256 + cbase + b * 32 + l31;
+      if (col < p.cols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = tile_n * 256 + nbase + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (n < p.N) out[(size_t)n * p.cols + col] = acc[a][b][r];
+        }
+      }
+    }
+}
+
 // reference for sampled (n, col) pairs: fp64 sum over all pixels
 __global__ void ref_kernel(const bf16_t* x, const bf16_t* dy, const int* samples, int ns, int M, int N, int C, int W,
                            double* out) {
@@ -209,18 +331,18 @@ __global__ void fill_kernel(bf16_t* p, size_t n, unsigned seed) {
   p[i] = __builtin_bit_cast(unsigned short, b);
 }
 
-template <int WPX, int NS>
-static void run(const char* name, Args a, int iters, const int* d_samples, int ns, const double* h_ref) {
-  const int lds = NS * 2 * WPX * ROWB;
-  CK(hipFuncSetAttribute((const void*)wgrad_dma_kernel<WPX, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+static void run(const char* name, void (*kernel)(Args), int threads, int lds, Args a, int iters, const int* d_samples, int ns,
+                const double* h_ref) {
+  CK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  CK(hipMemset(a.out, 0xff, (size_t)a.splits * a.N * a.cols * sizeof(float)));
   const int grid = a.tiles_n * a.tiles_c * a.splits;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wgrad_dma_kernel<WPX, NS>), dim3(grid), dim3(512), lds, 0, a);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wgrad_dma_kernel<WPX, NS>), dim3(grid), dim3(512), lds, 0, a);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, 0, a);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms = 0.f;
@@ -278,9 +400,11 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(href.data(), d_ref, sizeof(double) * ns, hipMemcpyDeviceToHost));
   printf("wgrad 3x3 N%d %dx%dx%d -> %d, 256 x 256 tiles, %d x %d tiles x %d splits, %d pixels per split\n", NB, H, W, C, N,
          a.tiles_n, a.tiles_c, splits, a.m_per_split);
-  run<64, 2>("DMA, 2 x 64-pixel stages", a, iters, d_samples, ns, href.data());
-  run<32, 4>("DMA, 4 x 32-pixel stages", a, iters, d_samples, ns, href.data());
-  run<32, 3>("DMA, 3 x 32-pixel stages", a, iters, d_samples, ns, href.data());
-  run<16, 8>("DMA, 8 x 16-pixel stages", a, iters, d_samples, ns, href.data());
+#define RUN(name, K, T, WPX, NS) run(name, K<WPX, NS>, T, NS * 2 * WPX * ROWB, a, iters, d_samples, ns, href.data())
+  RUN("8 waves, 2 x 64-pixel stages", wgrad_dma_kernel, 512, 64, 2);
+  RUN("8 waves, 4 x 32-pixel stages", wgrad_dma_kernel, 512, 32, 4);
+  RUN("4 waves, 2 x 64-pixel stages", wgrad_dma4_kernel, 256, 64, 2);
+  RUN("4 waves, 4 x 32-pixel stages", wgrad_dma4_kernel, 256, 32, 4);
+  RUN("4 waves, 3 x 32-pixel stages", wgrad_dma4_kernel, 256, 32, 3);
   return 0;
 }
