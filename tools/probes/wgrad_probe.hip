@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 typedef unsigned short bf16_t;
@@ -50,7 +51,7 @@ struct Args {
   const void* dy;   // [M][N] bf16
   float* out;       // [splits][N][9C] fp32
   unsigned x_bytes, dy_bytes;
-  int M, N, C, W, cols, tiles_n, tiles_c, splits, m_per_split;
+  int M, N, C, W, cols, tiles_n, tiles_c, splits, m_per_split, H, masked;
 };
 
 constexpr int ROWB = 512;                 // 256 bf16 per tile row
@@ -309,11 +310,13 @@ __global__ __launch_bounds__(256) void wgrad_dma4_kernel(Args p) {
 // r W + s.  28 KB staged per 9.4 MFLOP step instead of 64 KB per 8.4: 2.6 x less volume through L2 -> LDS.  Waves: 4 (n: 32
 // each) x 2 (channel tile of 32): 9 accumulator tiles per wave (one per tap).
 // WC: the map width as a compile-time constant (0 = p.W at run time); ROLL: the four 16-pixel sub-steps as a rolled loop
-template <int NS, int WC = 0, bool ROLL = false>
+// MASK: the zero padding of the convolution: a per-(pixel, tap) validity mask, built per step into LDS (one bf16-wide word per
+// pixel and tap) and ANDed onto the dy fragment of that tap (8 consecutive pixels per lane = one 16-byte broadcast read)
+template <int NS, int WC = 0, bool ROLL = false, bool MASK = false>
 __global__ __launch_bounds__(512) void wgrad_halo9_kernel(Args p) {
   const int Wd = WC ? WC : p.W;
   constexpr int WPX = 64, XROWS = 96, YRB = 256, XRB = 128;
-  constexpr int YT = WPX * YRB, XT = XROWS * XRB, STAGE = YT + XT;
+  constexpr int YT = WPX * YRB, XT = XROWS * XRB, MT = MASK ? 4 * WPX * 2 : 0, STAGE = YT + XT + MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wc = wave & 1;
@@ -363,6 +366,17 @@ __global__ __launch_bounds__(512) void wgrad_halo9_kernel(Args p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + 8 * (wave + 8 * j) * XRB), 16, (int)(ok ? off : OOB), 0, 0, 0);
       }
     }
+    if (MASK) {      // valid(m, (r, s)) = rowok_r(h) & colok_s(w): four masks per pixel -- r = 0, r = 2, s = 0, s = 2 (H, W constants)
+      unsigned short* ms = reinterpret_cast<unsigned short*>(xs + XT);
+      if (tid < 4 * WPX) {
+        constexpr int H_ = WC ? WC : 1;          // square maps in this probe
+        const int which = tid / WPX, px = tid - which * WPX;
+        const int m = m0 + px;
+        const int q = m / H_, w = m - q * H_, h = q % H_;
+        const bool v = which == 0 ? h >= 1 : which == 1 ? h <= H_ - 2 : which == 2 ? w >= 1 : w <= H_ - 2;
+        ms[tid] = v ? 0xffffu : 0u;
+      }
+    }
   };
 
   f32x16 acc[9];
@@ -375,23 +389,62 @@ __global__ __launch_bounds__(512) void wgrad_halo9_kernel(Args p) {
   const int cy = wn * 32 + colsel + tcol, oy = ((cy & 4) << 1);
   const int cx = wc * 32 + colsel + tcol, ox = ((cx & 4) << 1);
 
+  // x fragment addresses with W known at compile time: (row + sh) * 128 + (c ^ (((row + sh) & 2) << 5)); row & 3 == trow, so the
+  // XOR term takes one of four lane values selected by sh & 3 and everything else is an immediate offset of the read
+  const int cxb = ((cx >> 3) << 4) | ox;
+  int xl[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) xl[q] = (pgrp + trow) * XRB + (cxb ^ (((trow + q) & 2) << 5));
+  const int yl = (pgrp + trow) * YRB + ((((cy >> 3) ^ (trow << 2)) << 4) | oy);      // (row & 3) == (row2 & 3) == trow
+
   auto compute = [&](int step) {
     const unsigned char* ys = smem + (step % NS) * STAGE;
     const unsigned char* xs = ys + YT;
 #pragma unroll(ROLL ? 1 : 4)
     for (int kk = 0; kk < WPX / 16; ++kk) {
-      const int row = kk * 16 + pgrp + trow, row2 = row + 4;
-      const bf16x4 y0 = ds_read_tr(ys + row * YRB + ((((cy >> 3) ^ ((row & 3) << 2)) << 4) | oy));
-      const bf16x4 y1 = ds_read_tr(ys + row2 * YRB + ((((cy >> 3) ^ ((row2 & 3) << 2)) << 4) | oy));
-      const bf16x8 fy = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      bf16x8 fy;
+      if (WC) {
+        const bf16x4 y0 = ds_read_tr(ys + yl + kk * 16 * YRB);
+        const bf16x4 y1 = ds_read_tr(ys + yl + kk * 16 * YRB + 4 * YRB);
+        fy = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      } else {
+        const int row = kk * 16 + pgrp + trow, row2 = row + 4;
+        const bf16x4 y0 = ds_read_tr(ys + row * YRB + ((((cy >> 3) ^ ((row & 3) << 2)) << 4) | oy));
+        const bf16x4 y1 = ds_read_tr(ys + row2 * YRB + ((((cy >> 3) ^ ((row2 & 3) << 2)) << 4) | oy));
+        fy = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      u32x4 fyr0, fyr2, mc0, mc2;
+      if (MASK) {
+        const unsigned char* mb = xs + XT + (pgrp + kk * 16) * 2;
+        fyr0 = __builtin_bit_cast(u32x4, fy) & *reinterpret_cast<const u32x4*>(mb);
+        fyr2 = __builtin_bit_cast(u32x4, fy) & *reinterpret_cast<const u32x4*>(mb + WPX * 2);
+        mc0 = *reinterpret_cast<const u32x4*>(mb + 2 * WPX * 2);
+        mc2 = *reinterpret_cast<const u32x4*>(mb + 3 * WPX * 2);
+      }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int sh = (t / 3) * Wd + (t % 3);
-        const int ra = row + sh, rb = row2 + sh;
-        const bf16x4 x0 = ds_read_tr(xs + ra * XRB + ((((cx >> 3) ^ (((ra >> 1) & 1) << 2)) << 4) | ox));
-        const bf16x4 x1 = ds_read_tr(xs + rb * XRB + ((((cx >> 3) ^ (((rb >> 1) & 1) << 2)) << 4) | ox));
+        bf16x4 x0, x1;
+        if (WC) {
+          constexpr int W_ = WC ? WC : 1;
+          const int shc = (t / 3) * W_ + (t % 3);
+          x0 = ds_read_tr(xs + xl[shc & 3] + (kk * 16 + shc) * XRB);
+          x1 = ds_read_tr(xs + xl[shc & 3] + (kk * 16 + shc + 4) * XRB);
+        } else {
+          const int row = kk * 16 + pgrp + trow;
+          const int ra = row + sh, rb = row + 4 + sh;
+          x0 = ds_read_tr(xs + ra * XRB + ((((cx >> 3) ^ (((ra >> 1) & 1) << 2)) << 4) | ox));
+          x1 = ds_read_tr(xs + rb * XRB + ((((cx >> 3) ^ (((rb >> 1) & 1) << 2)) << 4) | ox));
+        }
         const bf16x8 fx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy, fx, acc[t], 0, 0, 0);
+        bf16x8 fyt = fy;
+        if (MASK) {
+          u32x4 v = t / 3 == 0 ? fyr0 : t / 3 == 2 ? fyr2 : __builtin_bit_cast(u32x4, fy);
+          if (t % 3 == 0) v &= mc0;
+          if (t % 3 == 2) v &= mc2;
+          fyt = __builtin_bit_cast(bf16x8, v);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fyt, fx, acc[t], 0, 0, 0);
       }
     }
   };
@@ -420,8 +473,169 @@ __global__ __launch_bounds__(512) void wgrad_halo9_kernel(Args p) {
   }
 }
 
+// The same workgroup tile (128 n x 9 taps x 64 channels) with the waves cut differently: 2 (n: 64 each) x 2 (channel tile of
+// 32) x 2 (taps 0 - 4 / 5 - 8): 10 or 8 accumulator tiles per wave, and per 16-pixel sub-step 2 dy + 5 (4) x fragments for 10 (8)
+// MFMAs instead of 1 + 9 for 9 -- 35 % fewer LDS fragment bytes per MFMA.  Waves w and w + 4 (the two tap groups) share a SIMD.
+template <int NS, int WC, bool MASK>
+__global__ __launch_bounds__(512) void wgrad_halo9b_kernel(Args p) {
+  constexpr int WPX = 64, XROWS = 96, YRB = 256, XRB = 128;
+  constexpr int YT = WPX * YRB, XT = XROWS * XRB, MT = MASK ? 4 * WPX * 2 : 0, STAGE = YT + XT + MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tg = wave >> 2, ng = (wave >> 1) & 1, cg = wave & 1;
+  int bid;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_n = p.N / 128, cchunks = p.C / 64;
+  const int tiles = tiles_n * cchunks;
+  const int split = bid / tiles;
+  bid -= split * tiles;
+  const int tile_n = bid / cchunks, cchunk = bid - tile_n * cchunks;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int steps = (m_end - m_begin + WPX - 1) / WPX;
+  const int xrows_total = p.M + 2 * WC + 2;
+  const int yr = lane >> 4, yslot = lane & 15;
+  const int xr = lane >> 3, xslot = lane & 7;
+  auto issue = [&](int step) {
+    unsigned char* ys = smem + (step % NS) * STAGE;
+    unsigned char* xs = ys + YT;
+    const int m0 = m_begin + step * WPX;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 4 * (wave + 8 * j) + yr;
+      const int m = m0 + row;
+      const int cs = yslot ^ ((row & 3) << 2);
+      const bool ok = m < m_end && step < steps;
+      const unsigned off = ((unsigned)m * (unsigned)p.N + (unsigned)(tile_n * 128 + cs * 8)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lptr_t)(ys + 4 * (wave + 8 * j) * YRB), 16, (int)(ok ? off : OOB), 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (wave + 8 * j < XROWS / 8) {
+        const int row = 8 * (wave + 8 * j) + xr;
+        const int xm = m0 + row;
+        const int cs = xslot ^ (((row >> 1) & 1) << 2);
+        const bool ok = xm < xrows_total && step < steps;
+        const unsigned off = ((unsigned)xm * (unsigned)p.C + (unsigned)(cchunk * 64 + cs * 8)) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + 8 * (wave + 8 * j) * XRB), 16, (int)(ok ? off : OOB), 0, 0, 0);
+      }
+    }
+    if (MASK) {
+      unsigned short* ms = reinterpret_cast<unsigned short*>(xs + XT);
+      if (tid < 4 * WPX) {
+        const int which = tid / WPX, px = tid - which * WPX;
+        const int m = m0 + px;
+        const int q = m / WC, w = m - q * WC, h = q % WC;
+        const bool v = which == 0 ? h >= 1 : which == 1 ? h <= WC - 2 : which == 2 ? w >= 1 : w <= WC - 2;
+        ms[tid] = v ? 0xffffu : 0u;
+      }
+    }
+  };
+
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][t][i] = 0.f;
+  const int t16 = lane & 15, g = lane >> 4;
+  const int colsel = (g & 1) * 16, pgrp = (g >> 1) * 8, trow = t16 >> 2, tcol = (t16 & 3) * 4;
+  const int cx = cg * 32 + colsel + tcol, ox = ((cx & 4) << 1);
+  const int cxb = ((cx >> 3) << 4) | ox;
+  int xl[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) xl[q] = (pgrp + trow) * XRB + (cxb ^ (((trow + q) & 2) << 5));
+  int yl[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int cy = ng * 64 + a * 32 + colsel + tcol;
+    yl[a] = (pgrp + trow) * YRB + ((((cy >> 3) ^ (trow << 2)) << 4) | ((cy & 4) << 1));
+  }
+
+  auto taps = [&](const unsigned char* ys, const unsigned char* xs, auto T0, auto NT) {
+    constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value;
+#pragma unroll
+    for (int kk = 0; kk < WPX / 16; ++kk) {
+      u32x4 fy[2], fyr0[2], fyr2[2], mc0, mc2;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x4 y0 = ds_read_tr(ys + yl[a] + kk * 16 * YRB);
+        const bf16x4 y1 = ds_read_tr(ys + yl[a] + kk * 16 * YRB + 4 * YRB);
+        fy[a] = __builtin_bit_cast(u32x4, __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+      if (MASK) {
+        const unsigned char* mb = xs + XT + (pgrp + kk * 16) * 2;
+        const u32x4 r0 = *reinterpret_cast<const u32x4*>(mb), r2 = *reinterpret_cast<const u32x4*>(mb + WPX * 2);
+        mc0 = *reinterpret_cast<const u32x4*>(mb + 2 * WPX * 2);
+        mc2 = *reinterpret_cast<const u32x4*>(mb + 3 * WPX * 2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          fyr0[a] = fy[a] & r0;
+          fyr2[a] = fy[a] & r2;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < nt; ++i) {
+        constexpr int W_ = WC;
+        const int t = t0 + i;
+        const int shc = (t / 3) * W_ + (t % 3);
+        const bf16x4 x0 = ds_read_tr(xs + xl[shc & 3] + (kk * 16 + shc) * XRB);
+        const bf16x4 x1 = ds_read_tr(xs + xl[shc & 3] + (kk * 16 + shc + 4) * XRB);
+        const bf16x8 fx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          u32x4 v = fy[a];
+          if (MASK) {
+            v = t / 3 == 0 ? fyr0[a] : t / 3 == 2 ? fyr2[a] : fy[a];
+            if (t % 3 == 0) v &= mc0;
+            if (t % 3 == 2) v &= mc2;
+          }
+          acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), fx, acc[a][i], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+#pragma unroll 1
+  for (int step = 0; step < steps; ++step) {
+    if (wave < 4) wait_vm<(NS - 2) * 4>();
+    else wait_vm<(NS - 2) * 3>();
+    __syncthreads();
+    issue(step + NS - 1);
+    const unsigned char* ys = smem + (step % NS) * STAGE;
+    if (tg == 0) taps(ys, ys + YT, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+    else taps(ys, ys + YT, std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+  }
+
+  float* out = p.out + (size_t)split * p.N * p.cols;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int nt = tg ? 4 : 5, t0 = tg ? 5 : 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (i < nt) {
+        const int col = (t0 + i) * p.C + cchunk * 64 + cg * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = tile_n * 128 + ng * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          out[(size_t)n * p.cols + col] = acc[a][i][r];
+        }
+      }
+    }
+}
+
 // reference for sampled (n, col) pairs: fp64 sum over all pixels
-__global__ void ref_kernel(const bf16_t* x, const bf16_t* dy, const int* samples, int ns, int M, int N, int C, int W,
+__global__ void ref_kernel(const bf16_t* x, const bf16_t* dy, const int* samples, int ns, int M, int N, int C, int W, int H,
                            double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ns) return;
@@ -430,6 +644,10 @@ __global__ void ref_kernel(const bf16_t* x, const bf16_t* dy, const int* samples
   const int shift = (tap / 3) * W + (tap % 3);
   double s = 0.0;
   for (int m = 0; m < M; ++m) {
+    if (H) {
+      const int q = m / W, w = m - q * W, h = q % H;
+      if ((unsigned)(h + tap / 3 - 1) >= (unsigned)H || (unsigned)(w + tap % 3 - 1) >= (unsigned)W) continue;
+    }
     const float a = __uint_as_float(((unsigned)dy[(size_t)m * N + n]) << 16);
     const float b = __uint_as_float(((unsigned)x[(size_t)(m + shift) * C + c]) << 16);
     s += (double)a * (double)b;
@@ -511,7 +729,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_samples, sizeof(int) * 2 * ns));
   CK(hipMalloc(&d_ref, sizeof(double) * ns));
   CK(hipMemcpy(d_samples, hs.data(), sizeof(int) * 2 * ns, hipMemcpyHostToDevice));
-  ref_kernel<<<(ns + 63) / 64, 64>>>(x, dy, d_samples, ns, M, N, C, W, d_ref);
+  ref_kernel<<<(ns + 63) / 64, 64>>>(x, dy, d_samples, ns, M, N, C, W, 0, d_ref);
   std::vector<double> href(ns);
   CK(hipMemcpy(href.data(), d_ref, sizeof(double) * ns, hipMemcpyDeviceToHost));
   printf("wgrad 3x3 N%d %dx%dx%d -> %d, 256 x 256 tiles, %d x %d tiles x %d splits, %d pixels per split\n", NB, H, W, C, N,
@@ -523,6 +741,10 @@ int main(int argc, char** argv) {
       (N / 128) * (C / 64));
   run("resident rows, 3 st, W const", wgrad_halo9_kernel<3, 14>, 512, 3 * (64 * 256 + 96 * 128), a, iters, d_samples, ns, href.data(),
       (N / 128) * (C / 64));
+  run("resident rows, 2 st, W const", wgrad_halo9_kernel<2, 14>, 512, 2 * (64 * 256 + 96 * 128), a, iters, d_samples, ns, href.data(),
+      (N / 128) * (C / 64));
+  run("resident rows, 4 st, W const", wgrad_halo9_kernel<4, 14>, 512, 4 * (64 * 256 + 96 * 128), a, iters, d_samples, ns, href.data(),
+      (N / 128) * (C / 64));
   run("resident rows, 3 st, rolled kk", wgrad_halo9_kernel<3, 0, true>, 512, 3 * (64 * 256 + 96 * 128), a, iters, d_samples, ns, href.data(),
       (N / 128) * (C / 64));
   run("resident rows, 3 st, W const, rolled", wgrad_halo9_kernel<3, 14, true>, 512, 3 * (64 * 256 + 96 * 128), a, iters, d_samples, ns, href.data(),
@@ -531,5 +753,25 @@ int main(int argc, char** argv) {
       (N / 128) * (C / 64));
   run("resident rows, 2 st, W const, rolled", wgrad_halo9_kernel<2, 14, true>, 512, 2 * (64 * 256 + 96 * 128), a, iters, d_samples, ns, href.data(),
       (N / 128) * (C / 64));
+  run("tap-split waves, 2 st", wgrad_halo9b_kernel<2, 14, false>, 512, 2 * (64 * 256 + 96 * 128), a, iters, d_samples, ns, href.data(),
+      (N / 128) * (C / 64));
+  run("tap-split waves, 3 st", wgrad_halo9b_kernel<3, 14, false>, 512, 3 * (64 * 256 + 96 * 128), a, iters, d_samples, ns, href.data(),
+      (N / 128) * (C / 64));
+  // the real convolution: zero padding as per-(pixel, tap) masks
+  a.H = H;
+  ref_kernel<<<(ns + 63) / 64, 64>>>(x, dy, d_samples, ns, M, N, C, W, H, d_ref);
+  CK(hipMemcpy(href.data(), d_ref, sizeof(double) * ns, hipMemcpyDeviceToHost));
+  run("resident rows, 3 st, W const, MASKED", wgrad_halo9_kernel<3, 14, false, true>, 512, 3 * (64 * 256 + 96 * 128 + 4 * 64 * 2), a, iters,
+      d_samples, ns, href.data(), (N / 128) * (C / 64));
+  run("resident rows, 2 st, W const, MASKED", wgrad_halo9_kernel<2, 14, false, true>, 512, 2 * (64 * 256 + 96 * 128 + 4 * 64 * 2), a, iters,
+      d_samples, ns, href.data(), (N / 128) * (C / 64));
+  run("resident rows, 4 st, W const, MASKED", wgrad_halo9_kernel<4, 14, false, true>, 512, 4 * (64 * 256 + 96 * 128 + 4 * 64 * 2), a, iters,
+      d_samples, ns, href.data(), (N / 128) * (C / 64));
+  run("resident rows, 2 st, W const, rolled, MASKED", wgrad_halo9_kernel<2, 14, true, true>, 512, 2 * (64 * 256 + 96 * 128 + 4 * 64 * 2), a,
+      iters, d_samples, ns, href.data(), (N / 128) * (C / 64));
+  run("tap-split waves, 2 st, MASKED", wgrad_halo9b_kernel<2, 14, true>, 512, 2 * (64 * 256 + 96 * 128 + 4 * 64 * 2), a, iters, d_samples, ns,
+      href.data(), (N / 128) * (C / 64));
+  run("tap-split waves, 3 st, MASKED", wgrad_halo9b_kernel<3, 14, true>, 512, 3 * (64 * 256 + 96 * 128 + 4 * 64 * 2), a, iters, d_samples, ns,
+      href.data(), (N / 128) * (C / 64));
   return 0;
 }
