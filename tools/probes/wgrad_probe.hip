@@ -1,13 +1,23 @@
-// Probe (round 4, for round 5): the 256 x 256 / 8-wave weight-gradient tile with its operands staged by LDS-DMA through a
-// ring of four 32-pixel stages, against the library's register-staged form (one register tile set, two 64-pixel stages:
-// the loads of step k + 1 have one step's MFMAs to land in; SQ counters: 41 % MFMA busy, 39 % issue-stalled).
+// Probe (end of round 4, for round 5): what holds the 3x3 weight gradient at 41 % MFMA busy, and a form that does better.
 //
-// Problem (the workload's heaviest 3x3 layer, 14 x 14 x 512 -> 1024 at batch 256), borders left out as in conv_probe.hip:
-//     dW[n][t][c] = sum_m dY[m][n] * X[m + r W + s][c]        t = (r, s), X front-padded by W + 1 pixel rows
-// i.e. a GEMM [N x M] . [M x 9C] whose right operand is nine linear row shifts of one matrix.  One workgroup owns a
-// 256 (n) x 256 (tap, channel) tile over a pixel range and writes an fp32 slab; the transposing LDS reads
-// (ds_read_b64_tr_b16) and the bank swizzle are the library kernel's (csrc/conv_wgrad.hip), the swizzle moved to the SOURCE
-// side of the DMA (a lane's LDS destination is fixed: base + 16 lane).
+// Problem: the workload's heaviest layer, 14 x 14 x 512 -> 1024 at batch 256 (474 GFLOP; library kernel: 511 us),
+//     dW[n][t][c] = sum_m dY[m][n] * X[m + r W + s][c] * valid(m, t)       t = (r, s), X front-padded by W + 1 pixel rows
+// i.e. a GEMM [N x M] . [M x 9C] whose right operand is nine linear row shifts of one matrix, the convolution's zero padding
+// a per-(pixel, tap) predicate inside the reduction.  Every variant writes fp32 slabs [split][N][9C] like the library kernel
+// and is checked against an fp64 reference on 96 sampled outputs.
+//
+//   wgrad_dma_kernel    the library's 256 x 256 / 8-wave tile, operands staged by LDS-DMA (swizzle on the source side) through
+//                       a ring of NS stages of WPX pixels: 557 us (2 x 64), 626 (4 x 32), 814 (8 x 16) -- no better than
+//                       register staging; a deeper prefetch is not what is missing
+//   wgrad_dma4_kernel   the same tile on four waves of 128 x 128 (half the fragment bytes per MFMA): 577 us -- nor LDS reads
+//   wgrad_halo9_kernel  resident rows: 128 (n) x [9 taps x 64 channels] per workgroup, the x rows of a step staged ONCE for
+//                       all nine taps (28 KB per step instead of 64), one accumulator tile per tap: 428 us unmasked;
+//                       MASK: the padding as four factor masks (row ok for r = 0 / 2, column ok for s = 0 / 2) built per step
+//                       into LDS and ANDed onto the dy fragment: 469 - 484 us
+//   wgrad_halo9b_kernel the same tile with the waves cut 2 (n) x 2 (channels) x 2 (taps 0-4 / 5-8): 414 us unmasked,
+//                       463 us with the padding = 1 024 TFLOP/s, 9.5 % under the library kernel
+// (borders are left out of the first two, as in conv_probe.hip; times on one MI355X, 4 pixel splits = one round of 256
+// workgroups for the resident-row forms, 7 splits for the 256 x 256 tiles)
 //
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/wgrad_probe.hip -o tools/probes/bin/wgrad_probe
 // run:   tools/probes/bin/wgrad_probe [splits] [iters]
