@@ -63,7 +63,7 @@ class Tuning(C.Structure):
   """struct asm_tuning: the kernel-selection overrides (the library itself reads no environment variable)"""
   _fields_ = [(n, C.c_int32) for n in (
       'igemm_mode', 'igemm_tile', 'igemm_v2', 'conv_halo', 'igemm_smallm', 'igemm_pfa', 'igemm_bk64_1x1', 'dgrad_parity',
-      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched', 'igemm3', 'bn_slices', 'bn_order', 'dgrad_s2', 'wgrad_slab_pct')] + [('reserved', C.c_int32 * 1)]
+      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched', 'igemm3', 'bn_slices', 'bn_order', 'dgrad_s2', 'wgrad_slab_pct', 'wgrad_rows')]
 
 
 # environment variable of the HOST -> asm_tuning field (same-box A/B runs, tests); unset = the library's default
@@ -71,7 +71,7 @@ TUNING_ENV = {'ASM_IGEMM_MODE': 'igemm_mode', 'ASM_IGEMM_TILE': 'igemm_tile', 'A
               'ASM_CONV_HALO': 'conv_halo', 'ASM_IGEMM_SMALLM': 'igemm_smallm', 'ASM_IGEMM_PFA': 'igemm_pfa',
               'ASM_IGEMM_BK64_1X1': 'igemm_bk64_1x1', 'ASM_DGRAD_PARITY': 'dgrad_parity', 'ASM_WGRAD_HALO': 'wgrad_halo',
               'ASM_WGRAD_BIG': 'wgrad_big', 'ASM_WGRAD_SPLITS': 'wgrad_splits', 'ASM_WGRAD_LINEAR': 'wgrad_linear',
-              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched', 'ASM_IGEMM3': 'igemm3', 'ASM_BN_SLICES': 'bn_slices', 'ASM_BN_ORDER': 'bn_order', 'ASM_DGRAD_S2': 'dgrad_s2', 'ASM_WGRAD_SLAB_PCT': 'wgrad_slab_pct'}
+              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched', 'ASM_IGEMM3': 'igemm3', 'ASM_BN_SLICES': 'bn_slices', 'ASM_BN_ORDER': 'bn_order', 'ASM_DGRAD_S2': 'dgrad_s2', 'ASM_WGRAD_SLAB_PCT': 'wgrad_slab_pct', 'ASM_WGRAD_ROWS': 'wgrad_rows'}
 
 
 def apply_env_tuning(lib) -> 'Tuning':

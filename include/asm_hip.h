@@ -101,7 +101,9 @@ typedef struct asm_tuning {
                               the four parity classes side by side: dgrad_s2_kernel); 0: four parity-class launches       */
   int32_t wgrad_slab_pct;  /* weight (percent) of the fp32 slab traffic in the weight gradient's split cost model: 100 = as
                               measured stand-alone; larger = fewer pixel splits                                          */
-  int32_t reserved[1];
+  int32_t wgrad_rows;      /* resident-row weight gradient of the deep 3x3 stride-1 layers on 14- and 7-wide maps
+                              (wgrad_rows_kernel): 0 off (default: faster stand-alone, slower beside the other streams of
+                              the training step), 1 where it measured faster stand-alone, 2 wherever the shape allows    */
 } asm_tuning;
 void asm_tuning_defaults(asm_tuning* t);
 int asm_set_tuning(const asm_tuning* t);

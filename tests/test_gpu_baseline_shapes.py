@@ -156,10 +156,10 @@ def test_every_conv_shape_at_batch_256_vs_direct(hip_lib, workload):
       _run_stem(hip_lib, key, errs, against_oracle=False)
     else:
       plan = _run_generic(hip_lib, key, errs, against_oracle=False)
-      big_plans += plan[1] == 256
+      big_plans += plan[1] == 256 or plan[1] == -2      # 256 x 256 tiles, or the resident-row kernel of the deep 3x3 layers
     torch.cuda.synchronize()
   if workload == 'assemble-r50':
-    assert big_plans >= 5, 'the 256 x 256 weight-gradient kernel should carry the heavy layers (%d did)' % big_plans
+    assert big_plans >= 5, 'the 256 x 256 / resident-row weight-gradient kernels should carry the heavy layers (%d did)' % big_plans
   assert not errs, '\n'.join(errs)
 
 

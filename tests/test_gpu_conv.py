@@ -469,3 +469,45 @@ def test_one_launch_stride2_dgrad_is_the_parity_class_launches_bit_for_bit(hip_l
   yr = O._conv_raw(xr, w.float().permute(1, 2, 3, 0), 3, 2)
   (gx,) = torch.autograd.grad(yr, [xr], dy.float().permute(0, 3, 1, 2))
   _check(outs['1'][0], gx.permute(0, 2, 3, 1), name='stride-2 dgrad vs oracle')
+
+
+@pytest.mark.parametrize('shape,splits', [((4, 14, 14, 128, 256), 0), ((2, 14, 14, 512, 1024), 0), ((8, 7, 7, 256, 512), 0),
+                                          ((3, 7, 7, 64, 128), 0), ((5, 14, 14, 64, 128), 1), ((6, 7, 14, 128, 128), 3)],
+                         ids=lambda s: 'x'.join(map(str, s)) if isinstance(s, tuple) else 'splits%d' % s)
+def test_resident_row_weight_gradient_matches_the_general_kernel(hip_lib, shape, splits, monkeypatch):
+  """wgrad_rows_kernel (deep 3x3 stride-1 layers on 14- and 7-wide maps: the x rows of a 64-pixel step staged once for all
+  nine taps, the zero padding as four factor masks ANDed onto the dy fragment) against the general kernel on the same
+  operands: the same sums in another order -- fp32 agreement -- and both against fp64 sums of the bf16 products.  Border
+  pixels are the point: images end inside steps (196 and 49 pixels per image against 64-pixel steps), ranges end inside
+  images, a pixel range per split, one split (straight into dW), a non-square map."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K = shape
+  x = _rand((N, H, W, Cn), 31).cuda()
+  dy = _rand((N, H, W, K), 32).cuda()
+  d = ops.make_conv_desc(N, H, W, Cn, K, 3, 3, 1)
+  if splits:
+    util.set_knob(monkeypatch, 'ASM_WGRAD_SPLITS', str(splits))
+  outs = {}
+  for knob in ('2', '0'):
+    util.set_knob(monkeypatch, 'ASM_WGRAD_ROWS', knob)
+    plan = (C.c_int32 * 6)()
+    assert ops.L().asm_conv2d_wgrad_plan(C.byref(d), C.byref(plan)) == 0
+    assert (plan[1] == -2) == (knob == '2'), list(plan)
+    dw = torch.full((K, 3, 3, Cn), float('nan'), device='cuda')
+    ops.conv_wgrad(d, x, dy, dw)
+    outs[knob] = dw
+  torch.cuda.synchronize()
+  # fp64 reference: dW[k][r][s][c] = sum_{n,h,w} dy[n,h,w,k] * x[n,h+r-1,w+s-1,c] with zero padding
+  xp = torch.nn.functional.pad(x.double().permute(0, 3, 1, 2), (1, 1, 1, 1))
+  ref = torch.empty((K, 3, 3, Cn), dtype=torch.float64, device='cuda')
+  dyd = dy.double().reshape(-1, K)
+  for r in range(3):
+    for s_ in range(3):
+      xs = xp[:, :, r:r + H, s_:s_ + W].permute(0, 2, 3, 1).reshape(-1, Cn)
+      ref[:, r, s_, :] = dyd.t() @ xs
+  scale = float(ref.abs().max())
+  for knob in ('2', '0'):
+    assert bool(torch.isfinite(outs[knob]).all()), knob
+    err = float((outs[knob].double() - ref).abs().max()) / scale
+    assert err <= 2e-5, (knob, err)
+  assert util.rel_l2(outs['2'].cpu(), outs['0'].cpu()) <= 2e-6
