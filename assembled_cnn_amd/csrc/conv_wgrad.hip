@@ -63,7 +63,12 @@ __device__ __forceinline__ int tr_swz(int row) {
 // LIN: 1x1, stride 1, no padding over a densely packed x: output pixel m IS input pixel m and column j IS channel j, so
 // the staging loads need no (image, row, column) decode at all (two multiply-shift divisions, ~25 VALU per row and step in
 // the general form; most weight-gradient launches of a bottleneck network are such 1x1 layers).
-template <int BNW, int BCW, bool LIN = false>
+// NS >= 2 (LIN, 128-column tiles): the two tiles of a step arrive by LDS-DMA into a ring of NS stages, requested NS - 1 steps
+// ahead with counted vmcnt (the loads of the following steps stay in flight across the barrier; csrc/conv_gemm1.hip has the
+// forward / input-gradient twin): no staging registers, no ds_write, and a prefetch distance that does not cost VGPRs.  The
+// XOR swizzle of the transposing reads is applied on the SOURCE side (a lane's LDS destination is base + 16 * lane).  Same
+// steps in the same order as the register-staged loop: bit-identical sums.
+template <int BNW, int BCW, bool LIN = false, int NS = 0>
 __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs p) {
   constexpr int NTHR = BCW == 256 ? 512 : 256;
   constexpr int WROWB = BCW * 2;            // x tile row bytes
@@ -226,7 +231,58 @@ __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs
     }
   };
 
-  if constexpr (BIG) {
+  if constexpr (NS >= 2) {
+    static_assert(LIN && !BIG, "the ring form covers the linear-address 128-column tiles");
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int YPW = YROWB == 256 ? 4 : (YROWB == 128 ? 2 : 1);   // dy pieces (1 KiB) per wave and step
+    constexpr int P = 4 + YPW;
+    static_assert(P * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
+    constexpr int YRPP = 1024 / YROWB;                                // dy rows per piece: 4 / 8 / 16
+    auto issue = [&](int stage, int step) {
+      unsigned char* ys = smem + stage * STAGE;
+      unsigned char* xs = ys + YTILE;
+      const int m0 = m_begin + step * WPX;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int piece = wave + 4 * j;
+        const int row = 4 * piece + (lane >> 4);
+        const int cs = (lane & 15) ^ tr_swz<WROWB>(row);
+        const int m = m0 + row, c = tile_c * BCW + cs * 8;
+        const unsigned off = ((unsigned)m * (unsigned)p.Ci + (unsigned)c) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + 4 * piece * WROWB), 16,
+                                                 (int)((m < m_end && c < p.cols) ? off : ASM_OOB), 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < YPW; ++j) {
+        const int piece = wave + 4 * j;
+        const int row = YRPP * piece + lane / CY;
+        const int cs = (lane % CY) ^ tr_swz<YROWB>(row);
+        const int m = m0 + row, n = tile_n * BNW + cs * 8;
+        const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)n) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lptr_t)(ys + YRPP * piece * YROWB), 16,
+                                                 (int)((m < m_end && n < p.Co) ? off : ASM_OOB), 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < steps) issue(s, s);
+    int cur = 0;
+#pragma unroll 1
+    for (int step = 0; step < steps; ++step) {
+      const int rem = steps - 1 - step;     // steps requested after this one may stay in flight (at most NS - 2 of them)
+      if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS >= 4 ? 2 * P : 0) : "memory");
+      else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS >= 3 ? P : 0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this step's tiles visible; step - 1's stage released
+      if (step + NS - 1 < steps) {
+        int nst = cur + NS - 1;
+        if (nst >= NS) nst -= NS;
+        issue(nst, step + NS - 1);
+      }
+      compute(cur);
+      cur = cur + 1 == NS ? 0 : cur + 1;
+    }
+  } else if constexpr (BIG) {
     // one register tile set (two would not fit beside 128 accumulator registers): tile k+1 is in flight in
     // registers while tile k is multiplied; a 256 x 256 step is 32 MFMAs per wave, twice the cover of a 128 x 128 one
     load_tile(0, ya, xa);
@@ -724,6 +780,21 @@ Plan make_plan(const asm_conv_desc* d) {
   return pl;
 }
 
+// ring depth of the LDS-DMA form for a linear-address 1x1 layer with 128-column tiles (asm_tuning.wgrad_ring: 0 never,
+// n >= 2 forced, -1 per layer from the same-box sweep, tools/gemm1_sweep.py --wgrad), or 0 for the register-staged loop
+int wgrad_ring_depth(const asm_conv_desc* d, const Plan& pl) {
+  const int mode = asm_tune().wgrad_ring;
+  if (mode == 0 || WPX != 64) return 0;
+  if (mode > 0) return mode < 2 ? 2 : (mode > 4 ? 4 : mode);
+  // Round-5 sweep (tools/gemm1_sweep.py --wgrad, every 1x1 shape of Assemble-ResNet-50 at batch 256, bit-identical sums): two
+  // stages (64 KB, two workgroups per CU like the register-staged loop) win 3 - 10 % on the 28 x 28 and smaller maps and on
+  // the 56 x 56 layers with >= 128 input channels, and lose 20 - 30 % on the narrow 56 x 56 ones (x rows of 64 / 128 bytes:
+  // a quarter / half of every 256-byte DMA row is padding); three and four stages (one workgroup per CU) lose everywhere.
+  (void)pl;
+  if ((long long)d->N * d->H * d->W >= 500000 && d->C <= 64) return 0;
+  return 2;
+}
+
 }  // namespace
 
 extern "C" size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d) {
@@ -848,7 +919,28 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   const bool lin = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->Ho == d->H && d->Wo == d->W &&
                    a.x_pix_pitch == d->C && a.x_row_pitch == d->W * d->C && a.x_img_pitch == d->H * d->W * d->C &&
                    asm_tune().wgrad_linear != 0;
-  if (lin && pl.bcw != 256) {
+  const int ring = lin && pl.bcw != 256 ? wgrad_ring_depth(d, pl) : 0;
+  if (ring >= 2) {
+#define LAUNCH_RING(BNW_, NS_)                                                                                         \
+    do {                                                                                                               \
+      constexpr int LDS_ = NS_ * (WPX * BNW_ * 2 + WPX * 256);                                                         \
+      static bool done_[ASM_MAX_DEVICES] = {};                                                                         \
+      if (hipError_t e = asm_ensure_dyn_lds(wgrad_kernel<BNW_, 128, true, NS_>, LDS_, done_); e != hipSuccess)         \
+        ASM_FAIL(ASM_EHIP, "wgrad_kernel (ring): dynamic LDS opt-in: %s", hipGetErrorString(e));                       \
+      ASM_LAUNCH((wgrad_kernel<BNW_, 128, true, NS_>), grid, dim3(256), LDS_, st, a);                                  \
+    } while (0)
+#define LAUNCH_RING_NS(NS_)                                      \
+    do {                                                         \
+      if (pl.bnw == 128) LAUNCH_RING(128, NS_);                  \
+      else if (pl.bnw == 64) LAUNCH_RING(64, NS_);               \
+      else LAUNCH_RING(32, NS_);                                 \
+    } while (0)
+    if (ring == 2) LAUNCH_RING_NS(2);
+    else if (ring == 3) LAUNCH_RING_NS(3);
+    else LAUNCH_RING_NS(4);
+#undef LAUNCH_RING_NS
+#undef LAUNCH_RING
+  } else if (lin && pl.bcw != 256) {
     if (pl.bnw == 128) ASM_LAUNCH((wgrad_kernel<128, 128, true>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);
     else if (pl.bnw == 64) ASM_LAUNCH((wgrad_kernel<64, 128, true>), grid, dim3(256), 2 * (WPX * 128 + WPX * 256), st, a);
     else ASM_LAUNCH((wgrad_kernel<32, 128, true>), grid, dim3(256), 2 * (WPX * 64 + WPX * 256), st, a);

@@ -96,10 +96,13 @@ __global__ void gem_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __res
 // ---- DropBlock (nets/blocks.py:191-251) ---------------------------------------------------------------------
 // keep[h][w][c] = 1 - any(seed(i,j,c) for |h-(i+tl)| <= .. ) : seeds live on the (H-bs+1)x(W-bs+1) grid, are
 // zero-padded by (tl, br) and dilated by a bs x bs SAME max-pool.  The mask is shared by the whole batch.
-__global__ void dropblock_mask_kernel(const float* __restrict__ uniform, float gamma, int H, int W, int C, int bs,
-                                      float* __restrict__ keep) {
+// gamma_dev != nullptr: the Bernoulli mean is read from device memory (a RECORDED training step replays this launch with
+// the arguments it was recorded with, while keep_prob follows its schedule: functions/model_fns.py:26-33)
+__global__ void dropblock_mask_kernel(const float* __restrict__ uniform, float gamma_arg, const float* __restrict__ gamma_dev,
+                                      int H, int W, int C, int bs, float* __restrict__ keep) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= H * W * C) return;
+  const float gamma = gamma_dev ? *gamma_dev : gamma_arg;
   const int c = i % C, w = (i / C) % W, h = i / (C * W);
   const int br = (bs - 1) / 2, tl = (bs - 1) - br;
   const int hs = H - bs + 1, ws = W - bs + 1;
@@ -292,10 +295,21 @@ extern "C" int asm_dropblock_mask(const float* uniform, float gamma, int H, int 
   ASM_REQUIRE(uniform && keep && scale && H >= block_size && W >= block_size && C > 0 && block_size >= 1,
               "dropblock_mask: bad arguments (H=%d W=%d block=%d)", H, W, block_size);
   hipStream_t st = (hipStream_t)stream;
-  ASM_LAUNCH(dropblock_mask_kernel, dim3(cdiv(H * W * C, 256)), dim3(256), 0, st, uniform, gamma, H, W, C,
-                     block_size, keep);
+  ASM_LAUNCH(dropblock_mask_kernel, dim3(cdiv(H * W * C, 256)), dim3(256), 0, st, uniform, gamma, (const float*)nullptr, H, W,
+                     C, block_size, keep);
   ASM_LAUNCH(dropblock_norm_kernel, dim3(1), dim3(256), 0, st, keep, H * W * C, scale);
   ASM_CHECK_LAUNCH("dropblock_mask");
+  return ASM_OK;
+}
+extern "C" int asm_dropblock_mask_dev(const float* uniform, const float* gamma_dev, int H, int W, int C, int block_size,
+                                      float* keep, float* scale, void* stream) {
+  ASM_REQUIRE(uniform && gamma_dev && keep && scale && H >= block_size && W >= block_size && C > 0 && block_size >= 1,
+              "dropblock_mask_dev: bad arguments (H=%d W=%d block=%d)", H, W, block_size);
+  hipStream_t st = (hipStream_t)stream;
+  ASM_LAUNCH(dropblock_mask_kernel, dim3(cdiv(H * W * C, 256)), dim3(256), 0, st, uniform, 0.f, gamma_dev, H, W, C,
+                     block_size, keep);
+  ASM_LAUNCH(dropblock_norm_kernel, dim3(1), dim3(256), 0, st, keep, H * W * C, scale);
+  ASM_CHECK_LAUNCH("dropblock_mask_dev");
   return ASM_OK;
 }
 extern "C" int asm_dropblock_apply(const void* x, const float* keep, const float* scale, const void* relu_mask_from,

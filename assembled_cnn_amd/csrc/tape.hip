@@ -120,6 +120,14 @@ hipError_t asm_fill_async(void* dst, const void* from, int value, size_t bytes, 
   return from ? hipMemcpyAsync(dst, from, bytes, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dst, value, bytes, stream);
 }
 
+extern "C" int asm_memcpy_async(void* dst, const void* src, size_t bytes, void* stream) {
+  ASM_REQUIRE(dst && src, "memcpy_async: null pointer");
+  if (bytes == 0) return ASM_OK;
+  if (hipError_t e = asm_fill_async(dst, src, 0, bytes, (hipStream_t)stream); e != hipSuccess)
+    ASM_FAIL(ASM_EHIP, "memcpy_async: %s", hipGetErrorString(e));
+  return ASM_OK;
+}
+
 extern "C" int asm_stream_join(void* dst, void* src) {
   if (dst == src) return ASM_OK;
   hipEvent_t ev = nullptr;

@@ -173,6 +173,16 @@ class GradSync(object):
       raise RuntimeError('gradient exchange covered %d of %d elements' % (self._reduced, self.arena.total_elems))
     self._reset()
 
+  def abort(self):
+    """A step failed between bucket launches (Trainer._replay): wait for what the collective library already holds and
+    forget the step's watermark, so that the next step starts clean instead of failing with 'replayed out of order'."""
+    for w, _, _ in self._work:
+      try:
+        w.wait()
+      except Exception:
+        pass
+    self._reset()
+
   # Trainer hook: called between backward and the optimiser
   def __call__(self, g32: torch.Tensor):
     self.finish()

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ASM_HIP_LIB') or os.path.join(HERE, 'libasm_hip.so')
 
 ASM_OK, ASM_EINVAL, ASM_ENOTSUP, ASM_EHIP = 0, -1, -2, -3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class AsmError(RuntimeError):
@@ -63,7 +63,8 @@ class Tuning(C.Structure):
   """struct asm_tuning: the kernel-selection overrides (the library itself reads no environment variable)"""
   _fields_ = [(n, C.c_int32) for n in (
       'igemm_mode', 'igemm_tile', 'igemm_v2', 'conv_halo', 'igemm_smallm', 'igemm_pfa', 'igemm_bk64_1x1', 'dgrad_parity',
-      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched', 'igemm3', 'bn_slices', 'bn_order', 'dgrad_s2', 'wgrad_slab_pct', 'wgrad_rows')]
+      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched', 'igemm3', 'bn_slices', 'bn_order', 'dgrad_s2', 'wgrad_slab_pct', 'wgrad_rows',
+      'gemm1', 'wgrad_ring', 'igemm_bk32_3x3', 'spare0', 'spare1', 'spare2')]
 
 
 # environment variable of the HOST -> asm_tuning field (same-box A/B runs, tests); unset = the library's default
@@ -71,7 +72,8 @@ TUNING_ENV = {'ASM_IGEMM_MODE': 'igemm_mode', 'ASM_IGEMM_TILE': 'igemm_tile', 'A
               'ASM_CONV_HALO': 'conv_halo', 'ASM_IGEMM_SMALLM': 'igemm_smallm', 'ASM_IGEMM_PFA': 'igemm_pfa',
               'ASM_IGEMM_BK64_1X1': 'igemm_bk64_1x1', 'ASM_DGRAD_PARITY': 'dgrad_parity', 'ASM_WGRAD_HALO': 'wgrad_halo',
               'ASM_WGRAD_BIG': 'wgrad_big', 'ASM_WGRAD_SPLITS': 'wgrad_splits', 'ASM_WGRAD_LINEAR': 'wgrad_linear',
-              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched', 'ASM_IGEMM3': 'igemm3', 'ASM_BN_SLICES': 'bn_slices', 'ASM_BN_ORDER': 'bn_order', 'ASM_DGRAD_S2': 'dgrad_s2', 'ASM_WGRAD_SLAB_PCT': 'wgrad_slab_pct', 'ASM_WGRAD_ROWS': 'wgrad_rows'}
+              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched', 'ASM_IGEMM3': 'igemm3', 'ASM_BN_SLICES': 'bn_slices', 'ASM_BN_ORDER': 'bn_order', 'ASM_DGRAD_S2': 'dgrad_s2', 'ASM_WGRAD_SLAB_PCT': 'wgrad_slab_pct', 'ASM_WGRAD_ROWS': 'wgrad_rows',
+              'ASM_GEMM1': 'gemm1', 'ASM_WGRAD_RING': 'wgrad_ring', 'ASM_IGEMM_BK32_3X3': 'igemm_bk32_3x3'}
 
 
 def apply_env_tuning(lib) -> 'Tuning':
@@ -103,6 +105,7 @@ SIGNATURES = {
     'asm_abi_version': (_I, []),
     'asm_launch_count': (C.c_ulonglong, []),
     'asm_stream_join': (_I, [_P, _P]),
+    'asm_memcpy_async': (_I, [_P, _P, _Z, _P]),
     'asm_tape_begin': (_I, []),
     'asm_tape_mark': (_I, []),
     'asm_tape_end': (_I, []),
@@ -178,6 +181,7 @@ SIGNATURES = {
     'asm_gem_fwd': (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     'asm_gem_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     'asm_dropblock_mask': (_I, [_P, _F, _I, _I, _I, _I, _P, _P, _P]),
+    'asm_dropblock_mask_dev': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'asm_dropblock_apply': (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _P]),
     'asm_eval_rows': (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     'asm_eval_accumulate': (_I, [_P, _P, _P, _I, _P, _P]),

@@ -125,7 +125,7 @@ class Model(object):
       self.arena.enable_side_stream()     # no-op on the CPU test double
 
   def __call__(self, inputs, training, reuse=False, use_resnet_d=False, keep_prob=1.0, return_embedding=False,
-               record_tape=None, prepadded=False, dropblock_uniforms=None):
+               record_tape=None, prepadded=False, dropblock_uniforms=None, db_static=None):
     """inputs: [N, H, W, 3] float32 / bfloat16 NHWC (already mean-subtracted), or with ``prepadded`` the
     zero-haloed [N, H+6, W+6, 4] bf16 buffer produced by ops.mixup_meansub.  Returns float32 logits
     [N, num_classes] (a view of the padded logits buffer)."""
@@ -147,8 +147,13 @@ class Model(object):
     ctx = Ctx(self.arena, training, False, self.bn_momentum, self.device, tape, self._layers)
     # blocks.dropblock is the identity unless training with keep_prob < 1 (nets/blocks.py:208-213)
     ctx.keep_prob = keep_prob if (training and keep_prob < 1.0) else 1.0
-    ctx.uniforms = iter(dropblock_uniforms) if dropblock_uniforms is not None else None
-    if ctx.keep_prob < 1.0 and ctx.uniforms is None:
+    # db_static (nn.DropBlockState, prepared by the caller for this step): every DropBlock call of the topology runs, whatever
+    # keep_prob is -- at keep_prob = 1 its gamma is 0, the mask all ones and the scale exactly 1, i.e. the identity the
+    # reference returns early for (nets/blocks.py:208-213; the un-fused block tail rounds to bf16 twice more than the fused
+    # one the eager identity path takes) -- so that the step's launch sequence is static
+    ctx.db_static = db_static if training else None
+    ctx.uniforms = iter(dropblock_uniforms) if (dropblock_uniforms is not None and ctx.db_static is None) else None
+    if ctx.keep_prob < 1.0 and ctx.uniforms is None and ctx.db_static is None:
       if self._db_rng is None:
         self._db_rng = torch.Generator(device=self.device)
         self._db_rng.manual_seed(self.seed + 12345)
@@ -180,8 +185,8 @@ class Model(object):
     """the HIP stream the big branch of a BigLittle stage runs on (forward, and blocks 2..n of its backward), or None"""
     if ctx.dry or x.data is None or not x.data.is_cuda or ops.knob('ASM_BL_STREAMS', '1') == '0':
       return None
-    if getattr(ctx, 'keep_prob', 1.0) < 1.0:
-      return None          # DropBlock draws come from one generator in creation order
+    if getattr(ctx, 'keep_prob', 1.0) < 1.0 and getattr(ctx, 'db_static', None) is None:
+      return None          # DropBlock draws come from one generator in creation order (static buffers are drawn beforehand)
     if self._bl_stream is None:
       self._bl_stream = torch.cuda.Stream(device=x.data.device)
       self.arena.extra_streams.append(self._bl_stream)
@@ -249,7 +254,8 @@ class Model(object):
     stage (0.25 / 1.0 for stages 3 / 4, :434-453) or None; active only while training with keep_prob < 1."""
     L = ctx.layer
     cin = x.shape[3]
-    db = db_gamma_scale if (db_gamma_scale is not None and getattr(ctx, 'keep_prob', 1.0) < 1.0) else None
+    db = db_gamma_scale if (db_gamma_scale is not None and (getattr(ctx, 'keep_prob', 1.0) < 1.0 or
+                                                           getattr(ctx, 'db_static', None) is not None)) else None
     kp = getattr(ctx, 'keep_prob', 1.0)
     shortcut = x
     t0 = len(ctx.tape) if ctx.tape is not None else None

@@ -433,6 +433,7 @@ class Ctx(object):
     self._cursor = 0
     self.dlogits = None
     self.uniforms = None      # iterator of DropBlock uniform draws supplied by the caller (tests)
+    self.db_static = None     # DropBlockState: draws and gamma in static device buffers (recordable step)
     self.rng = None           # torch.Generator for DropBlock when none are supplied
     self.training = training
     self.dry = dry
@@ -1054,16 +1055,114 @@ def flatten_pool(ctx: Ctx, x: Var) -> Var:
 DROPBLOCK_SIZE = 7  # nets/resnet_model.py:434-439
 
 
+def dropblock_gamma(gamma_scale: float, keep_prob: float, H: int, W: int) -> float:
+  """the Bernoulli mean of one DropBlock call (nets/blocks.py:231-232), in the host's double arithmetic"""
+  bs = DROPBLOCK_SIZE
+  return gamma_scale * (1. - keep_prob) * (W * H) / (bs ** 2) / ((W - bs + 1) * (H - bs + 1))
+
+
+class DropBlockState(object):
+  """DropBlock inputs of a training step in STATIC device buffers, so that the step can be recorded once and replayed
+  (train.Trainer.capture) while keep_prob follows its schedule (functions/model_fns.py:26-33,221-226) and the draws change:
+  one float32 uniform buffer per DropBlock call of the walk (creation order) and one slot of ``gamma`` per call.  The first
+  step discovers the calls (``slot`` allocates and fills as the walk reaches them); from then on ``prepare`` rewrites every
+  buffer BEFORE the step -- torch kernels on the step's stream, outside the recorded region -- and the walk only picks
+  the buffers up.  The gamma values are the ones the eager path passes by value (same double expression, rounded to
+  float32 once), so a recorded step and an eager step with the same draws keep the same mask bit for bit."""
+  CAP = 256          # DropBlock calls per step (Assemble-ResNet-152: 4 per block x 39 blocks of stages 3 - 4)
+  RING = 16          # pinned staging buffers for the per-step gamma upload
+
+  def __init__(self, device):
+    self.device = torch.device(device)
+    self.slots = []          # (uniform buffer, gamma_scale, H, W) in creation order
+    self.gamma = torch.zeros((self.CAP,), dtype=torch.float32, device=self.device)
+    self.known = False       # a whole step has been walked: the call list is final
+    self._i = 0
+    self._kp = 1.0
+    self._pin = None
+    self._pin_ev = None
+    self._k = 0
+
+  def begin(self, keep_prob: float, uniforms, rng):
+    """Before a step: rewrite gamma and the draws (known call list) or arm discovery (first step)."""
+    self._i = 0
+    self._kp = float(keep_prob)
+    self._given = list(uniforms) if uniforms is not None else None
+    self._rng = rng
+    if not self.known:
+      return
+    n = len(self.slots)
+    if self._given is not None and len(self._given) != n:
+      raise ValueError('dropblock_uniforms holds %d draws, the step makes %d DropBlock calls' % (len(self._given), n))
+    vals = [dropblock_gamma(gs, self._kp, H, W) for (_, gs, H, W) in self.slots]
+    if self.gamma.is_cuda:
+      if self._pin is None:
+        self._pin = [torch.empty((self.CAP,), dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+        self._pin_ev = [None] * self.RING
+      k = self._k
+      self._k = (k + 1) % self.RING
+      if self._pin_ev[k] is not None:
+        self._pin_ev[k].synchronize()      # the upload that last read this staging buffer (RING steps ago) is done
+      self._pin[k][:n] = torch.tensor(vals, dtype=torch.float32)
+      self.gamma[:n].copy_(self._pin[k][:n], non_blocking=True)
+      ev = torch.cuda.Event()
+      ev.record()
+      self._pin_ev[k] = ev
+    else:
+      self.gamma[:n] = torch.tensor(vals, dtype=torch.float32)
+    for i, (u, _, _, _) in enumerate(self.slots):
+      if self._given is not None:
+        g = self._given[i]
+        if tuple(g.shape) != tuple(u.shape):
+          raise ValueError('dropblock uniform has shape %s, expected %s' % (tuple(g.shape), tuple(u.shape)))
+        u.copy_(g, non_blocking=True)
+      else:
+        u.uniform_(0.0, 1.0, generator=self._rng)
+
+  def slot(self, shape, gamma_scale: float, H: int, W: int):
+    """the walk reaches its next DropBlock call: (uniform buffer, gamma slot [1])"""
+    i = self._i
+    self._i += 1
+    if self.known:
+      if i >= len(self.slots) or tuple(self.slots[i][0].shape) != tuple(shape):
+        raise RuntimeError('the DropBlock calls of this step differ from the ones the static buffers were made for')
+      return self.slots[i][0], self.gamma[i:i + 1]
+    if i >= self.CAP:
+      raise RuntimeError('more than %d DropBlock calls in a step' % self.CAP)
+    if self._given is not None:
+      if i >= len(self._given) or tuple(self._given[i].shape) != tuple(shape):
+        raise ValueError('dropblock uniform %d has the wrong shape (expected %s)' % (i, tuple(shape)))
+      u = self._given[i].to(torch.float32).contiguous().clone()
+    else:
+      u = torch.rand(shape, generator=self._rng, device=self.device, dtype=torch.float32)
+    self.slots.append((u, gamma_scale, H, W))
+    self.gamma[i:i + 1].fill_(dropblock_gamma(gamma_scale, self._kp, H, W))
+    return u, self.gamma[i:i + 1]
+
+  def end(self):
+    """after a step's walk"""
+    if not self.known:
+      self.known = True
+    elif self._i != len(self.slots):
+      raise RuntimeError('the step made %d DropBlock calls, %d were prepared' % (self._i, len(self.slots)))
+
+
 def dropblock(ctx: Ctx, x: Var, keep_prob: float, gamma_scale: float, relu: bool) -> Var:
   """blocks.dropblock (nets/blocks.py:191-251) [+ the tf.nn.relu that follows it in the block].
-  One Bernoulli seed mask per call, shared by the whole batch; draws come from ctx.next_uniform."""
+  One Bernoulli seed mask per call, shared by the whole batch; draws come from ctx.next_uniform, or -- with
+  ctx.db_static (DropBlockState) -- from that step's static buffers, with gamma read from device memory."""
   N, H, W, Cn = x.shape
   if ctx.dry:
     return Var(None, x.shape)
   bs = DROPBLOCK_SIZE
-  gamma = gamma_scale * (1. - keep_prob) * (W * H) / (bs ** 2) / ((W - bs + 1) * (H - bs + 1))
-  u = ctx.next_uniform((H - bs + 1, W - bs + 1, Cn))
-  keep, scale = ops.dropblock_mask(u, float(gamma), H, W, Cn, bs)
+  st = getattr(ctx, 'db_static', None)
+  if st is not None:
+    u, gdev = st.slot((H - bs + 1, W - bs + 1, Cn), gamma_scale, H, W)
+    keep, scale = ops.dropblock_mask(u, 0.0, H, W, Cn, bs, gamma_dev=gdev)
+  else:
+    gamma = dropblock_gamma(gamma_scale, keep_prob, H, W)
+    u = ctx.next_uniform((H - bs + 1, W - bs + 1, Cn))
+    keep, scale = ops.dropblock_mask(u, float(gamma), H, W, Cn, bs)
   y = Var(ops.dropblock_apply(x.data, keep, scale, relu=relu))
   if ctx.tape is not None:
     def bwd():

@@ -340,6 +340,11 @@ def dgrad_pool_ok(d: ConvDesc) -> bool:
 def dgrad_s2_ok(d: ConvDesc) -> bool:
   """does the one-launch 3x3 / stride-2 input gradient (csrc/conv_dgrad_s2.hip) take this layer?  It adds a MASKED fan-in
   addend in its copy-out, so the caller need not materialise the masked gradient first.  ASM_DGRAD_S2=0: never"""
+  if not _IS_DOUBLE:        # the library decides from asm_tuning (asm_dgrad_s2_try): ask it, not only the environment
+    t = _lib.Tuning()
+    L().asm_get_tuning(C.byref(t))
+    if not t.dgrad_s2 or t.igemm_mode:
+      return False
   return (knob('ASM_DGRAD_S2', '1') != '0' and knob('ASM_IGEMM_MODE', '0') in ('', '0') and d.R == 3 and d.S == 3
           and d.stride == 2 and d.pad == 1 and d.C == 64 and d.K == 64 and d.H == 2 * d.Ho and d.W == 2 * d.Wo
           and d.Ho % 8 == 0 and d.Wo % 8 == 0)
@@ -918,12 +923,28 @@ def gem_bwd(x, dy, ssum, p=3.0):
   return dx
 
 
-def dropblock_mask(uniform, gamma, H, W, Cn, block_size):
+def dropblock_mask(uniform, gamma, H, W, Cn, block_size, gamma_dev=None):
+  """gamma_dev: float32 device tensor [1] holding the Bernoulli mean instead of the host scalar (a recorded step replays
+  the launch with its recorded arguments; the host rewrites gamma_dev[0] as keep_prob follows its schedule)."""
   keep = empty((H, W, Cn), F32, uniform)
   scale = empty((1,), F32, uniform)
-  check(L().asm_dropblock_mask(_ptr(uniform), gamma, H, W, Cn, block_size, _ptr(keep), _ptr(scale), _stream()),
-        'dropblock_mask')
+  if gamma_dev is not None:
+    check(L().asm_dropblock_mask_dev(_ptr(uniform), _ptr(gamma_dev), H, W, Cn, block_size, _ptr(keep), _ptr(scale),
+                                     _stream()), 'dropblock_mask_dev')
+  else:
+    check(L().asm_dropblock_mask(_ptr(uniform), gamma, H, W, Cn, block_size, _ptr(keep), _ptr(scale), _stream()),
+          'dropblock_mask')
   return keep, scale
+
+
+def memcpy(dst: torch.Tensor, src: torch.Tensor):
+  """dst <- src, two contiguous device tensors of the same byte size, through the library (asm_memcpy_async: seen by a
+  launch tape that is being recorded, unlike a framework copy kernel)."""
+  nb = src.numel() * src.element_size()
+  if not (dst.is_contiguous() and src.is_contiguous()) or dst.numel() * dst.element_size() != nb:
+    raise ValueError('memcpy needs two contiguous tensors of the same byte size')
+  check(L().asm_memcpy_async(_ptr(dst), _ptr(src), nb, _stream()), 'memcpy_async')
+  return dst
 
 
 def dropblock_apply(x, keep, scale, relu=False, relu_mask_from=None):

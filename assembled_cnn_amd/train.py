@@ -17,7 +17,7 @@ from typing import Callable, List, Optional
 
 import torch
 
-from . import ops
+from . import nn, ops
 from .model import Model
 
 IMAGENET_NUM_CLASSES = 1001          # functions/data_config.py:44
@@ -166,7 +166,14 @@ class Trainer(object):
   """Holds the model + optimiser state and runs training steps.  ``grad_sync`` (see dp.py) is called
   between backward and the optimiser with the flat fp32 gradient arena."""
 
-  def __init__(self, hparams: HParams, seed: int = 0, device='cuda', grad_sync=None, world_size: int = 1):
+  AUTO_WARMUP = 3      # eager steps of one input signature before train_step records itself
+
+  def __init__(self, hparams: HParams, seed: int = 0, device='cuda', grad_sync=None, world_size: int = 1,
+               recorded: Optional[bool] = None):
+    """``recorded``: None (default) -- on a GPU, train_step records itself after AUTO_WARMUP eager steps with inputs of one
+    shape (Trainer.capture: the launch tape) and replays from then on, re-records when the shapes change and falls back
+    to the eager step, with a warning, if recording fails; True -- the same, but a failed recording raises; False --
+    never on its own (capture() can still be called).  ASM_STEP_TAPE=0 switches the automatic recording off."""
     self.p = hparams
     self.model = hparams.make_model(seed, device)
     self.lr_fn = lr_fn_from_hparams(hparams)
@@ -181,6 +188,16 @@ class Trainer(object):
     # the stream a captured step is recorded and replayed on: taken from the pool BEFORE the model takes its side streams
     dev = torch.device(device)
     self._step_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+    self.recorded = recorded
+    self._auto = dev.type == 'cuda' and recorded is not False and ops.knob('ASM_STEP_TAPE', '1') != '0'
+    self._auto_sig, self._auto_n, self._auto_made = None, 0, False
+    self._capturing = False
+    self.step_mode = 'eager'                 # 'eager' | 'recorded' | 'eager (recording failed: ...)'
+    # DropBlock with its draws and gamma in static device buffers (nn.DropBlockState): what lets the published recipe
+    # (scripts/train_assemble_from_scratch.sh: --use_dropblock=True) run as a recorded step
+    # (on the CPU test double only on request: recorded=True, for the host-logic tests)
+    self._db = nn.DropBlockState(dev) if (self.keep_prob_fn is not None and recorded is not False and
+                                          (dev.type == 'cuda' or recorded is True)) else None
 
   @property
   def stream(self):
@@ -196,6 +213,10 @@ class Trainer(object):
     either way (tests/test_gpu_model.py); only the overlap changes.  Switching off parks the stream objects and switching
     on again reuses them; ``fresh`` creates new ones instead."""
     import os
+    if self._graph is not None:
+      if not self._auto_made:
+        raise RuntimeError('the stream setting is frozen into the captured step: release_graph() first')
+      self.release_graph()                 # the trainer's own recording: drop it, the next steps record again
     os.environ['ASM_WGRAD_STREAM'] = '1' if on else '0'
     os.environ['ASM_BL_STREAMS'] = '1' if on else '0'
     ops.refresh_tuning()
@@ -251,27 +272,42 @@ class Trainer(object):
     return res
 
   # -----------------------------------------------------------------------------------------------
+  def split_labels(self, labels):
+    """labels -> (hard targets, teacher logits or None).  labels: int [Bin] or, with kd_temp > 0, float32 [Bin, 2C] =
+    concat(one-hot, teacher logits) (run_loop_classification.py:90-96).  Framework slices / casts: this is the part of the
+    input side that stays OUTSIDE a recorded step (capture keeps the two halves as separate static buffers)."""
+    p = self.p
+    C = p.num_classes
+    if p.kd_temp > 0:
+      if labels.dim() != 2 or labels.shape[1] != 2 * C:
+        raise ValueError('kd_temp > 0 expects labels [B, 2*num_classes]')
+      return labels[:, :C].contiguous(), labels[:, C:].contiguous()
+    return labels.to(torch.int32).contiguous(), None
+
   def prepare_inputs(self, images, labels, lam1=None, lam2=None):
     """images: [Bin,H,W,3] uint8 / float32 (0..255).  labels: int32 [Bin] or, with kd_temp > 0,
     float32 [Bin, 2C] = concat(one-hot, teacher logits) (run_loop_classification.py:90-96).
     Returns (stem input halo buffer, dense targets, teacher probabilities or None)."""
+    hard, tlogits = self.split_labels(labels)
+    return self._prepare(images, hard, tlogits, lam1, lam2)
+
+  def _prepare(self, images, hard, tlogits, lam1, lam2):
+    """The input side of a step from its split labels: library launches only (a recorded step contains it)."""
     p = self.p
     C = p.num_classes
     Bin = images.shape[0]
     if p.kd_temp > 0:
-      if labels.dim() != 2 or labels.shape[1] != 2 * C:
-        raise ValueError('kd_temp > 0 expects labels [B, 2*num_classes]')
-      onehot = labels[:, :C].contiguous()
-      teacher = ops.softmax_rows(labels[:, C:].contiguous(), Bin, C, 1.0 / p.kd_temp)
+      onehot = hard
+      teacher = ops.softmax_rows(tlogits, Bin, C, 1.0 / p.kd_temp)
     else:
-      onehot = ops.onehot(labels.to(torch.int32).contiguous(), Bin, C)
+      onehot = ops.onehot(hard, Bin, C)
       teacher = None
     mt = p.mixup_type
     if mt not in (0, 1, 2):
       raise ValueError('mixup_type must be 0, 1 or 2')
     if mt and lam1 is None:
       raise ValueError('mixup needs the Beta(0.2, 0.2) draws (lam1 [, lam2])')
-    x = ops.mixup_meansub(images.contiguous(), mt, lam1, lam2)
+    x = ops.mixup_meansub(images if images.is_contiguous() else images.contiguous(), mt, lam1, lam2)
     if mt:
       onehot_src = onehot
       onehot = ops.mixup_labels(onehot, mt, lam1, lam2)
@@ -279,11 +315,17 @@ class Trainer(object):
         if mt == 2:
           # the reference mixes the second-half teacher targets from the HARD labels y1, not y1_t
           # (utils/data_util.py:154).  Reproduced: first half = type-1 mix of the teacher; second half = the
-          # type-2 mix of [y1 ; y2_t], whose second half is lam2*y1 + (1-lam2)*reverse(y2_t).
+          # type-2 mix of [y1 ; y2_t], whose second half is lam2*y1 + (1-lam2)*reverse(y2_t).  Row ranges are moved
+          # with library copies, so that a recorded step sees them.
           half = Bin // 2
           first = ops.mixup_labels(teacher, 1, lam1, None)
-          second = ops.mixup_labels(torch.cat([onehot_src[:half], teacher[half:]], 0).contiguous(), 2, lam1, lam2)
-          teacher = torch.cat([first, second[half:]], 0).contiguous()
+          src2 = ops.empty((Bin, C), torch.float32, teacher)
+          ops.memcpy(src2[:half], onehot_src[:half])
+          ops.memcpy(src2[half:], teacher[half:])
+          second = ops.mixup_labels(src2, 2, lam1, lam2)
+          teacher = ops.empty((Bin, C), torch.float32, second)
+          ops.memcpy(teacher[:half], first)
+          ops.memcpy(teacher[half:], second[half:])
         else:
           teacher = ops.mixup_labels(teacher, mt, lam1, lam2)
     return x, onehot, teacher
@@ -298,20 +340,71 @@ class Trainer(object):
   # -----------------------------------------------------------------------------------------------
   def train_step(self, images, labels, lam1=None, lam2=None, lr: Optional[float] = None,
                  dropblock_uniforms=None):
-    if self._graph is not None and dropblock_uniforms is None:
-      return self._replay(images, labels, lam1, lam2, lr)
+    """One optimisation step.  A recorded step (capture(), or the trainer's own recording after AUTO_WARMUP eager steps) is
+    replayed; ``dropblock_uniforms`` (tests: the draws of every DropBlock call in creation order) go into the static
+    draw buffers of a recorded step, or straight to the layers of an eager one."""
+    if self._graph is not None:
+      if self._auto_made and self._signature(images, labels, lam1, lam2) != self._auto_sig:
+        self.release_graph()               # other shapes: back to the eager step, which records itself again
+      elif dropblock_uniforms is not None and self._db is None:
+        pass                               # a step captured without DropBlock state: run this one eagerly
+      else:
+        return self._replay(images, labels, lam1, lam2, lr, dropblock_uniforms)
     loss_rows, loss_scale, keep_prob = self._forward_backward(images, labels, lam1, lam2, dropblock_uniforms)
-    return self._apply(loss_rows, loss_scale, keep_prob, lr)
+    out = self._apply(loss_rows, loss_scale, keep_prob, lr)
+    if self._auto and self._graph is None and not self._capturing:
+      self._auto_step(images, labels, lam1, lam2)
+    return out
+
+  @staticmethod
+  def _signature(images, labels, lam1, lam2):
+    return tuple((tuple(t.shape), t.dtype if t.dim() != 1 or t.dtype.is_floating_point else torch.int32, t.device)
+                 if t is not None else None for t in (images, labels, lam1, lam2))
+
+  def _auto_step(self, images, labels, lam1, lam2):
+    """after an eager step: count steps of one input signature; record once there were AUTO_WARMUP of them"""
+    if not images.is_cuda or (self.grad_sync is not None and not hasattr(self.grad_sync, 'launch_recorded')):
+      return
+    sig = self._signature(images, labels, lam1, lam2)
+    if sig != self._auto_sig:
+      self._auto_sig, self._auto_n = sig, 0
+    self._auto_n += 1
+    if self._auto_n < self.AUTO_WARMUP:
+      return
+    try:
+      self.capture(images, labels, lam1, lam2, warmup=0)
+      self._auto_made = True
+    except Exception as e:                 # loud, once: the trainer stays eager
+      if self.recorded is True:
+        raise
+      import warnings
+      self._auto = False
+      self.step_mode = 'eager (recording failed: %s)' % (str(e).splitlines()[0][:200] if str(e) else type(e).__name__)
+      warnings.warn('assembled_cnn_amd.Trainer: recording the training step failed, staying with the eager step '
+                    '(14 ms of host time per step instead of 3): %r' % (e,), RuntimeWarning)
 
   def _forward_backward(self, images, labels, lam1, lam2, dropblock_uniforms=None):
     """Everything of a step that does not depend on the step number: inputs -> loss rows, gradients in the arena."""
+    hard, tlogits = self.split_labels(labels)
+    return self._forward_backward_split(images, hard, tlogits, lam1, lam2, dropblock_uniforms)
+
+  def _forward_backward_split(self, images, hard, tlogits, lam1, lam2, dropblock_uniforms=None, db_prepared=False):
+    """_forward_backward behind split_labels: library launches only (this is what a recording holds).  With DropBlock state (self._db) the draws and gamma of this step are written
+    into its static buffers first -- unless the caller has done that already (db_prepared: a step being recorded)."""
     p = self.p
     m = self.model
-    x, onehot, teacher = self.prepare_inputs(images, labels, lam1, lam2)
-    B = x.shape[0]
     keep_prob = self.keep_prob_fn(self.global_step) if self.keep_prob_fn else 1.0
+    db = self._db
+    if db is not None and not db_prepared:
+      db.begin(keep_prob, dropblock_uniforms, self._db_rng())
+    elif db is not None:
+      db._i = 0
+    x, onehot, teacher = self._prepare(images, hard, tlogits, lam1, lam2)
+    B = x.shape[0]
     m(x, True, use_resnet_d=p.use_resnet_d, prepadded=True, keep_prob=keep_prob,
-      dropblock_uniforms=dropblock_uniforms)
+      dropblock_uniforms=dropblock_uniforms if db is None else None, db_static=db)
+    if db is not None:
+      db.end()
     loss_scale = p.get_loss_scale()
     if p.cls_loss_type == 'softmax':      # losses/cls_losses.py:27-33 (+ KD, run_loop_classification.py:156-162)
       loss_rows, dlogits = ops.softmax_ce(m.logits_padded, m.ldc, onehot, teacher, B, p.num_classes,
@@ -325,6 +418,15 @@ class Trainer(object):
       raise AssertionError('cross_entropy is None')   # losses/cls_losses.py:40
     m.backward(dlogits)
     return loss_rows, loss_scale, keep_prob
+
+  def _db_rng(self):
+    """the generator DropBlock draws come from when the caller supplies none (the model's, so that an eager trainer and a
+    recorded one with the same seed draw the same sequence)"""
+    m = self.model
+    if m._db_rng is None:
+      m._db_rng = torch.Generator(device=m.device)
+      m._db_rng.manual_seed(m.seed + 12345)
+    return m._db_rng
 
   def _apply(self, loss_rows, loss_scale, keep_prob, lr=None):
     """[gradient exchange ->] momentum-SGD at the step's learning rate (a host scalar: outside any captured graph)."""
@@ -362,8 +464,13 @@ class Trainer(object):
     ``replay='graph'``: hipGraphLaunch of the captured graph; ROCm 7 spends 11.5 - 22 ms of host time per launch on the
     step's nodes, so this only pays where the eager step is host-bound anyway.
 
-    Both replays are bit-identical to the eager step (tests/test_gpu_model.py).  Not available with DropBlock (its
-    keep_prob and random draws change per step).  With a gradient exchange attached (dp.GradSync) only the tape works: the
+    Both replays are bit-identical to the eager step (tests/test_gpu_model.py).  DropBlock (the published recipe,
+    scripts/train_assemble_from_scratch.sh:22) is recorded with its draws and its gamma in static device buffers that
+    every replay rewrites first (nn.DropBlockState).  KD labels are split into their two halves OUTSIDE the recording
+    (split_labels: framework slices) and everything behind the split is library launches.  The recording is checked
+    against the captured HIP graph: the graph must hold exactly the kernels and copies the tape wrote down -- a framework
+    kernel that slipped into the recorded region would be in the graph only, i.e. silently missing from every replay.
+    With a gradient exchange attached (dp.GradSync) only the tape works: the
     bucket launches the host interleaves with the backward pass become segment boundaries of the tape, and the replayed
     step hands bucket k to RCCL after segment k (tests/test_gpu_dp_rccl.py).  ``warmup`` real training steps run first
     (one-time initialisation must not be recorded).
@@ -373,8 +480,9 @@ class Trainer(object):
       raise RuntimeError('a step is already captured: release_graph() first')
     if replay not in ('tape', 'graph'):
       raise ValueError("replay must be 'tape' or 'graph'")
-    if self.keep_prob_fn is not None:
-      raise NotImplementedError('DropBlock changes keep_prob and its draws every step: the step cannot be one static recording')
+    if self.keep_prob_fn is not None and self._db is None:
+      raise NotImplementedError('DropBlock changes keep_prob and its draws every step: recording needs the static DropBlock '
+                                'buffers (a Trainer made with recorded=False has none)')
     if self.grad_sync is not None and replay != 'tape':
       raise NotImplementedError('with a gradient exchange attached the bucket launches are host-driven: a HIP graph cannot '
                                 'hold them; the launch tape is cut into segments at the bucket launches instead')
@@ -382,9 +490,9 @@ class Trainer(object):
       raise NotImplementedError('capture needs a dp.GradSync as the gradient exchange (segmented replay)')
     if not images.is_cuda:
       raise RuntimeError('capture needs device tensors')
-    if labels.dim() == 1 and labels.dtype != torch.int32:
-      labels = labels.to(torch.int32)        # the conversion is a torch kernel: it must not be part of the recorded step
-    static = [t.clone() if t is not None else None for t in (images, labels, lam1, lam2)]
+    hard, tlogits = self.split_labels(labels)    # framework kernels (cast / column slices): not part of the recorded step
+    static = [t.clone() if t is not None else None for t in (images, hard, tlogits, lam1, lam2)]
+    sig = self._signature(images, labels, lam1, lam2)
     cur = torch.cuda.current_stream(images.device)
     if cur != torch.cuda.default_stream(images.device):
       cap = cur           # already on a stream of the caller's: record there (a capture cannot run on the default stream)
@@ -395,8 +503,15 @@ class Trainer(object):
     if cap != cur:
       ops.stream_join(cap, cur)
     with torch.cuda.stream(cap):
-      for _ in range(warmup):     # one-time initialisation (workspaces, kernel attributes, side streams) stays out of the recording
-        self.train_step(images, labels, lam1, lam2)
+      self._capturing = True      # the warm-up steps below must not start a recording of their own
+      try:
+        for _ in range(warmup):   # one-time initialisation (workspaces, kernel attributes, side streams) stays out of the recording
+          self.train_step(images, labels, lam1, lam2)
+      finally:
+        self._capturing = False
+      if self._db is not None:
+        if not self._db.known:
+          raise RuntimeError('capture with DropBlock needs one eager step first (warmup >= 1): it discovers the DropBlock calls')
     torch.cuda.synchronize()
     # tape replay never launches the captured graph: it is not even instantiated (keep_graph), only kept for its memory pool
     g = torch.cuda.CUDAGraph(keep_graph=(replay == 'tape'))
@@ -411,7 +526,7 @@ class Trainer(object):
         if gs is not None:
           gs.begin_recording()      # bucket launches of the recorded backward pass become segment boundaries of the tape
         try:
-          out = self._forward_backward(*static)
+          out = self._forward_backward_split(*static, db_prepared=True)
         finally:
           if gs is not None:
             gs.end_recording()
@@ -419,13 +534,49 @@ class Trainer(object):
             ops.tape_end()
       if gs is not None and ops.tape_info(tape)['segments'] != len(gs.recorded) + 1:
         raise RuntimeError('tape segments and recorded bucket launches disagree')
+      if tape is not None:
+        self._check_tape_against_graph(g, tape)
     except BaseException:
       if tape is not None:        # a recording that failed half-way is dropped, the trainer stays eager
         ops.tape_free(tape)
       raise
     self._graph, self._static, self._graph_out = g, static, out
     self._tape, self._cap_stream = tape, cap
+    self._auto_sig, self._auto_made = sig, False
+    self.step_mode = 'recorded'
     return self
+
+  @staticmethod
+  def _check_tape_against_graph(g, tape):
+    """A tape replay issues what the LIBRARY launched while the step was captured.  A framework kernel inside the
+    recorded region (a .contiguous(), a cast, a concatenation) is in the captured HIP graph but not on the tape: every
+    replay would silently skip it.  Count the graph's kernel and copy / fill nodes through the HIP runtime and compare."""
+    info = ops.tape_info(tape)
+    try:
+      import ctypes
+      raw = g.raw_cuda_graph()
+      hip = ctypes.CDLL('libamdhip64.so')
+      n = ctypes.c_size_t(0)
+      if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+        return None
+      nodes = (ctypes.c_void_p * n.value)()
+      if hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+        return None
+      kernels = copies = 0
+      for h in nodes[:n.value]:
+        ty = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(h), ctypes.byref(ty)) != 0:
+          return None
+        kernels += ty.value == 0                  # hipGraphNodeTypeKernel
+        copies += ty.value in (1, 2)              # hipGraphNodeTypeMemcpy, hipGraphNodeTypeMemset
+    except (AttributeError, OSError, RuntimeError):
+      return None                                 # this torch / runtime does not expose the raw graph: nothing to compare with
+    # (compared as one total: whether the runtime keeps a device-to-device copy as a copy node or as a blit kernel is its business)
+    if kernels + copies != info['launches'] + info['fills']:
+      raise RuntimeError('the captured step holds %d kernels and %d copies, the launch tape %d and %d: a framework kernel '
+                         'ran inside the recorded region and would be missing from every replay'
+                         % (kernels, copies, info['launches'], info['fills']))
+    return kernels + copies
 
   def release_graph(self):
     if getattr(self, '_tape', None) is not None:
@@ -433,12 +584,14 @@ class Trainer(object):
       ops.tape_free(self._tape)
     self._graph = self._static = self._graph_out = None
     self._tape = self._cap_stream = None
+    self._auto_made = False
+    self._auto_n = 0
+    self.step_mode = 'eager'
 
-  def _replay(self, images, labels, lam1, lam2, lr):
+  def _replay(self, images, labels, lam1, lam2, lr, dropblock_uniforms=None):
     srcs = []
-    for dst, src in zip(self._static, (images, labels, lam1, lam2)):
-      if dst is not None and src is not None and dst.dtype == torch.int32 and src.dtype != torch.int32 and src.dim() == 1:
-        src = src.to(torch.int32)
+    hard, tlogits = self.split_labels(labels)
+    for dst, src in zip(self._static, (images, hard, tlogits, lam1, lam2)):
       if (dst is None) != (src is None) or (dst is not None and (dst.shape != src.shape or dst.dtype != src.dtype)):
         raise ValueError('the captured step takes inputs of the shapes / dtypes it was captured with')
       srcs.append(src)
@@ -456,17 +609,25 @@ class Trainer(object):
       for dst, src in zip(self._static, srcs):
         if dst is not None and dst.data_ptr() != src.data_ptr():
           dst.copy_(src, non_blocking=True)
+      if self._db is not None:      # this step's keep_prob (gamma) and draws into the static DropBlock buffers
+        self._db.begin(self.keep_prob_fn(self.global_step), dropblock_uniforms, self._db_rng())
       gs = self.grad_sync
       if self._tape is not None and gs is not None:
-        for k in range(len(gs.recorded)):   # segment k, then the bucket that became ready at its end goes to RCCL
-          ops.tape_replay(self._tape, k)
-          gs.launch_recorded(k)
-        ops.tape_replay(self._tape, len(gs.recorded))
+        try:
+          for k in range(len(gs.recorded)):   # segment k, then the bucket that became ready at its end goes to RCCL
+            ops.tape_replay(self._tape, k)
+            gs.launch_recorded(k)
+          ops.tape_replay(self._tape, len(gs.recorded))
+        except BaseException:
+          gs.abort()        # half a step's buckets are with the collective library: wait for them, forget the watermark
+          raise
       elif self._tape is not None:
         ops.tape_replay(self._tape)       # (the recording ends with its side streams joined into the capture stream)
       else:
         self._graph.replay()
       loss_rows, loss_scale, keep_prob = self._graph_out
+      if self.keep_prob_fn is not None:
+        keep_prob = self.keep_prob_fn(self.global_step)
       out = self._apply(loss_rows, loss_scale, keep_prob, lr)
     finally:
       if not same:

@@ -66,6 +66,14 @@ WORKLOADS = {
     'assemble-r50-mixup': dict(desc='Assemble-ResNet-50 + mixup(type 1) + label smoothing 0.1 bf16 train',
                                hp=dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
                                        anti_alias_filter_size=3, use_resnet_d=True, mixup_type=1, label_smoothing=0.1)),
+    # the published recipe (scripts/train_assemble_from_scratch.sh:9-34): mixup type 1, label smoothing 0.1, KD at T = 1,
+    # DropBlock with its keep_prob schedule, no resnet_d, cosine learning rate with 5 warm-up epochs; per-GPU shard of
+    # BASELINE config 4's size (256 mixed images from 512 inputs)
+    'assemble-r50-recipe': dict(desc='Assemble-ResNet-50 published recipe: BigLittle + SK + sconv k=3 + DropBlock + mixup(type 1) '
+                                     '+ label smoothing 0.1 + KD (T=1) bf16 train',
+                                hp=dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
+                                        mixup_type=1, label_smoothing=0.1, kd_temp=1.0, use_dropblock=True,
+                                        learning_rate_decay_type='cosine', lr_warmup_epochs=5, train_epochs=600)),
     # published recipe variant (scripts/train_assemble_from_scratch.sh: use_resnet_d=False)
     'assemble-r50-nod': dict(desc='Assemble-ResNet-50 (BigLittle + SK + sconv k=3, no resnet_d) bf16 train',
                              hp=dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv',
@@ -277,14 +285,50 @@ def _gradsync_leg(tr, step, sync, args, plain_ms, capture=None):
     return {'world': 1, 'error': repr(e)}
 
 
+def _recipe_leg(Trainer, make_hp, make_inputs, dev, args, B):
+  """N = 1: the published recipe (scripts/train_assemble_from_scratch.sh: mixup type 1 + label smoothing + KD + DropBlock with
+  its keep_prob schedule) on a DEFAULT Trainer -- nobody calls capture(): train_step records itself after its three eager
+  steps and replays from then on, DropBlock draws and gamma rewritten in their static buffers before every replay."""
+  import torch
+  try:
+    wl = WORKLOADS['assemble-r50-recipe']
+    hp = make_hp(wl)
+    tr = Trainer(hp, seed=0, device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    images, labels, nin = make_inputs(hp, g)
+    lam1 = tr.sample_mixup_lambdas(nin // 2)
+    steps = min(args.steps, 30)
+    with torch.cuda.stream(tr.stream):
+      for _ in range(Trainer.AUTO_WARMUP + 3):
+        tr.train_step(images, labels, lam1)
+      torch.cuda.synchronize()
+      t0 = time.time()
+      for _ in range(steps):
+        tr.train_step(images, labels, lam1)
+      torch.cuda.synchronize()
+      el = time.time() - t0
+    loss = float(tr.cross_entropy())
+    out = {'workload': wl['desc'], 'value': round(B * steps / el, 2), 'unit': 'images/sec', 'ms_per_step': round(1000.0 * el / steps, 3),
+           'steps': steps, 'step_mode': tr.step_mode, 'keep_prob': round(float(tr.last.get('keep_prob', 1.0)), 6),
+           'final_cross_entropy': round(loss, 4),
+           'what': 'per-GPU shard of BASELINE config 4 (512 uint8 images -> 256 mixed) + KD + DropBlock on a default Trainer: '
+                   'the step records itself after %d eager steps (no capture() call); not the headline configuration' % Trainer.AUTO_WARMUP}
+    tr.release_graph()
+    del tr
+    torch.cuda.empty_cache()
+    return out
+  except Exception as e:   # a reported extra must never lose the measured number
+    return {'error': repr(e)}
+
+
 def main():
   if len(sys.argv) >= 3 and sys.argv[1] == '--cpu-baseline-only':
     print(json.dumps(_cpu_baseline_worker(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 20.0)), flush=True)
     return
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=30)
-  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--steps', type=int, default=50)       # SURVEY.md 8d: >= 50 timed steps after >= 10 warm-up steps
+  ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (BASELINE configs: 256)')
   ap.add_argument('--workload', default='assemble-r50', choices=sorted(WORKLOADS))
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -298,6 +342,13 @@ def main():
                   help='N = 1: time the eager step (~930 launches enqueued by Python) instead of the recorded one '
                        '(Trainer.capture: the same launches replayed from a launch tape by one C call)')
   ap.add_argument('--no-gradsync', action='store_true', help='N = 1: skip the extra leg with the gradient exchange attached')
+  ap.add_argument('--no-recipe', action='store_true',
+                  help='N = 1: skip the extra leg that times the published recipe (mixup + label smoothing + KD + DropBlock) as the '
+                       'step a default Trainer records on its own')
+  ap.add_argument('--rehearsal-one-gpu', action='store_true',
+                  help='N > 1 REHEARSAL on a box with one GPU: every rank uses cuda:0 and the process group is gloo (RCCL refuses '
+                       'two ranks on one device).  Executes the real N > 1 control flow of this script -- shards, bucket plan, '
+                       'recorded step cut at the bucket launches, barriers, MAX-reduce -- on hardware; the value is NOT a scaling number')
   ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='precision of the exchanged gradient buckets')
   ap.add_argument('--dry-run-cpu', action='store_true',
                   help='TEST ONLY (tests/test_bench_dryrun_cpu.py): run the control flow of this script -- rank-0 build, '
@@ -319,12 +370,14 @@ def main():
   if not dry:
     if not torch.cuda.is_available():
       raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    if args.rehearsal_one_gpu:
+      local_rank = 0
     torch.cuda.set_device(local_rank)
   if rank == 0:
     __graft_entry__.build()
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('gloo' if dry else 'nccl', rank=rank, world_size=world)
+    dist.init_process_group('gloo' if (dry or args.rehearsal_one_gpu) else 'nccl', rank=rank, world_size=world)
     dist.barrier()
   if dry:
     args.no_roofline = args.no_cpu_baseline = args.no_gradsync = True
@@ -345,25 +398,36 @@ def main():
   B = args.batch
   if 'batch' in wl and args.batch == 256:
     B = wl['batch']               # the per-GPU shard BASELINE quotes for this configuration
-  hp = HParams(**dict(dict(resnet_size=50, zero_gamma=True, weight_decay=1e-4, momentum=0.9,
-                           base_learning_rate=0.1 * B * world / 256, learning_rate_decay_type='fixed',
-                           batch_size=B * world, dtype='bf16'), **wl['hp']))
+  def make_hp(w):
+    return HParams(**dict(dict(resnet_size=50, zero_gamma=True, weight_decay=1e-4, momentum=0.9,
+                               base_learning_rate=0.1 * B * world / 256, learning_rate_decay_type='fixed',
+                               batch_size=B * world, dtype='bf16'), **w['hp']))
+
+  def make_inputs(hp_, gen):
+    nin_ = B * 2 if hp_.mixup_type == 1 else B
+    im = torch.randint(0, 256, (nin_, side, side, 3), generator=gen, device=dev, dtype=torch.uint8)
+    lb = torch.randint(1, 1001, (nin_,), generator=gen, device=dev, dtype=torch.int32)
+    if hp_.kd_temp > 0:   # labels = concat(one-hot, teacher logits) (nets/run_loop_classification.py:90-96)
+      oh = torch.nn.functional.one_hot(lb.long(), 1001).float()
+      te = torch.randn((nin_, 1001), generator=gen, device=dev) * 3.0
+      lb = torch.cat([oh, te], 1).contiguous()
+    return im, lb, nin_
+
+  hp = make_hp(wl)
   dev = torch.device('cpu') if dry else torch.device('cuda', local_rank)
   side = 64 if dry else 224
-  tr = Trainer(hp, seed=0, device=dev, world_size=world)
+  # recorded=False: this script decides itself when the step is recorded (after the warm-up) and releases the recording for
+  # its instrumented legs; a default Trainer records on its own after three eager steps (the `recipe` leg below uses one)
+  tr = Trainer(hp, seed=0, device=dev, world_size=world, recorded=False if not wl['hp'].get('use_dropblock') else None)
+  if wl['hp'].get('use_dropblock'):
+    tr._auto = False            # DropBlock needs the trainer's static draw buffers; the recording is still made below
   tr.model.build((side, side), use_resnet_d=hp.use_resnet_d)
   dp_info = None
   if world > 1:
     tr.grad_sync = dp.GradSync(tr.model.arena, comm_dtype=args.comm_dtype)
     dp_info = _dp_plan(tr.grad_sync, world)
   g = torch.Generator(device=dev).manual_seed(1 + rank)
-  nin = B * 2 if hp.mixup_type == 1 else B
-  images = torch.randint(0, 256, (nin, side, side, 3), generator=g, device=dev, dtype=torch.uint8)
-  labels = torch.randint(1, 1001, (nin,), generator=g, device=dev, dtype=torch.int32)
-  if hp.kd_temp > 0:   # labels = concat(one-hot, teacher logits) (nets/run_loop_classification.py:90-96)
-    onehot = torch.nn.functional.one_hot(labels.long(), 1001).float()
-    teacher = torch.randn((nin, 1001), generator=g, device=dev) * 3.0
-    labels = torch.cat([onehot, teacher], 1).contiguous()
+  images, labels, nin = make_inputs(hp, g)
   lam1 = tr.sample_mixup_lambdas(nin // 2) if hp.mixup_type else None
 
   def step():
@@ -477,6 +541,9 @@ def main():
   if on_stream:
     torch.cuda.default_stream().wait_stream(tr.stream)
     torch.cuda.set_stream(torch.cuda.default_stream())
+  recipe = None
+  if world == 1 and not dry and not args.no_recipe and args.workload != 'assemble-r50-recipe':
+    recipe = _recipe_leg(Trainer, make_hp, make_inputs, dev, args, B)
   class_sum = None
   INSTR = 3
   single = None
@@ -584,6 +651,20 @@ def main():
                                    'algorithmic_bytes_per_step': int(b33),
                                    'frac_of_mfma_peak': round(f33 / (t33 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                                    'launches': sum(v[0] for k, v in convs.items() if k[6] == 3 and k[7] == 3)}
+        f11 = sum(conv_flops(k) * v[0] for k, v in convs.items() if k[6] == 1 and k[7] == 1 and k[2] > 1)
+        t11 = sum(v[1] for k, v in convs.items() if k[6] == 1 and k[7] == 1 and k[2] > 1)
+        b11 = sum(conv_bytes(k) * v[0] for k, v in convs.items() if k[6] == 1 and k[7] == 1 and k[2] > 1)
+        if t11 > 0:
+          # the 1x1 class (conv1 / conv3 / projections on maps larger than 1 x 1) is bandwidth-bound on the large maps and
+          # matrix-bound on the small ones: both fractions are given; its bound is the per-layer max of the two
+          st_obj['conv1x1_class'] = {'ms_per_step': round(t11, 3), 'tflops': round(f11 / (t11 * 1e-3) / 1e12, 1),
+                                     'algorithmic_bytes_per_step': int(b11), 'gbs_in_out_once': round(b11 / (t11 * 1e-3) / 1e9, 1),
+                                     'frac_of_mfma_peak': round(f11 / (t11 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                     'frac_of_hbm_peak': round(b11 / (t11 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     'bound_ms': round(sum(max(conv_flops(k) / (MFMA_BF16_PEAK_TFLOPS * 1e12), conv_bytes(k) / (HBM_PEAK_GBS * 1e9))
+                                                           * v[0] for k, v in convs.items() if k[6] == 1 and k[7] == 1 and k[2] > 1) * 1e3, 3),
+                                     'launches': sum(v[0] for k, v in convs.items() if k[6] == 1 and k[7] == 1 and k[2] > 1),
+                                     'note': 'in + out once: the fan-in addend a conv1 input gradient also reads is not counted'}
         st_obj['conv_all_ms_per_step'] = round(tall, 3)
         if 'bn' in classes:
           nb, tb, wb = classes['bn']
@@ -606,6 +687,14 @@ def main():
             'traffic_source': 'profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --single-stream`, '
                               'tools/profile_round.sh; not measured in this run)' % CLASS_TRAFFIC_FILE,
             'dominant_layer': dominant_obj}
+        if 'conv1x1_class' in st_obj:
+          c11 = st_obj['conv1x1_class']
+          out['roofline']['conv1x1'] = {'bound': 'hbm / mfma per layer', 'ms_per_step': c11['ms_per_step'], 'bound_ms': c11['bound_ms'],
+                                        'frac': round(c11['bound_ms'] / c11['ms_per_step'], 4), 'achieved_tflops': c11['tflops'],
+                                        'achieved_gbs': c11['gbs_in_out_once'],
+                                        'kernel': '1x1 convolution class: every 1x1 fprop / input-gradient / weight-gradient launch on maps '
+                                                  'larger than 1 x 1 (%d launches); frac = sum of per-layer max(flops / 2.5 PFLOP/s, '
+                                                  'bytes / 8 TB/s) over the class time' % c11['launches']}
         if 'bn_class' in st_obj:
           bc = st_obj['bn_class']
           out['roofline']['hbm'] = {'bound': 'hbm', 'achieved': bc['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -653,6 +742,10 @@ def main():
                                'handful of calls per step (stream joins, asm_tape_replay, the optimiser): the launches are the tape\'s'}
     if dp_info is not None:
       out['dp'] = dp_info
+    if recipe is not None:
+      out['recipe'] = recipe
+    if args.rehearsal_one_gpu:
+      out['data'] += '; REHEARSAL: %d ranks sharing ONE GPU over gloo -- exercises the N > 1 code path, the value is not a scaling number' % world
     if dry:
       out['data'] = 'DRY RUN on CPU (test double of the C ABI, gloo): control flow only, the value means nothing'
     if single is not None:

@@ -35,7 +35,7 @@ extern "C" {
 #define ASM_ENOTSUP (-2)
 #define ASM_EHIP (-3)
 
-#define ASM_ABI_VERSION 3
+#define ASM_ABI_VERSION 4
 
 const char* asm_last_error(void);
 int asm_abi_version(void);
@@ -62,6 +62,9 @@ unsigned long long asm_launch_count(void);
  * asm_stream_join(dst, src): dst waits for everything enqueued on src so far (event record + stream wait; raw
  * hipStream_t handles).  The host layer uses it for every cross-stream edge of a step so that a tape sees them. */
 int asm_stream_join(void* dst_stream, void* src_stream);
+/* device-to-device copy on `stream`, seen by a tape that is being recorded (a fill node): row slices / concatenations of
+ * the input side of a step (the KD label split, run_loop_classification.py:90-96) without a framework kernel in between */
+int asm_memcpy_async(void* dst, const void* src, size_t bytes, void* stream);
 int asm_tape_begin(void);
 int asm_tape_mark(void);
 int asm_tape_end(void);
@@ -104,6 +107,14 @@ typedef struct asm_tuning {
   int32_t wgrad_rows;      /* resident-row weight gradient of the deep 3x3 stride-1 layers on 14- and 7-wide maps
                               (wgrad_rows_kernel): 0 off (default: faster stand-alone, slower beside the other streams of
                               the training step), 1 where it measured faster stand-alone, 2 wherever the shape allows    */
+  int32_t gemm1;           /* 1x1 convolutions (forward / input gradient) as a GEMM with a ring of LDS stages, the loads of a
+                              K step requested several steps ahead (igemm1_kernel): -1 per layer (default), 0 never
+                              (igemm2_kernel), n > 0 force tile / depth n of the table in csrc/conv_gemm1.hip            */
+  int32_t wgrad_ring;      /* 1x1 stride-1 weight gradients with a ring of LDS-DMA stages (wgrad1_kernel): -1 per layer
+                              (default), 0 never, n > 0 force ring depth n                                               */
+  int32_t igemm_bk32_3x3;  /* 3x3 layers on 128-row igemm2 tiles stage 32 instead of 64 channels per step (half the LDS: four
+                              workgroups per CU instead of two): 0 never, 1 where Ci == 64, 2 every such layer              */
+  int32_t spare[3];        /* must be 0                                                                                   */
 } asm_tuning;
 void asm_tuning_defaults(asm_tuning* t);
 int asm_set_tuning(const asm_tuning* t);
@@ -440,6 +451,11 @@ int asm_gem_bwd(const void* x, const void* dy, const float* ssum, void* dx, int 
  * on dy with relu_mask_from = the forward output (dx = dy * keep * scale * [y > 0]) or NULL (no fused ReLU). */
 int asm_dropblock_mask(const float* uniform, float gamma, int H, int W, int C, int block_size, float* keep,
                        float* scale, void* stream);
+/* The same with the Bernoulli mean in DEVICE memory (gamma_dev[0]): a recorded training step (asm_tape_replay) issues
+ * this launch with the arguments it was recorded with while keep_prob follows its schedule
+ * (functions/model_fns.py:26-33, 221-226), so the host rewrites gamma_dev[0] before each replay. */
+int asm_dropblock_mask_dev(const float* uniform, const float* gamma_dev, int H, int W, int C, int block_size, float* keep,
+                           float* scale, void* stream);
 int asm_dropblock_apply(const void* x, const float* keep, const float* scale, const void* relu_mask_from, int relu,
                         void* y, int N, int HWC, void* stream);
 /* Evaluation metrics (nets/run_loop_classification.py:208-219): per row arg-max, max softmax probability,

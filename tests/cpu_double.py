@@ -934,6 +934,13 @@ class CpuDouble(object):
     T(scale, (1,), 'f32').copy_((k.numel() / (k.sum() + 1e-8)).view(1))
     return 0
 
+  def asm_dropblock_mask_dev(self, uniform, gamma_dev, H, W, Cn, bs, keep, scale, stream):
+    return self.asm_dropblock_mask(uniform, float(T(gamma_dev, (1,), 'f32')[0]), H, W, Cn, bs, keep, scale, stream)
+
+  def asm_memcpy_async(self, dst, src, nbytes, stream):
+    T(dst, (nbytes,), 'u8').copy_(T(src, (nbytes,), 'u8'))
+    return 0
+
   def asm_dropblock_apply(self, x, keep, scale, relu_mask_from, relu, y, N, HWC, stream):
     v = T(x, (N, HWC), 'bf16').float() * T(keep, (HWC,), 'f32') * T(scale, (1,), 'f32')
     if relu_mask_from:

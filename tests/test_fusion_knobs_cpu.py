@@ -196,8 +196,96 @@ def test_capture_refuses_what_it_cannot_record(cpu_double):
     tr.capture(img, labels)                     # device tensors only: there is no CPU path to record
   with pytest.raises(ValueError):
     tr.capture(img, labels, replay='magic')
-  db = Trainer(HParams(**dict(hp, use_dropblock=True)), seed=0, device='cpu')
+  db = Trainer(HParams(**dict(hp, use_dropblock=True)), seed=0, device='cpu', recorded=False)
   with pytest.raises(NotImplementedError):
-    db.capture(img, labels)
+    db.capture(img, labels)                     # no static DropBlock buffers: nothing a replay could rewrite
   tr.release_graph()                            # nothing captured: a no-op
   tr.train_step(img, labels)                    # and the trainer is an ordinary eager trainer
+
+
+def test_dropblock_from_static_buffers_is_the_eager_dropblock_bit_for_bit(cpu_double):
+  """nn.DropBlockState (what makes the published recipe recordable): draws in static buffers rewritten before every step,
+  gamma read from device memory, every DropBlock call of the topology issued whatever keep_prob is.  Against the eager
+  form (draws handed to the layers, gamma by value): the same losses and the same weights bit for bit over steps whose
+  keep_prob moves.  At keep_prob == 1 exactly (the first step of the reference's schedule) the eager form skips DropBlock
+  and runs the FUSED block tail, the static form runs the un-fused tail with an all-ones mask: the same function, two more
+  bf16 roundings per block -- compared within rounding noise."""
+  from assembled_cnn_amd import nn
+  from assembled_cnn_amd.train import HParams, Trainer
+  hp = dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
+            batch_size=2, use_dropblock=True, dropblock_kp=[0.9, 0.6], train_epochs=1, num_images_train=8,
+            base_learning_rate=0.01, learning_rate_decay_type='fixed')
+  img, _, labels = MP.inputs(2, 224)
+  eager = Trainer(HParams(**hp), seed=0, device='cpu', recorded=False)
+  static = Trainer(HParams(**hp), seed=0, device='cpu', recorded=True)
+  assert eager._db is None and isinstance(static._db, nn.DropBlockState)
+  # discover the draw shapes with a throw-away trainer (the walk asks for them in creation order)
+  probe = Trainer(HParams(**hp), seed=0, device='cpu', recorded=True)
+  probe.train_step(img, labels)
+  shapes = [tuple(u.shape) for (u, _, _, _) in probe._db.slots]
+  assert len(shapes) >= 8
+  g = torch.Generator().manual_seed(5)
+  kps = []
+  for step in range(3):
+    kp = eager.keep_prob_fn(eager.global_step)
+    kps.append(kp)
+    draws = [torch.rand(s, generator=g) for s in shapes]
+    le = eager.train_step(img, labels, dropblock_uniforms=draws).clone()
+    ls = static.train_step(img, labels, dropblock_uniforms=draws).clone()
+    assert torch.equal(le, ls), 'step %d: loss rows differ' % step
+    assert torch.equal(eager.model.arena.w32, static.model.arena.w32), 'step %d: weights differ' % step
+    assert static.last['keep_prob'] == kp
+  assert kps[0] == 0.9 and kps[0] > kps[1] > kps[2]
+  assert static._db.known and len(static._db.slots) == len(shapes)
+  with pytest.raises(ValueError):
+    static.train_step(img, labels, dropblock_uniforms=draws[:-1])     # a draw is missing
+  # keep_prob == 1: all-ones masks, scale exactly 1
+  hp1 = dict(hp, dropblock_kp=[1.0, 1.0])
+  e1 = Trainer(HParams(**hp1), seed=0, device='cpu', recorded=False)
+  s1 = Trainer(HParams(**hp1), seed=0, device='cpu', recorded=True)
+  l_e, l_s = e1.train_step(img, labels).clone(), s1.train_step(img, labels).clone()
+  assert float((l_e - l_s).abs().max()) <= 2e-2 * float(l_e.abs().max())
+  assert float(s1._db.gamma[:len(shapes)].abs().max()) == 0.0
+
+
+def test_kd_input_side_is_library_calls_only(cpu_double, monkeypatch):
+  """ADVICE (round 4, high): a recorded step replays what the LIBRARY launched; a framework slice / concatenation inside
+  the recorded region would be silently missing from every replay.  Behind split_labels the input side must not call a
+  torch kernel: with torch.cat / Tensor.contiguous poisoned, _prepare still runs -- KD with both mixup types -- and
+  gives what the reference formula gives (utils/data_util.py:97-158 incl. the :154 quirk)."""
+  from assembled_cnn_amd.train import HParams, Trainer
+  C, B = 1001, 8
+  g = torch.Generator().manual_seed(3)
+  img = torch.randint(0, 256, (B, 64, 64, 3), generator=g, dtype=torch.uint8)
+  hard = torch.nn.functional.one_hot(torch.randint(1, C, (B,), generator=g), C).float()
+  tl = torch.randn((B, C), generator=g) * 2.0
+  labels = torch.cat([hard, tl], 1)
+  lam1, lam2 = torch.rand(B // 2, generator=g), torch.rand(B // 2, generator=g)
+  for mt in (1, 2):
+    tr = Trainer(HParams(resnet_version=1, batch_size=B, kd_temp=2.0, mixup_type=mt), seed=0, device='cpu')
+    h, t = tr.split_labels(labels)
+    with monkeypatch.context() as m:
+      import sys
+
+      def guard(orig):
+        def f(*a, **k):     # the test double of the library computes with torch; the HOST package must not
+          if sys._getframe(1).f_globals.get('__name__', '').startswith('assembled_cnn_amd'):
+            raise AssertionError('a framework kernel inside the recordable input side')
+          return orig(*a, **k)
+        return f
+      m.setattr(torch, 'cat', guard(torch.cat))
+      m.setattr(torch.Tensor, 'contiguous', guard(torch.Tensor.contiguous))
+      m.setattr(torch.Tensor, 'clone', guard(torch.Tensor.clone))
+      m.setattr(torch.Tensor, 'to', guard(torch.Tensor.to))
+      x, onehot, teacher = tr._prepare(img, h, t, lam1, lam2 if mt == 2 else None)
+    p = torch.softmax(tl / 2.0, 1)
+    half = B // 2
+    l1 = lam1[:, None]
+    want1 = l1 * p[:half] + (1 - l1) * p[half:]
+    if mt == 1:
+      assert teacher.shape == (half, C) and torch.allclose(teacher, want1, atol=1e-6)
+    else:
+      l2 = lam2[:, None]
+      want2 = l2 * hard[:half] + (1 - l2) * torch.flip(p[half:], [0])     # y1, not y1_t: the reference's own quirk
+      assert teacher.shape == (B, C)
+      assert torch.allclose(teacher[:half], want1, atol=1e-6) and torch.allclose(teacher[half:], want2, atol=1e-6)

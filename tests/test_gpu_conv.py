@@ -511,3 +511,80 @@ def test_resident_row_weight_gradient_matches_the_general_kernel(hip_lib, shape,
     err = float((outs[knob].double() - ref).abs().max()) / scale
     assert err <= 2e-5, (knob, err)
   assert util.rel_l2(outs['2'].cpu(), outs['0'].cpu()) <= 2e-6
+
+
+GEMM1_CODES = (1, 2, 5, 8, 10, 11, 12, 13, 14, 15, 16)
+
+
+@pytest.mark.parametrize('shape', [(2, 14, 14, 256, 512, 1), (3, 7, 7, 1024, 264, 1), (2, 28, 28, 64, 72, 1), (1, 9, 11, 40, 136, 1),
+                                   (2, 28, 28, 128, 256, 2)], ids=lambda s: 'x'.join(map(str, s)))
+def test_ring_gemm_of_the_1x1_layers_is_igemm2_bit_for_bit(hip_lib, shape, monkeypatch):
+  """igemm1_kernel (csrc/conv_gemm1.hip: the 1x1 layers as a GEMM with a ring of LDS stages and counted vmcnt) multiplies in
+  igemm2_kernel's (chunk, k) order with its epilogue: every tile / depth of its table must give IDENTICAL outputs --
+  forward, input gradient plain / with a fan-in addend / with a masked addend / with the pooled-gradient gather -- ragged
+  row tiles, channel tails (a single-chunk reduction of 40 channels), output tails and the stride-2 projection (parity
+  class, strided output) included; the fused statistics (summed per tile width) within fp32 summation order; and the
+  forward output against the oracle's convolution."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K, st = shape
+  d = ops.make_conv_desc(N, H, W, Cn, K, 1, 1, st)
+  x = _rand((N, H, W, Cn), 31).cuda()
+  w = _rand((K, 1, 1, Cn), 32, scale=Cn ** -0.5).cuda()
+  dy = _rand((N, d.Ho, d.Wo, K), 33).cuda()
+  addend = _rand((N, H, W, Cn), 34).cuda()
+  mask = torch.randint(0, 256, (N, H, W, Cn // 8), dtype=torch.uint8, generator=torch.Generator().manual_seed(35)).cuda()
+  wt = torch.zeros((Cn, 1, 1, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w, wt, K, 1, 1, Cn)
+  pooled = st == 1 and K % 32 == 0 and H % 2 == 0 and W % 2 == 0
+  pdy = _rand((N, H // 2, W // 2, Cn), 36).cuda() if pooled else None
+
+  def run():
+    y, stt = ops.conv_fprop(d, x, w, want_stats=True)
+    outs = [y, stt, ops.conv_dgrad(d, dy, wt), ops.conv_dgrad(d, dy, wt, addend=addend)]
+    if st == 1:
+      outs.append(ops.conv_dgrad(d, dy, wt, addend=addend, addend_mask=mask))
+    if pooled:
+      outs.append(ops.conv_dgrad(d, dy, wt, addend=addend, addend_mask=mask, pool=(pdy, 2, 2, 0, False)))
+    return outs
+  util.set_knob(monkeypatch, 'ASM_GEMM1', '0')
+  ref = run()
+  yo = _ref_conv(x.cpu(), w.cpu(), st)
+  for code in GEMM1_CODES:
+    util.set_knob(monkeypatch, 'ASM_GEMM1', str(code))
+    poison = [torch.full_like(t, float('nan')) for t in ref for _ in range(2)]
+    del poison        # the caching allocator hands these blocks to run(): an output that is not written cannot pass on stale bytes
+    got = run()
+    for i, (a, b) in enumerate(zip(got, ref)):
+      if i == 1:
+        assert float((a.double() - b.double()).norm()) <= 1e-5 * float(b.double().norm()) + 1e-6, ('stats', code)
+      else:
+        assert torch.equal(a, b), (i, code)
+  util.set_knob(monkeypatch, 'ASM_GEMM1', '-1')
+  _check(ref[0], yo, name='1x1 forward vs oracle')
+
+
+@pytest.mark.parametrize('shape', [(2, 14, 14, 256, 512), (3, 7, 7, 520, 264), (1, 28, 28, 64, 48), (2, 9, 11, 40, 24)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_ring_weight_gradient_is_the_register_staged_one_bit_for_bit(hip_lib, shape, monkeypatch):
+  """wgrad_kernel<.., LIN, NS>: the two tiles of a 64-pixel step by LDS-DMA into a ring of NS stages (source-side swizzle
+  of the transposing reads) instead of through registers -- the same steps in the same order under the same pixel split,
+  so dW must be IDENTICAL for every depth, pixel tails and channel tails included; and within fp32 noise of a float64
+  product."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K = shape
+  d = ops.make_conv_desc(N, H, W, Cn, K, 1, 1, 1)
+  x = _rand((N, H, W, Cn), 41).cuda()
+  dy = _rand((N, H, W, K), 42).cuda()
+  outs = {}
+  for splits in ('0', '3'):
+    util.set_knob(monkeypatch, 'ASM_WGRAD_SPLITS', splits)
+    for ring in ('0', '2', '3', '4'):
+      util.set_knob(monkeypatch, 'ASM_WGRAD_RING', ring)
+      dw = torch.full((K, 1, 1, Cn), float('nan'), dtype=torch.float32, device='cuda')
+      ops.conv_wgrad(d, x, dy, dw)
+      outs[(splits, ring)] = dw
+    for ring in ('2', '3', '4'):
+      assert torch.equal(outs[(splits, ring)], outs[(splits, '0')]), (splits, ring)
+  want = dy.double().reshape(-1, K).t() @ x.double().reshape(-1, Cn)
+  got = outs[('0', '2')].double().reshape(K, Cn)
+  assert float((got - want).norm() / want.norm()) <= 1e-5

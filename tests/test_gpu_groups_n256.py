@@ -145,3 +145,95 @@ def test_group_forward_and_backward_at_batch_256(hip_lib, group):
   for nme, t in vs.trainable.items():
     check(nme, util.product_to_oracle_grad(nme, arena.g(nme).cpu(), t), og[nme], 6e-3)
   assert not errs, '%s:\n  %s' % (name, '\n  '.join(errs))
+
+
+# ---- whole bottleneck blocks at batch 256, nothing forced ---------------------------------------
+# (name, H, cin, filters, blocks, stride): block_layer of Assemble-ResNet-50 + D (SK unit, sconv blur-pool k = 3): a projection
+# block (ResNet-D shortcut: average pool -> 1x1 convolution -> batch norm, its gradient gathered in conv1's input-gradient
+# epilogue; SK unit; blur-pool where the stride is 2; dual batch norm behind one ReLU; reordered backward tape) followed by
+# an identity block (SK unit, conv3's batch norm + residual + ReLU, the lazily masked shortcut gradient as the fan-in
+# addend of conv1's input gradient).  14 x 14 and 7 x 7 maps: the oracle's autograd at batch 256 fits the host.
+BLOCKS = [
+    ('stage 4: 14x14x1024 -> 7x7x2048, stride 2 (projection + blur-pool + identity)', 14, 1024, 512, 2, 2),
+    ('stage 3 tail: 14x14x1024 -> 14x14x1024 (projection at stride 1 + identity)', 14, 1024, 256, 2, 1),
+]
+# measured on MI355X (batch 256, this file): see the bounds below; a failure prints every measured value
+BLOCK_TOL = {'forward': 1e-2, 'dx': 1e-2, 'default': 6e-3}
+
+
+@pytest.mark.parametrize('blk', BLOCKS, ids=lambda b: b[0].split(':')[0].replace(' ', '_'))
+def test_sk_blocks_forward_and_backward_at_batch_256(hip_lib, blk):
+  from assembled_cnn_amd import nn
+  from assembled_cnn_amd.train import HParams
+  from oracle import assembled_oracle as O
+  name, H, cin, filters, nb, stride = blk
+  dev = torch.device('cuda')
+  import zlib
+  g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0xffff)
+  Ho = H // stride
+  cout = 4 * filters
+  x = torch.randn((N, H, H, cin), generator=g).abs_().to(BF)      # a block input is a ReLU output
+  dy = (torch.randn((N, Ho, Ho, cout), generator=g) / (N * Ho * Ho) ** 0.5).to(BF)
+
+  vs = O.VarStore(seed=7)
+  oc = O.Ctx(vs, emulate_bf16=True)
+  xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+  rng = torch.Generator().manual_seed(99)
+
+  def oracle_graph():
+    vs.begin_call()
+    return O.block_layer(oc, xr, filters, True, O._bottleneck_block_v1, nb, stride, True, 'blk', zero_gamma=False,
+                         use_resnet_d=True, use_sk_block=True, anti_alias_filter_size=3, anti_alias_type='sconv')
+  with torch.no_grad():
+    oracle_graph()            # creates the variables
+  for nme, t in vs.trainable.items():      # gamma / beta away from (1, 0): a wrong coefficient must show
+    if nme.endswith('gamma'):
+      t.data.copy_(torch.rand(t.shape, generator=rng) * 0.5 + 0.5)
+    elif nme.endswith('beta'):
+      t.data.copy_(torch.randn(t.shape, generator=rng) * 0.1)
+  zr = oracle_graph()
+  leaves = [xr] + list(vs.trainable.values())
+  grads = torch.autograd.grad(zr, leaves, dy.float().permute(0, 3, 1, 2))
+  og = dict(zip(['x'] + list(vs.trainable.keys()), grads))
+
+  hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True)
+  m = hp.make_model(seed=0, device='cuda')
+  dry = nn.Ctx(m.arena, True, True, 0.997, dev, False, m._layers)
+  dry.keep_prob = 1.0
+  m._block_layer(dry, nn.Var(None, (N, H, H, cin)), filters, nb, stride, 'blk', use_resnet_d=True)
+  m.arena.finalize(dev, 0)
+  assert list(m.arena.specs.keys()) == list(vs.trainable.keys()), (list(m.arena.specs.keys()), list(vs.trainable.keys()))
+  with torch.no_grad():
+    for nme, t in vs.trainable.items():
+      m.arena.w(nme).copy_(util.oracle_to_product_param(nme, t.detach().float()).to(dev))
+  m.arena.refresh_shadows()
+  m.arena.refresh_derived()
+  m.arena.enable_side_stream()
+  ctx = nn.Ctx(m.arena, True, False, 0.997, dev, True, m._layers)
+  ctx.keep_prob = 1.0
+  xv = nn.Var(x.to(dev))
+  out = m._block_layer(ctx, xv, filters, nb, stride, 'blk', use_resnet_d=True)
+  z = out.data
+  out.grad = dy.to(dev)
+  m._ctx = ctx
+  m.backward(None)            # the model's own backward driver (side streams, gradient-notification bookkeeping) over this tape
+  torch.cuda.synchronize()
+
+  rows, errs = [], []
+
+  def check(what, got, ref, tol):
+    r = _rel(got, ref)
+    rows.append('%-60s %.3e (<= %.1e)' % (what, r, tol))
+    if not r <= tol:
+      errs.append(rows[-1])
+
+  check('forward', z, zr.detach().permute(0, 2, 3, 1), BLOCK_TOL['forward'])
+  check('dx', xv.grad, og['x'].permute(0, 2, 3, 1), BLOCK_TOL['dx'])
+  for nme, t in vs.trainable.items():
+    tol = BLOCK_TOL['default']
+    for key, v in BLOCK_TOL.items():
+      if key not in ('forward', 'dx', 'default') and key in nme:
+        tol = v
+    check(nme, util.product_to_oracle_grad(nme, m.arena.g(nme).cpu(), t), og[nme], tol)
+  print('\n'.join(rows))
+  assert not errs, '%s:\n  %s\nall:\n  %s' % (name, '\n  '.join(errs), '\n  '.join(rows))

@@ -268,9 +268,149 @@ def test_the_step_as_one_hip_graph_is_the_same_step(hip_lib, mixup):
     assert runs[0][0] == r[0], (runs[0][0], r[0])
     for p, q in zip(runs[0][1:], r[1:]):
       assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
-  db = Trainer(HParams(**dict(hp, use_dropblock=True)), seed=0, device='cuda')
+  db = Trainer(HParams(**dict(hp, use_dropblock=True)), seed=0, device='cuda', recorded=False)
   with pytest.raises(NotImplementedError):
-    db.capture(*batches[0])
+    db.capture(*batches[0])       # a trainer without the static DropBlock buffers has nothing a replay could rewrite
+
+
+def test_train_step_records_itself(hip_lib):
+  """A default Trainer is the recorded step: after AUTO_WARMUP eager steps with inputs of one shape train_step records the
+  step (launch tape) and replays it; other shapes drop the recording and the next AUTO_WARMUP steps record again;
+  recorded=False never records.  Against a trainer that never records: identical losses and weights, bit for bit."""
+  from assembled_cnn_amd.train import HParams, Trainer
+  hp = dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
+            zero_gamma=True, learning_rate_decay_type='cosine', base_learning_rate=0.01, batch_size=8, label_smoothing=0.1)
+  big = [mp.inputs(8, 64, seed=s) for s in (1, 2)]
+  big = [(b[0].cuda(), b[2].cuda()) for b in big]
+  small = mp.inputs(4, 64, seed=3)
+  small = (small[0].cuda(), small[2].cuda())
+  plan = [big[0], big[1], big[0], big[1], big[0], small, small, small, small, big[1]]
+  n = Trainer.AUTO_WARMUP
+  want_mode = ['eager'] * n + ['recorded'] * (5 - n) + ['eager'] * n + ['recorded'] * (4 - n) + ['eager']
+  runs = []
+  for recorded in (None, False):
+    tr = Trainer(HParams(**hp), seed=0, device='cuda', recorded=recorded)
+    losses, modes = [], []
+    for b in plan:
+      mode_before = tr.step_mode if tr._signature(b[0], b[1], None, None) == tr._auto_sig else 'eager'
+      tr.train_step(*b)
+      modes.append(mode_before)
+      losses.append(float(tr.cross_entropy()))
+    torch.cuda.synchronize()
+    a = tr.model.arena
+    runs.append((losses, a.w32.clone(), a.m32.clone(), a.state.clone()))
+    if recorded is None:
+      assert modes == want_mode, modes
+    else:
+      assert modes == ['eager'] * len(plan) and tr._tape is None
+    tr.release_graph()
+  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+  for p, q in zip(runs[0][1:], runs[1][1:]):
+    assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
+
+
+def test_recorded_step_with_dropblock_equals_eager_bit_for_bit(hip_lib):
+  """The published recipe runs DropBlock (scripts/train_assemble_from_scratch.sh:22): its keep_prob follows a schedule
+  (functions/model_fns.py:26-33) and its draws change every step.  The recorded step keeps both in static device buffers
+  (nn.DropBlockState) that every replay rewrites first.  A default Trainer (records itself) against an eager one that is
+  handed the same draws, at 224 x 224 (DropBlock needs maps of at least 7 x 7), with mixup type 1, label smoothing and
+  KD (the rest of the recipe's input side: the KD label halves are split outside the recording): identical losses,
+  weights, momentum and moving statistics over steps whose keep_prob moves, bit for bit; the recording checked node for
+  node against the captured HIP graph."""
+  from assembled_cnn_amd import ops
+  from assembled_cnn_amd.train import HParams, Trainer
+  hp = dict(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3,
+            zero_gamma=True, learning_rate_decay_type='cosine', base_learning_rate=0.01, batch_size=4, label_smoothing=0.1,
+            mixup_type=1, kd_temp=1.0, use_dropblock=True, dropblock_kp=[0.95, 0.7], train_epochs=1, num_images_train=40)
+  C = 1001
+  g = torch.Generator().manual_seed(11)
+  batches = []
+  for s in (1, 2):
+    img, _, lab = mp.inputs(8, 224, seed=s)
+    soft = torch.cat([torch.nn.functional.one_hot(lab.long(), C).float(), torch.randn((8, C), generator=g) * 2.0], 1)
+    batches.append((img.cuda(), soft.cuda(), torch.rand(4, generator=g).cuda()))
+  probe = Trainer(HParams(**hp), seed=0, device='cuda', recorded=True)
+  probe._auto = False
+  probe.train_step(*batches[0])
+  shapes = [tuple(u.shape) for (u, _, _, _) in probe._db.slots]
+  assert len(shapes) >= 20, len(shapes)
+  del probe
+  draws = [[torch.rand(sh, generator=g).cuda() for sh in shapes] for _ in range(7)]
+  runs = []
+  for recorded in (False, True):
+    tr = Trainer(HParams(**hp), seed=0, device='cuda', recorded=recorded)
+    losses, kps = [], []
+    for s in range(7):
+      tr.train_step(*batches[s % 2], dropblock_uniforms=draws[s])
+      losses.append(float(tr.cross_entropy()))
+      kps.append(tr.last['keep_prob'])
+    torch.cuda.synchronize()
+    a = tr.model.arena
+    runs.append((losses, a.w32.clone(), a.m32.clone(), a.state.clone(), kps))
+    if recorded:
+      assert tr.step_mode == 'recorded' and tr._tape is not None
+      info = ops.tape_info(tr._tape)
+      assert info['launches'] > 400 and info['fills'] == 0, info
+      nodes = Trainer._check_tape_against_graph(tr._graph, tr._tape)
+      assert nodes is None or nodes == info['launches'] + info['fills']
+    else:
+      assert tr.step_mode == 'eager' and tr._tape is None
+    tr.release_graph()
+  assert runs[0][4] == runs[1][4] and runs[0][4][0] > runs[0][4][-1]
+  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+  for p, q in zip(runs[0][1:4], runs[1][1:4]):
+    assert bool(torch.isfinite(p).all()) and torch.equal(p, q)
+
+
+def test_recorded_step_with_kd_and_mixup_type_2(hip_lib):
+  """ADVICE (round 4, high): with kd_temp > 0 the label split and, for mixup type 2, two concatenations were framework
+  kernels INSIDE the recorded region -- in the captured graph, not on the launch tape, i.e. skipped by every replay.
+  Now the split happens outside the recording and the row moves are library copies the tape sees (fill nodes).  Recorded
+  against eager on alternating batches: bit for bit; and capture() refuses a recording whose graph holds a kernel the
+  tape does not."""
+  from assembled_cnn_amd import ops
+  from assembled_cnn_amd.train import HParams, Trainer
+  hp = dict(resnet_version=1, zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01, batch_size=8,
+            mixup_type=2, kd_temp=2.0)
+  C = 1001
+  g = torch.Generator().manual_seed(21)
+  batches = []
+  for s in (1, 2):
+    img, _, lab = mp.inputs(8, 64, seed=s)
+    soft = torch.cat([torch.nn.functional.one_hot(lab.long(), C).float(), torch.randn((8, C), generator=g) * 2.0], 1)
+    batches.append((img.cuda(), soft.cuda(), torch.rand(4, generator=g).cuda(), torch.rand(4, generator=g).cuda()))
+  runs = []
+  for recorded in (False, None):
+    tr = Trainer(HParams(**hp), seed=0, device='cuda', recorded=recorded)
+    losses = []
+    for s in range(7):
+      tr.train_step(*batches[s % 2])
+      losses.append(float(tr.cross_entropy()))
+    torch.cuda.synchronize()
+    a = tr.model.arena
+    runs.append((losses, a.w32.clone(), a.state.clone()))
+    if recorded is None:
+      assert tr.step_mode == 'recorded'
+      assert ops.tape_info(tr._tape)['fills'] == 4      # the four row moves of the type-2 teacher mix
+    tr.release_graph()
+  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+  for p, q in zip(runs[0][1:], runs[1][1:]):
+    assert torch.equal(p, q)
+  # a framework kernel inside the recorded region is caught at capture time
+  tr = Trainer(HParams(**hp), seed=0, device='cuda', recorded=False)
+  orig = tr._prepare
+
+  def leaky(images, hard, tlogits, lam1, lam2):
+    return orig(images, hard + 0.0, tlogits, lam1, lam2)      # `hard + 0.0`: a torch kernel the tape cannot see
+  tr._prepare = leaky
+  tr.train_step(*batches[0])
+  try:
+    tr.capture(*batches[0], warmup=0)
+    caught = Trainer._check_tape_against_graph(tr._graph, tr._tape) is None     # raw graph not exposed: nothing to compare
+  except RuntimeError as e:
+    caught = 'framework kernel' in str(e)
+  assert caught
+  tr.release_graph()
 
 
 def test_a_tape_replays_what_was_recorded(hip_lib):
