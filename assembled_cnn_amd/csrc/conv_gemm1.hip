@@ -230,16 +230,23 @@ struct AutoRow {
   int kind, M, Ci, Co, code;
 };
 constexpr AutoRow kAuto[] = {
-    {0, 802816,   64,   64, 12}, {1, 200704,  256,   64, 12}, {0, 200704,  256,   64, 12}, {2, 200704,   64,  256, 13},
-    {1, 802816,   32,   64, 12}, {0, 802816,   32,  128, 10}, {1, 802816,  128,   32, 12}, {0, 802816,  128,  256, 10},
-    {1, 802816,  256,  128, 14}, {0, 200704,  256,  256,  5}, {1, 200704,  256,  256, 14}, {2, 802816,   64,  256, 14},
-    {0,  50176,  256,  512, 10}, {0, 200704,  256,  128,  5}, {1, 200704,  128,  256,  5}, {2, 200704,  128,  256, 14},
-    {0,  50176,  128,  512, 10}, {1,  50176,  128,  512, 10}, {2,  50176,  128,  512, 12}, {0, 200704,  256,  512, 16},
-    {1, 200704,  512,  256,  5}, {0, 200704,  512,  128,  5}, {1, 200704,  128,  512, 10}, {2, 200704,  128,  512, 14},
-    {1,  12544, 1024,  512,  8}, {1,  50176,  256,  512, 10}, {2,  50176,  256,  512, 10}, {0,  12544,  256, 1024, 16},
-    {1,  12544, 1024,  256,  5}, {0,  12544, 1024,  256,  5}, {1,  12544,  256, 1024, 14}, {2,  12544,  256, 1024, 14},
-    {0,  50176,  512, 1024, 10}, {1,  50176,  256, 1024, 14}, {2,  50176,  256, 1024,  5}, {0,  50176,  256, 1024, 10},
-    {1,  50176,  512, 1024, 14}, {2,  50176,  512, 1024, 14}, {1,  12544, 2048,  512,  8}, {0,  12544, 2048,  512,  8},
+    {0, 802816,   32,   64, 13}, {0, 802816,   32,  128, 13}, {0, 802816,   64,   32, 12}, {0, 802816,   64,  128, 10},
+    {0, 802816,  128,  256, 10}, {0, 802816,  256,   64, 12}, {0, 200704,   64,  256, 10}, {0, 200704,  256,   64, 12},
+    {0, 200704,  256,  128,  5}, {0, 200704,  256,  256,  5}, {0, 200704,  256,  512, 10}, {0, 200704,  512,  128,  5},
+    {0,  50176,  128,  512, 10}, {0,  50176,  256,  512, 10}, {0,  50176,  256, 1024, 10}, {0,  50176,  512,  128, 14},
+    {0,  50176,  512,  256, 16}, {0,  50176,  512,  512, 10}, {0,  50176,  512, 1024, 10}, {0,  50176, 1024,  256, 16},
+    {0,  50176, 1024,  512, 16}, {0,  50176, 1024, 1024, 14}, {0,  12544,  256, 1024, 16}, {0,  12544,  512, 1024, 14},
+    {0,  12544,  512, 2048, 10}, {0,  12544, 1024,  256,  5}, {0,  12544, 2048,  512,  8}, {1, 802816,   32,   64, 12},
+    {1, 802816,   64,   32, 12}, {1, 802816,   64,   64, 11}, {1, 802816,   64,  256, 16}, {1, 802816,  128,   32, 13},
+    {1, 802816,  128,   64, 13}, {1, 802816,  256,  128,  5}, {1, 200704,   64,  256,  5}, {1, 200704,  128,  256,  5},
+    {1, 200704,  128,  512,  5}, {1, 200704,  256,   64, 12}, {1, 200704,  256,  256, 10}, {1, 200704,  512,  256,  5},
+    {1,  50176,  128,  512, 10}, {1,  50176,  256,  512, 10}, {1,  50176,  256, 1024, 14}, {1,  50176,  512,  128,  1},
+    {1,  50176,  512,  512, 10}, {1,  50176,  512, 1024, 10}, {1,  50176, 1024,  256, 16}, {1,  50176, 1024,  512, 14},
+    {1,  50176, 1024, 1024, 10}, {1,  12544,  256, 1024, 14}, {1,  12544,  512, 2048, 10}, {1,  12544, 1024,  256,  8},
+    {1,  12544, 1024,  512,  8}, {1,  12544, 2048,  512,  8}, {1,  12544, 2048, 1024, 16}, {2, 802816,   64,  256, 14},
+    {2, 200704,   64,  256, 13}, {2, 200704,  128,  256, 12}, {2, 200704,  128,  512, 14}, {2,  50176,  128,  512, 12},
+    {2,  50176,  256,  512, 12}, {2,  50176,  256, 1024, 13}, {2,  50176,  512, 1024, 14}, {2,  12544,  256, 1024, 14},
+    {2,  12544,  512, 2048, 14},
 };
 
 int auto_cfg(const IGemmArgs& a, bool stats) {

@@ -51,6 +51,7 @@ struct Tape {
   std::vector<size_t> seg;       // seg[s] = first node of segment s; seg.back() = nodes.size() once closed
   size_t launches = 0, joins = 0, fills = 0;
   bool closed = false;
+  int device = -1;               // the device that was current while the tape was recorded: its streams and events live there
   void destroy_events() {     // asm_tape_free only: never from a static destructor, where the HIP runtime may be gone already
     for (Node& n : nodes)
       if (n.kind == N_JOIN && n.ev) {
@@ -68,9 +69,14 @@ thread_local Tape* t_rec = nullptr;
 
 // events of the eager asm_stream_join (outside a recording): a wait refers to the record that precedes it, so re-recording
 // an event that an earlier, still pending wait used is harmless -- a small ring only bounds the number of live events
+// One ring per DEVICE (events belong to the device that was current when they were created; recording one on a stream of
+// another device fails with an invalid handle): a thread that drives two GPUs gets two rings.
 constexpr int RING = 64;
-thread_local hipEvent_t t_ring[RING];
-thread_local int t_ring_n = 0, t_ring_i = 0;
+struct EventRing {
+  hipEvent_t ev[RING];
+  int n = 0, i = 0;
+};
+thread_local EventRing t_rings[ASM_MAX_DEVICES];
 
 Tape* find(int id) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -142,13 +148,16 @@ extern "C" int asm_stream_join(void* dst, void* src) {
     t->nodes.push_back(n);
     ++t->joins;
   } else {
-    if (t_ring_n < RING) {
-      if (hipEventCreateWithFlags(&t_ring[t_ring_n], hipEventDisableTiming) != hipSuccess)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ASM_MAX_DEVICES) ASM_FAIL(ASM_EHIP, "stream_join: no current device");
+    EventRing& r = t_rings[dev];
+    if (r.n < RING) {
+      if (hipEventCreateWithFlags(&r.ev[r.n], hipEventDisableTiming) != hipSuccess)
         ASM_FAIL(ASM_EHIP, "stream_join: hipEventCreate failed");
-      ++t_ring_n;
+      ++r.n;
     }
-    ev = t_ring[t_ring_i];
-    t_ring_i = (t_ring_i + 1) % t_ring_n;
+    ev = r.ev[r.i];
+    r.i = (r.i + 1) % r.n;
   }
   hipError_t e = hipEventRecord(ev, (hipStream_t)src);
   if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)dst, ev, 0);
@@ -162,6 +171,7 @@ extern "C" int asm_tape_begin(void) {
   g_tapes.emplace_back(new Tape());
   t_rec = g_tapes.back().get();
   t_rec->seg.push_back(0);
+  (void)hipGetDevice(&t_rec->device);
   asm_tape_on = true;
   return (int)g_tapes.size();
 }
@@ -205,6 +215,9 @@ extern "C" int asm_tape_replay(int tape, int segment) {
   if (t == t_rec) ASM_FAIL(ASM_EINVAL, "tape_replay: the tape is being recorded");
   const int nseg = (int)t->seg.size() - 1;
   if (segment >= nseg) ASM_FAIL(ASM_EINVAL, "tape_replay: segment %d of %d", segment, nseg);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != t->device)
+    ASM_FAIL(ASM_EINVAL, "tape_replay: tape %d was recorded on device %d, the current device is %d", tape, t->device, dev);
   const size_t i0 = segment < 0 ? 0 : t->seg[segment], i1 = segment < 0 ? t->nodes.size() : t->seg[segment + 1];
   (void)hipGetLastError();
   for (size_t i = i0; i < i1; ++i) {

@@ -355,7 +355,9 @@ def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional
   """dx = conv_transpose(dy, w) [+ addend [where addend_mask]] [+ avgpool_bwd(pool)];
   pool = (pooled gradient [N,Hp,Wp,C], k, stride, pad, count_valid)"""
   dx = empty((d.N, d.H, d.W, d.C), BF16, dy)
-  ev = _TIMER.start('dgrad', d) if _TIMER is not None else None
+  ev = None
+  if _TIMER is not None:     # tools/insitu_sweep.py keeps the input gradients with a fan-in addend apart (another kernel variant)
+    ev = _TIMER.start('dgrad+add' if (addend is not None and getattr(_TIMER, 'split_addend', False)) else 'dgrad', d)
   if pool is not None:
     pdy, pk, pst, ppad, pcv = pool
     check(L().asm_conv2d_dgrad_pooled(C.byref(d), _ptr(dy), _ptr(wt), _ptr(addend), _ptr(addend_mask), _ptr(pdy), pk, pst,

@@ -52,7 +52,7 @@ if ROOT not in sys.path:
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PMC_FILE = 'round4_c_pmc_traffic.json'        # dominant layer, tools/conv_bench.py in isolation (round 4, tools/profile_round.sh dominant)
-CLASS_TRAFFIC_FILE = 'round4_c_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
+CLASS_TRAFFIC_FILE = 'round5_a_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
 HBM_PEAK_GBS = 8000.0            # spec; MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {
@@ -230,11 +230,12 @@ def _flush_c_stdio():
     pass
 
 
-def _dp_plan(gs, world):
+def _dp_plan(gs, world, backend='RCCL (torch.distributed nccl)'):
   nb = sum(len(seg) for seg in gs.segments)
   width = 2 if gs.comm_dtype == 'bf16' else 4
   return {'world': world, 'buckets': nb, 'bucket_bytes_max': max((hi - lo) for seg in gs.segments for lo, hi in seg) * width,
-          'bytes_per_step': gs.arena.total_elems * width, 'comm_dtype': gs.comm_dtype, 'backend': 'RCCL (torch.distributed nccl)',
+          'bytes_per_step': gs.arena.total_elems * width, 'comm_dtype': gs.comm_dtype, 'backend': backend,
+          'ring_bytes_per_gpu_per_step': int(2 * (world - 1) / max(world, 1) * gs.arena.total_elems * width),
           'overlap': 'buckets are launched as the backward watermark passes them; the optimiser waits for the last one'}
 
 
@@ -425,7 +426,7 @@ def main():
   dp_info = None
   if world > 1:
     tr.grad_sync = dp.GradSync(tr.model.arena, comm_dtype=args.comm_dtype)
-    dp_info = _dp_plan(tr.grad_sync, world)
+    dp_info = _dp_plan(tr.grad_sync, world, 'gloo (REHEARSAL on one GPU)' if args.rehearsal_one_gpu else ('gloo (dry run)' if dry else 'RCCL (torch.distributed nccl)'))
   g = torch.Generator(device=dev).manual_seed(1 + rank)
   images, labels, nin = make_inputs(hp, g)
   lam1 = tr.sample_mixup_lambdas(nin // 2) if hp.mixup_type else None

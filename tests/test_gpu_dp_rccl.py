@@ -227,3 +227,35 @@ def test_two_ranks_replay_the_recorded_step_with_the_same_exchange(hip_lib, tmp_
       assert bool(torch.isfinite(p).all()) and torch.equal(p, q), 'replayed run differs from the eager run'
   assert torch.equal(r0['eager'][0], r1['eager'][0]) and torch.equal(r0['eager'][1], r1['eager'][1]), 'ranks drifted apart'
   assert not torch.equal(r0['eager'][2], r1['eager'][2]), 'moving statistics are per replica: the shards differ'
+
+
+@pytest.mark.timeout(1200)
+def test_bench_n2_rehearsal_on_one_gpu(hip_lib):
+  """bench.py's REAL N > 1 code path on hardware: two ranks launched the way the driver launches
+  them, sharing the one GPU this box has (--rehearsal-one-gpu: cuda:0 for both, gloo between them) -- shards, the bucket
+  plan, the recorded step cut at the bucket launches, barriers, the MAX-reduce of the elapsed time, one JSON line from
+  rank 0.  The value it prints is not a scaling number and says so."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  port = _free_port()
+  procs = []
+  for rank in range(2):
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(port), OMP_NUM_THREADS='4')
+    procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '4',
+                                   '--batch', '32', '--rehearsal-one-gpu', '--no-roofline', '--no-cpu-baseline'], env=env, cwd=root,
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+  outs = [p.communicate(timeout=1100) for p in procs]
+  for p, (so, se) in zip(procs, outs):
+    assert p.returncode == 0, se[-3000:]
+  lines0 = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+  lines1 = [l for l in outs[1][0].splitlines() if l.startswith('{')]
+  assert len(lines0) == 1 and not lines1, 'rank 0 prints exactly one JSON line, the other ranks none'
+  r = json.loads(lines0[0])
+  assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['config']['global_batch'] == 64 and r['config']['parallelism'] == 'dp2'
+  assert r['value'] > 0 and 'REHEARSAL' in r['data']
+  dp = r['dp']
+  assert dp['world'] == 2 and dp['comm_dtype'] == 'fp32' and dp['buckets'] >= 5 and dp['bucket_bytes_max'] <= 32 << 20
+  assert 'segments' in r['step_mode'] and 'launch tape' in r['step_mode'], r['step_mode']

@@ -157,8 +157,15 @@ BLOCKS = [
     ('stage 4: 14x14x1024 -> 7x7x2048, stride 2 (projection + blur-pool + identity)', 14, 1024, 512, 2, 2),
     ('stage 3 tail: 14x14x1024 -> 14x14x1024 (projection at stride 1 + identity)', 14, 1024, 256, 2, 1),
 ]
-# measured on MI355X (batch 256, this file): see the bounds below; a failure prints every measured value
-BLOCK_TOL = {'forward': 1e-2, 'dx': 1e-2, 'default': 6e-3}
+# What "nothing forced" can and cannot show.  Through ONE conv -> BN -> ReLU group (above) the product's own ReLU decisions
+# differ from the oracle's on ~1e-5 of the elements.  Through a whole block the forward pass drifts by ~1e-2 (rel-L2: 5 - 7 bf16
+# tensors in a row, the SK softmax, the blur-pool), activations within that distance of zero take the other ReLU branch, and a
+# fraction p of flipped decisions moves every masked gradient behind them by ~sqrt(p): two bf16
+# implementations of the same block that agree to 1e-2 in the forward pass agree to ~1e-1 in the gradients -- and so does the
+# oracle with ITSELF: its bf16-emulating graph against its fp32 graph, measured here on the same inputs, is the noise floor the
+# product is held against (x 1.5 + 1e-2), per tensor, next to a direction check (cosine >= 0.98).  The teacher-forced
+# harness (tests/model_parity.py) is what checks the arithmetic of every layer at 6e-3 with the decisions pinned.
+FLOOR_FACTOR, FLOOR_ABS, MIN_COS, FWD_TOL = 1.5, 1e-2, 0.98, 1.5e-2
 
 
 @pytest.mark.parametrize('blk', BLOCKS, ids=lambda b: b[0].split(':')[0].replace(' ', '_'))
@@ -175,26 +182,31 @@ def test_sk_blocks_forward_and_backward_at_batch_256(hip_lib, blk):
   x = torch.randn((N, H, H, cin), generator=g).abs_().to(BF)      # a block input is a ReLU output
   dy = (torch.randn((N, Ho, Ho, cout), generator=g) / (N * Ho * Ho) ** 0.5).to(BF)
 
-  vs = O.VarStore(seed=7)
-  oc = O.Ctx(vs, emulate_bf16=True)
-  xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-  rng = torch.Generator().manual_seed(99)
+  def oracle_run(emulate, values=None):
+    vs = O.VarStore(seed=7)
+    oc = O.Ctx(vs, emulate_bf16=emulate)
+    xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
 
-  def oracle_graph():
-    vs.begin_call()
-    return O.block_layer(oc, xr, filters, True, O._bottleneck_block_v1, nb, stride, True, 'blk', zero_gamma=False,
-                         use_resnet_d=True, use_sk_block=True, anti_alias_filter_size=3, anti_alias_type='sconv')
-  with torch.no_grad():
-    oracle_graph()            # creates the variables
-  for nme, t in vs.trainable.items():      # gamma / beta away from (1, 0): a wrong coefficient must show
-    if nme.endswith('gamma'):
-      t.data.copy_(torch.rand(t.shape, generator=rng) * 0.5 + 0.5)
-    elif nme.endswith('beta'):
-      t.data.copy_(torch.randn(t.shape, generator=rng) * 0.1)
-  zr = oracle_graph()
-  leaves = [xr] + list(vs.trainable.values())
-  grads = torch.autograd.grad(zr, leaves, dy.float().permute(0, 3, 1, 2))
-  og = dict(zip(['x'] + list(vs.trainable.keys()), grads))
+    def graph():
+      vs.begin_call()
+      return O.block_layer(oc, xr, filters, True, O._bottleneck_block_v1, nb, stride, True, 'blk', zero_gamma=False,
+                           use_resnet_d=True, use_sk_block=True, anti_alias_filter_size=3, anti_alias_type='sconv')
+    with torch.no_grad():
+      graph()            # creates the variables
+    rng = torch.Generator().manual_seed(99)
+    for nme, t in vs.trainable.items():      # gamma / beta away from (1, 0): a wrong coefficient must show
+      if values is not None:
+        t.data.copy_(values[nme])
+      elif nme.endswith('gamma'):
+        t.data.copy_(torch.rand(t.shape, generator=rng) * 0.5 + 0.5)
+      elif nme.endswith('beta'):
+        t.data.copy_(torch.randn(t.shape, generator=rng) * 0.1)
+    z = graph()
+    grads = torch.autograd.grad(z, [xr] + list(vs.trainable.values()), dy.float().permute(0, 3, 1, 2))
+    return vs, z.detach(), dict(zip(['x'] + list(vs.trainable.keys()), grads))
+
+  vs, zr, og = oracle_run(True)
+  _, z32, og32 = oracle_run(False, {n_: t.detach().clone() for n_, t in vs.trainable.items()})
 
   hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True)
   m = hp.make_model(seed=0, device='cuda')
@@ -221,19 +233,24 @@ def test_sk_blocks_forward_and_backward_at_batch_256(hip_lib, blk):
 
   rows, errs = [], []
 
-  def check(what, got, ref, tol):
-    r = _rel(got, ref)
-    rows.append('%-60s %.3e (<= %.1e)' % (what, r, tol))
-    if not r <= tol:
+  def cos(a, b):
+    a, b = a.float().cpu().reshape(-1), b.float().cpu().reshape(-1)
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+
+  fwd = _rel(z, zr.permute(0, 2, 3, 1))
+  fwd_floor = _rel(zr, z32)
+  rows.append('%-58s %.3e   (oracle bf16 vs fp32: %.3e)' % ('forward', fwd, fwd_floor))
+  if not fwd <= FWD_TOL:
+    errs.append(rows[-1])
+
+  def check(what, got, ref, ref32):
+    r, floor, c = _rel(got, ref), _rel(ref, ref32), cos(got, ref)
+    rows.append('%-58s %.3e   floor %.3e   cos %.4f' % (what, r, floor, c))
+    if not (r <= FLOOR_FACTOR * floor + FLOOR_ABS and c >= MIN_COS):
       errs.append(rows[-1])
 
-  check('forward', z, zr.detach().permute(0, 2, 3, 1), BLOCK_TOL['forward'])
-  check('dx', xv.grad, og['x'].permute(0, 2, 3, 1), BLOCK_TOL['dx'])
+  check('dx', xv.grad, og['x'].permute(0, 2, 3, 1), og32['x'].permute(0, 2, 3, 1))
   for nme, t in vs.trainable.items():
-    tol = BLOCK_TOL['default']
-    for key, v in BLOCK_TOL.items():
-      if key not in ('forward', 'dx', 'default') and key in nme:
-        tol = v
-    check(nme, util.product_to_oracle_grad(nme, m.arena.g(nme).cpu(), t), og[nme], tol)
+    check(nme, util.product_to_oracle_grad(nme, m.arena.g(nme).cpu(), t), og[nme], og32[nme])
   print('\n'.join(rows))
-  assert not errs, '%s:\n  %s\nall:\n  %s' % (name, '\n  '.join(errs), '\n  '.join(rows))
+  assert not errs, '%s: %d of %d outside the bounds:\n  %s' % (name, len(errs), len(rows), '\n  '.join(errs[:12]))

@@ -391,7 +391,7 @@ def test_recorded_step_with_kd_and_mixup_type_2(hip_lib):
     runs.append((losses, a.w32.clone(), a.state.clone()))
     if recorded is None:
       assert tr.step_mode == 'recorded'
-      assert ops.tape_info(tr._tape)['fills'] == 4      # the four row moves of the type-2 teacher mix
+      assert ops.tape_info(tr._tape)['fills'] >= 4      # the four row moves of the type-2 teacher mix (+ the fills of the stride-2 1x1 input gradients)
     tr.release_graph()
   assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
   for p, q in zip(runs[0][1:], runs[1][1:]):

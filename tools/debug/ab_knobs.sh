@@ -5,7 +5,7 @@ out=gpurun_out/ab_knobs.log
 : > $out
 run() { # label, env...
   lab=$1; shift
-  r=$(env "$@" python bench.py --steps ${STEPS:-40} --warmup ${WARM:-8} --no-cpu-baseline --no-roofline --no-gradsync $BENCH_ARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('streams_autotune',{}).get('side_streams_ms'), d.get('streams_autotune',{}).get('single_stream_ms'), d.get('streams_autotune',{}).get('chosen'), 'gpu', d.get('step_detail',{}).get('gpu_ms_between_step_ends'), 'host', d.get('step_detail',{}).get('host_enqueue_ms'), d.get('step_detail',{}).get('host'))")
+  r=$(env "$@" python bench.py --steps ${STEPS:-40} --warmup ${WARM:-8} --no-cpu-baseline --no-roofline --no-gradsync --no-recipe $BENCH_ARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('streams_autotune',{}).get('side_streams_ms'), d.get('streams_autotune',{}).get('single_stream_ms'), d.get('streams_autotune',{}).get('chosen'), 'gpu', d.get('step_detail',{}).get('gpu_ms_between_step_ends'), 'host', d.get('step_detail',{}).get('host_enqueue_ms'), d.get('step_detail',{}).get('host'))")
   echo "$lab $r" >> $out
 }
 for i in 1 2; do

@@ -11,7 +11,7 @@ REPO=$(pwd)
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 # --single-stream: a kernel's duration (and its counters) are then properties of the kernel, not of what ran beside it
-BENCH="python $REPO/bench.py --single-stream --no-cpu-baseline --no-roofline --no-gradsync"
+BENCH="python $REPO/bench.py --single-stream --no-cpu-baseline --no-roofline --no-gradsync --no-recipe"
 for w in $WHAT; do
   case $w in
     stats)
@@ -20,7 +20,7 @@ for w in $WHAT; do
       python $REPO/tools/rocpd_summary.py $DB $REPO/gpurun_out/${TAG}_kernel_stats.md "$TAG: bench.py --steps 5 --warmup 3 (8 steps profiled)"
       ;;
     stats_default)   # the DEFAULT command (recorded step replayed from the launch tape, side streams): the same kernels, counted
-      rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/profd_$TAG -o r -- python $REPO/bench.py --no-cpu-baseline --no-roofline --no-gradsync --steps 5 --warmup 3 > $REPO/gpurun_out/profd_$TAG.log 2>&1
+      rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/profd_$TAG -o r -- python $REPO/bench.py --no-cpu-baseline --no-roofline --no-gradsync --no-recipe --steps 5 --warmup 3 > $REPO/gpurun_out/profd_$TAG.log 2>&1
       DB=$(find $REPO/gpurun_out/profd_$TAG -name '*results.db' | head -1)
       python $REPO/tools/rocpd_summary.py $DB $REPO/gpurun_out/${TAG}_kernel_stats_default.md "$TAG: bench.py --steps 5 --warmup 3, DEFAULT mode = 3 eager warm-up steps + 1 + 5 replays of the recorded step + 1 + 5 eager steps (eager_step leg): 15 executed steps; kernels share the CUs across 4 streams, so durations are not the kernels' own"
       ;;
