@@ -531,9 +531,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
 // best gather-form tile of each layer; with the filter DMA as the only per-step traffic the loop runs within 4 % of its
 // own MFMA + LDS-read time.  80 KB of LDS: two workgroups per CU, so one's epilogue runs under the other's main loop.
 // Requires Ci % 64 == 0, at least two chunks (a single chunk has nothing to prefetch under), W <= 30, dense NHWC input.
-constexpr int H3_ROWS = 192;   // halo rows per buffer (128 + 2 W + 2 <= 191: the last row is never written -> stays zero)
+// halo rows per buffer: 128 + 2 W + 2 <= H3_ROWS - 1 (rows past the live ones are zero-filled by the DMA: the last one is the
+// all-zero row an out-of-image tap reads); 192 for W <= 30, 256 for the single-chunk form up to W = 62
 
-template <int BN, bool STATS, bool PFA>
+// HR / NHB (round 5): halo rows per buffer and number of halo buffers.  A layer with ONE 64-channel chunk (Ci = 64: the SK
+// convolutions of the 56 x 56 and 28 x 28 stages) has no next chunk to stage under the current one, so one buffer does, and
+// with it 256 rows (W <= 62) fit 64 KB together with the two filter stages: two workgroups per CU like igemm2's tile, 178 +
+// 9 x 128 instead of 9 x 256 staged rows per workgroup.
+template <int BN, bool STATS, bool PFA, int H3_ROWS = 192, int NHB = 2>
 __global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
   constexpr int BM = 128, BK = 64, WGM = 2, WGN = 2;
   using C = Cfg<BM, BN, BK, WGM, WGN, false, STATS, 2>;
@@ -543,10 +548,10 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
   constexpr int HALO = H3_ROWS * ROWB, WST = BN * ROWB;
   constexpr int KK = BK / 16, NTAP = 9;
   constexpr unsigned ZERO_ROW = (unsigned)(H3_ROWS - 1) * ROWB;
-  static_assert(RPP == 32 && H3_ROWS % RPP == 0 && HP <= NTAP - 1, "halo pieces are issued one per tap");
+  static_assert(RPP == 32 && H3_ROWS % RPP == 0 && (NHB == 1 || HP <= NTAP - 1), "halo pieces are issued one per tap");
   typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // halo[2] | filter ring[2]; reused by the epilogue
-  unsigned char* const wring = smem + 2 * HALO;
+  unsigned char* const wring = smem + NHB * HALO;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -687,7 +692,9 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
         mma((KK - 1) & 1);
         const bool more = (t + 1 < NTAP) || has_next;
         const int tn = (t + 1 < NTAP) ? t + 1 : 0;           // compile time after unrolling
-        if (has_next && t < HP) issue_halo(hb ^ 1, kcb + BK * 2, t);
+        if constexpr (NHB == 2) {
+          if (has_next && t < HP) issue_halo(hb ^ 1, kcb + BK * 2, t);
+        }
         if (more) issue_w(cur ^ 1, (t + 1 < NTAP ? kcb : kcb + BK * 2) + tap_off(tn), 0, WP);
 #pragma unroll
         for (int kk = 0; kk + 1 < KK; ++kk) {
@@ -697,7 +704,7 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
         cur ^= 1;
       }
       kcb += BK * 2;
-      hb ^= 1;
+      if constexpr (NHB == 2) hb ^= 1;
     }
     mma((KK - 1) & 1);
   }
@@ -705,12 +712,12 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
   igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, false, STATS, PFA, false>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
-template <int BN, bool STATS, bool PFA>
+template <int BN, bool STATS, bool PFA, int HR = 192, int NHB = 2>
 int launch3_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg<128, BN, 64, 2, 2, false, STATS, 2>;
-  constexpr int LDS = cmax(cmax(2 * H3_ROWS * 128 + 2 * BN * 128, C::EPI), C::RED);
+  constexpr int LDS = cmax(cmax(NHB * HR * 128 + 2 * BN * 128, C::EPI), C::RED);
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
-  auto kern = igemm3_kernel<BN, STATS, PFA>;
+  auto kern = igemm3_kernel<BN, STATS, PFA, HR, NHB>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm3_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
@@ -724,7 +731,9 @@ int try_igemm3(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.pool_dy) return 1;
   if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return 1;
   if (a.wt0 != 0 || a.wtr != 3 || a.wts != 1) return 1;
-  if (a.Ci % 64 || a.Ci < 128 || a.Co <= 64 || a.Wi > (H3_ROWS - 1 - 128 - 2) / 2) return 1;
+  const bool one_chunk = a.Ci == 64;      // asm_tuning.igemm3 >= 2: also the single-chunk layers (one halo buffer)
+  if (one_chunk && asm_tune().igemm3 == 1) return 1;
+  if (a.Ci % 64 || a.Co <= 64 || a.Wi > ((one_chunk ? 256 : 192) - 1 - 128 - 2) / 2) return 1;
   if (a.HoWo != a.Hi * a.Wi || a.Wo != a.Wi || a.M % a.HoWo) return 1;
   if (a.x_pix_pitch != a.Ci || a.x_row_pitch != a.Wi * a.Ci || a.x_img_pitch != a.Hi * a.Wi * a.Ci) return 1;
   a.n_tiles_n = cdiv(a.Co, 128);
@@ -733,6 +742,16 @@ int try_igemm3(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
   const int pfa_env = asm_tune().igemm_pfa;
   const bool pfa = a.addend != nullptr && (pfa_env >= 0 ? pfa_env != 0 : a.n_blocks <= 1024);
+  if (one_chunk) {
+    if (a.Wi <= 30) {
+      if (stats) return launch3_one<128, true, false, 192, 1>(a, st);
+      if (pfa) return launch3_one<128, false, true, 192, 1>(a, st);
+      return launch3_one<128, false, false, 192, 1>(a, st);
+    }
+    if (stats) return launch3_one<128, true, false, 256, 1>(a, st);
+    if (pfa) return launch3_one<128, false, true, 256, 1>(a, st);
+    return launch3_one<128, false, false, 256, 1>(a, st);
+  }
   if (stats) return launch3_one<128, true, false>(a, st);
   if (pfa) return launch3_one<128, false, true>(a, st);
   return launch3_one<128, false, false>(a, st);

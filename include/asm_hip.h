@@ -96,7 +96,8 @@ typedef struct asm_tuning {
                               1x1: all at the head of the step); 1: always spread; 2: never                              */
   int32_t igemm3;          /* 3x3 stride-1 layers with >= 128 input channels on maps up to 30 wide with the activation rows
                               resident across the nine taps (igemm3_kernel): 1: where it measured faster than igemm2's
-                              tile for the layer; 2: wherever the shape allows; 0: never                                */
+                              tile for the layer; 2: wherever the shape allows; 0: never; 3: as 1, plus the layers with ONE
+                              64-channel chunk (Ci = 64, maps up to 62 wide) with a single row buffer               */
   int32_t bn_slices;       /* channel slices of the batch-norm reducers (fewer partial rows per channel for the finalize
                               kernels): 0: C / 64 capped at 8; n: capped at n (1: every workgroup covers all channels)   */
   int32_t bn_order;        /* rows of a batch-norm reducer workgroup: 0 tiles interleaved over the workgroups, 1 one contiguous block, 2 that, back to front */
