@@ -222,10 +222,17 @@ int launch1_cfg(IGemmArgs& a, bool stats, hipStream_t st) {
   return launch1_one<BM, BN, BK, WGM, WGN, false, NS, false, false>(a, st);
 }
 
-// Per-layer choice (asm_tuning.gemm1 = -1): the same-box sweep of every 1x1 shape of Assemble-ResNet-50 at batch 256
-// (tools/gemm1_sweep.py, profiles/round5_gemm1_sweep.md; warm + cold HIP-event time, bit-identical outputs) -- a layer is
-// listed where a configuration beat igemm2_kernel's choice by >= 4 %; everything else (other batch sizes, other networks)
-// stays with igemm2.  kind: 0 forward with fused statistics, 1 input gradient, 2 input gradient with a fan-in addend.
+// Per-layer choice (asm_tuning.gemm1 = -1) for the 1x1 stride-1 layers of Assemble-ResNet-50 at batch 256 -- 65 of its 69
+// (layer, kind) pairs; everything else (other batch sizes, other networks) stays with igemm2.  Built in three steps, every
+// candidate bit-identical to igemm2:
+//   1. the same-box stand-alone sweep (tools/gemm1_sweep.py, profiles/round5_gemm1_sweep.md; warm + cold HIP-event time):
+//      rows where a configuration beat igemm2's choice by >= 4 %   -> whole step 25.25 -> 24.2 - 24.4 ms
+//   2. + rows where the best other configuration TIED igemm2 stand-alone (within 3 %): beside the weight-gradient streams
+//      the smaller footprint wins them                            -> -0.15 .. -0.25 ms
+//   3. 24 rows re-picked from IN-SITU times (tools/insitu_sweep.py: every configuration forced in turn on all 1x1 layers of
+//      an eager side-stream step, HIP events around every launch; a row changed where another configuration was >= 5 %
+//      faster in place)                                            -> the same step time, better per-layer numbers
+// kind: 0 forward with fused statistics, 1 input gradient, 2 input gradient with a fan-in addend.
 struct AutoRow {
   int kind, M, Ci, Co, code;
 };

@@ -11,7 +11,7 @@ mean-subtract(+mixup) -> forward -> softmax-CE(+label smoothing) -> backward -> 
 
 The timed region is the product as it ships: the weight gradients run beside the input-gradient chain and the big branch of
 each BigLittle stage beside the little one, on side streams; and the step is RECORDED once after the warm-up
-(Trainer.capture) and replayed from the library's launch tape -- the same ~910 kernel launches on the same streams, issued
+(Trainer.capture -- what a default Trainer does on its own after three eager steps) and replayed from the library's launch tape -- the same ~910 kernel launches on the same streams, issued
 by one C call in 3 - 4 ms of host time instead of ~14.5 ms of Python per step, bit-identical results (tests/test_gpu_model.py,
 tests/test_gpu_dp_rccl.py) -- with the loop on the trainer's stream.  `--eager` times the eager step instead (`step_mode`
 says which ran; if recording fails the bench falls back to eager and says so).  Kernels of different streams share the CUs,
@@ -32,8 +32,11 @@ Extra objects on the line:
   step          the whole step against its per-layer bound sum_l max(flops_l / 2.5 PFLOP/s, bytes_l / 8 TB/s)
                 (every conv as fprop + dgrad + wgrad with un-fused algorithmic bytes, every batch norm
                 as 3 + 5 tensor passes), plus two class figures from HIP events of three instrumented single-stream steps run
-                after the timed region: the 3x3-convolution class against the MFMA peak, the batch-norm family against
-                the HBM peak.
+                after the timed region: the 3x3-convolution class against the MFMA peak, the 1x1-convolution class against
+                its per-layer max(MFMA, HBM) bound (`conv1x1_class`, `roofline.conv1x1`), the batch-norm family against the HBM peak.
+  recipe        N = 1: the published recipe (scripts/train_assemble_from_scratch.sh: mixup type 1 + label smoothing + KD +
+                DropBlock with its keep_prob schedule, no resnet_d) at the same shard size on a DEFAULT Trainer, i.e. recorded
+                by the trainer itself after three eager steps (DropBlock draws and gamma in static buffers); not the headline.
   cpu_baseline  the CPU oracle (a restatement of the reference's TF graph; TF 1.14 itself cannot run
                 here) timed on this host's cores, BASELINE.md section 2: value = training step of the same network
                 at batch 32 (median of 3), c1 = config-1 ResNet-50 64-image eval forward (median of 5).
