@@ -254,6 +254,23 @@ constexpr AutoRow kAuto[] = {
     {2, 200704,   64,  256, 13}, {2, 200704,  128,  256, 12}, {2, 200704,  128,  512, 14}, {2,  50176,  128,  512, 12},
     {2,  50176,  256,  512, 12}, {2,  50176,  256, 1024, 13}, {2,  50176,  512, 1024, 14}, {2,  12544,  256, 1024, 14},
     {2,  12544,  512, 2048, 14},
+    // shapes of the other BASELINE configurations that Assemble-ResNet-50 + D does not have: ResNet-50 v1.5 at batch 256 (config 2:
+    // stand-alone wins >= 4 % and ties within 3 %) and Assemble-ResNet-152 at batch 128 (config 5 shard: wins >= 4 % only -- its ties
+    // LOST in the step); profiles/round5_gemm1_sweep_r50.md, _r152.md
+    {0, 802816,   64,  256, 10}, {1, 802816,  256,   64, 11}, {0, 802816,  256,  128, 14}, {1, 802816,  128,  256, 14},
+    {2, 802816,  128,  256, 14}, {0, 200704,  128,  512, 10}, {1, 200704,  512,  128,  5}, {0, 200704,  512,  256,  5},
+    {1, 200704,  256,  512, 10}, {2, 200704,  256,  512, 14}, {0, 401408,   64,   64, 12}, {1, 100352,  256,   64, 12},
+    {0, 100352,  256,   64, 12}, {1, 100352,   64,  256,  5}, {2, 100352,   64,  256, 13}, {0, 401408,   64,  256, 10},
+    {0, 401408,  256,  256,  5}, {1, 401408,  256,  256, 14}, {0, 100352,  256,  256, 10}, {1, 100352,  256,  256, 10},
+    {0, 401408,  256,   64, 12}, {1, 401408,   64,  256,  5}, {2, 401408,   64,  256, 14}, {0,  25088,  256,  512, 16},
+    {1,  25088,  512,  256,  8}, {0, 100352,  256,  128, 14}, {1, 100352,  128,  256, 12}, {2, 100352,  128,  256, 12},
+    {0,  25088,  128,  512, 10}, {1,  25088,  512,  128, 11}, {0,  25088,  512,  128,  5}, {1,  25088,  128,  512, 14},
+    {2,  25088,  128,  512, 12}, {0, 100352,  256,  512, 10}, {0, 100352,  128,  512, 10}, {1, 100352,  512,  128, 14},
+    {1, 100352,  128,  512, 10}, {2, 100352,  128,  512, 12}, {0, 100352,  512,  512, 14}, {1, 100352,  512,  512, 14},
+    {1,   6272, 1024,  512,  5}, {0,  25088,  512,  256,  8}, {1,  25088,  256,  512, 14}, {2,  25088,  256,  512, 14},
+    {1,   6272, 1024,  256, 12}, {0,   6272, 1024,  256, 11}, {1,   6272,  256, 1024,  8}, {0,  25088,  256, 1024, 10},
+    {1,  25088, 1024,  256,  8}, {0,  25088, 1024,  256,  8}, {1,  25088,  256, 1024, 10}, {2,  25088,  256, 1024, 10},
+    {1,   6272, 2048, 1024,  8}, {1,   6272, 2048,  512,  5}, {0,   6272, 2048,  512,  5},
 };
 
 int auto_cfg(const IGemmArgs& a, bool stats) {

@@ -171,7 +171,8 @@ extern "C" int asm_tape_begin(void) {
   g_tapes.emplace_back(new Tape());
   t_rec = g_tapes.back().get();
   t_rec->seg.push_back(0);
-  (void)hipGetDevice(&t_rec->device);
+  if (hipGetDevice(&t_rec->device) != hipSuccess) t_rec->device = -1;
+  (void)hipGetLastError();
   asm_tape_on = true;
   return (int)g_tapes.size();
 }
@@ -215,9 +216,11 @@ extern "C" int asm_tape_replay(int tape, int segment) {
   if (t == t_rec) ASM_FAIL(ASM_EINVAL, "tape_replay: the tape is being recorded");
   const int nseg = (int)t->seg.size() - 1;
   if (segment >= nseg) ASM_FAIL(ASM_EINVAL, "tape_replay: segment %d of %d", segment, nseg);
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev != t->device)
-    ASM_FAIL(ASM_EINVAL, "tape_replay: tape %d was recorded on device %d, the current device is %d", tape, t->device, dev);
+  if (t->device >= 0) {       // (no device while it was recorded: an empty host-only tape)
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != t->device)
+      ASM_FAIL(ASM_EINVAL, "tape_replay: tape %d was recorded on device %d, the current device is %d", tape, t->device, dev);
+  }
   const size_t i0 = segment < 0 ? 0 : t->seg[segment], i1 = segment < 0 ? t->nodes.size() : t->seg[segment + 1];
   (void)hipGetLastError();
   for (size_t i = i0; i < i1; ++i) {

@@ -106,6 +106,7 @@ SIGNATURES = {
     'asm_launch_count': (C.c_ulonglong, []),
     'asm_stream_join': (_I, [_P, _P]),
     'asm_memcpy_async': (_I, [_P, _P, _Z, _P]),
+    'asm_allreduce_bucket': (_I, [_P, _Z, _I, _P, _P, _P]),
     'asm_tape_begin': (_I, []),
     'asm_tape_mark': (_I, []),
     'asm_tape_end': (_I, []),

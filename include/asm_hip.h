@@ -65,6 +65,15 @@ int asm_stream_join(void* dst_stream, void* src_stream);
 /* device-to-device copy on `stream`, seen by a tape that is being recorded (a fill node): row slices / concatenations of
  * the input side of a step (the KD label split, run_loop_classification.py:90-96) without a framework kernel in between */
 int asm_memcpy_async(void* dst, const void* src, size_t bytes, void* stream);
+
+/* Gradient exchange of one bucket for a caller that owns its RCCL communicator -- MirroredStrategy's all-reduce
+ * (official/utils/misc/distribution_utils.py:24-45): in-place SUM over `count` elements (dtype: ASM_F32 or ASM_BF16) of the flat
+ * gradient arena, issued on comm_stream (not the null stream) behind everything producer_stream has enqueued so far (the
+ * backward kernels that wrote the bucket).  nccl_comm is the caller's ncclComm_t; librccl.so is resolved on first use.  The
+ * caller joins comm_stream back into its consumer stream (asm_stream_join) before asm_sgd_momentum, whose grad_scale carries
+ * the 1 / replicas.  The Python host of this repository hands the same buckets to torch.distributed instead
+ * (dp.GradSync). */
+int asm_allreduce_bucket(void* buf, size_t count, int dtype, void* nccl_comm, void* comm_stream, void* producer_stream);
 int asm_tape_begin(void);
 int asm_tape_mark(void);
 int asm_tape_end(void);

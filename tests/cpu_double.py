@@ -937,6 +937,10 @@ class CpuDouble(object):
   def asm_dropblock_mask_dev(self, uniform, gamma_dev, H, W, Cn, bs, keep, scale, stream):
     return self.asm_dropblock_mask(uniform, float(T(gamma_dev, (1,), 'f32')[0]), H, W, Cn, bs, keep, scale, stream)
 
+  def asm_allreduce_bucket(self, buf, count, dtype, comm, comm_stream, producer_stream):
+    self._err = b'allreduce_bucket: the CPU test double has no RCCL'
+    return -2
+
   def asm_memcpy_async(self, dst, src, nbytes, stream):
     T(dst, (nbytes,), 'u8').copy_(T(src, (nbytes,), 'u8'))
     return 0

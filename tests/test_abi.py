@@ -101,3 +101,16 @@ def test_launch_tape_bookkeeping_needs_no_gpu():
   assert L.asm_tape_end() < 0
   t4 = L.asm_tape_begin()
   assert t4 > 0 and L.asm_tape_end() == t4 and L.asm_tape_free(t4) == 0
+
+
+def test_allreduce_bucket_argument_checks_need_no_gpu():
+  """asm_allreduce_bucket (the gradient exchange for a C caller with its own ncclComm_t): the argument checks come before
+  librccl is even resolved."""
+  from assembled_cnn_amd import lib
+  L = lib.load()
+  fake = ctypes.c_void_p(0x1000)
+  assert L.asm_allreduce_bucket(None, 16, lib.ASM_F32, fake, fake, fake) == lib.ASM_EINVAL
+  assert L.asm_allreduce_bucket(fake, 16, lib.ASM_F32, None, fake, fake) == lib.ASM_EINVAL
+  assert L.asm_allreduce_bucket(fake, 16, lib.ASM_F32, fake, None, fake) == lib.ASM_EINVAL and b'null stream' in L.asm_last_error()
+  assert L.asm_allreduce_bucket(fake, 16, lib.ASM_F16, fake, fake, fake) == lib.ASM_ENOTSUP
+  assert L.asm_allreduce_bucket(fake, 0, lib.ASM_BF16, fake, fake, fake) == lib.ASM_OK      # an empty bucket is nothing to do

@@ -259,3 +259,45 @@ def test_bench_n2_rehearsal_on_one_gpu(hip_lib):
   dp = r['dp']
   assert dp['world'] == 2 and dp['comm_dtype'] == 'fp32' and dp['buckets'] >= 5 and dp['bucket_bytes_max'] <= 32 << 20
   assert 'segments' in r['step_mode'] and 'launch tape' in r['step_mode'], r['step_mode']
+
+
+def test_allreduce_bucket_on_a_callers_own_rccl_communicator(hip_lib):
+  """asm_allreduce_bucket with an ncclComm_t made through librccl's C API (one rank: the sum over the replicas is the
+  identity) -- what a C caller without PyTorch does.  The exchange is issued on the communicator's stream BEHIND the
+  producer stream's kernels: the bucket is written by a library kernel on the producer stream right before the call, and
+  what comes back must be that kernel's output (fp32 and bf16 buckets), not the bytes that were there before."""
+  import ctypes as C
+  from assembled_cnn_amd import lib, ops
+  try:
+    rccl = C.CDLL('librccl.so.1')
+  except OSError:
+    rccl = C.CDLL('/opt/rocm/lib/librccl.so')
+
+  class UniqueId(C.Structure):
+    _fields_ = [('internal', C.c_char * 128)]
+  uid = UniqueId()
+  assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+  comm = C.c_void_p()
+  rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+  assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+  try:
+    L = ops.L()
+    prod, cs = torch.cuda.Stream(), torch.cuda.Stream()
+    n = 1 << 20
+    src = torch.randn(n, device='cuda')
+    bucket = torch.full((n,), float('nan'), device='cuda')
+    b16 = torch.full((n,), float('nan'), device='cuda', dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(prod):
+      ops.memcpy(bucket, src)                       # the "backward kernel" that writes the bucket, on the producer stream
+      ops.cast_f32_to_bf16(src, b16)
+    for buf, dt in ((bucket, lib.ASM_F32), (b16, lib.ASM_BF16)):
+      rc = L.asm_allreduce_bucket(buf.data_ptr(), n, dt, comm, cs.cuda_stream, prod.cuda_stream)
+      assert rc == 0, L.asm_last_error()
+    ops.stream_join(torch.cuda.current_stream(), cs)
+    torch.cuda.synchronize()
+    assert torch.equal(bucket, src) and torch.equal(b16, src.to(torch.bfloat16))
+    assert L.asm_allreduce_bucket(bucket.data_ptr(), n, lib.ASM_F16, comm, cs.cuda_stream, prod.cuda_stream) == lib.ASM_ENOTSUP
+  finally:
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
