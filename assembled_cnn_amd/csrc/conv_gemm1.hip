@@ -3,14 +3,20 @@
 //   Y[m][n] = sum_c X[row(m)][c] * Wt[n][c]        fprop: Wt = filter KRSC (R = S = 1), dgrad: Wt = the CRSK copy
 //
 // conv1 / conv3 of every bottleneck, the projection shortcuts and the BigLittle transition layers
-// (nets/resnet_model.py:55-60,76-80, nets/model_helper.py:67-78) are this GEMM with M = N*H*W pixel rows.  On the 14 x 14
-// and 7 x 7 maps (M = 50 176 / 12 544 at batch 256, reductions of 256 .. 2048 channels) igemm2_kernel's two LDS stages
-// leave every K step behind an exposed LDS-DMA round trip: the step's tiles are requested ONE step (16 MFMAs per wave,
-// ~0.2 us) ahead, an L2 / HBM fetch takes 0.2 - 0.5 us and longer under load, and with a few hundred workgroups there
-// is no second workgroup on the CU to run meanwhile (SQ counters, profiles/round4_c_sq_counters.md: matrix pipe 9 - 15 %
-// busy, 49 - 65 % of a wave's life parked on s_waitcnt).  Here a step's tiles are requested NS - 1 steps ahead:
-// `s_waitcnt vmcnt(P * (NS - 2))` (P = LDS-DMA pieces per wave and step) waits for the OLDEST step only, a raw
-// s_barrier publishes it, and the requests of the following steps stay in flight across the barrier.
+// (nets/resnet_model.py:55-60,76-80, nets/model_helper.py:67-78) are this GEMM with M = N*H*W pixel rows: 159 launches and
+// as much time per step as the 3x3 class.  The kernel was written on the hypothesis that igemm2_kernel's two LDS stages leave
+// every K step of the 14 x 14 / 7 x 7 layers behind an exposed LDS-DMA round trip (SQ counters, profiles/round4_c_sq_counters.md:
+// matrix pipe 9 - 15 % busy, 49 - 65 % of a wave's life parked on s_waitcnt): a step's tiles are requested NS - 1 steps ahead,
+// `s_waitcnt vmcnt(P * (NS - 2))` (P = LDS-DMA pieces per wave and step) waits for the OLDEST step only, a raw s_barrier
+// publishes it, and the requests of the following steps stay in flight across the barrier.
+//
+// The sweeps refuted the hypothesis and found something else (profiles/round5_gemm1_sweep*.md): with 3 - 4
+// stages of 128 x 128 x 64 tiles (96 - 128 KB of LDS: ONE workgroup per CU) every layer is 20 - 60 % SLOWER than with two stages
+// and two workgroups per CU.  A workgroup of these layers spends its life in prologue (address decode, first round trip),
+// 2 - 32 K steps and epilogue (LDS staging, 8 - 16 store passes, the statistics' barriers); what hides one workgroup's
+// prologue and epilogue is another workgroup's K loop on the same CU.  The configurations that win are the SMALL ones --
+// 24 - 72 KB, three to six workgroups per CU -- and the template below exists to provide them per layer (asm_gemm1_try's
+// table); beside the weight-gradient streams' kernels of the training step they gain 2.5 x what they gain alone.
 // Same tiles, fragment layout, (chunk, k) accumulation order and epilogue as igemm2_kernel: bit-identical results.
 #include "common.h"
 #include "igemm_common.h"
