@@ -289,3 +289,66 @@ def test_kd_input_side_is_library_calls_only(cpu_double, monkeypatch):
       want2 = l2 * hard[:half] + (1 - l2) * torch.flip(p[half:], [0])     # y1, not y1_t: the reference's own quirk
       assert teacher.shape == (B, C)
       assert torch.allclose(teacher[:half], want1, atol=1e-6) and torch.allclose(teacher[half:], want2, atol=1e-6)
+
+
+def test_self_recording_bookkeeping_without_a_gpu(cpu_double, monkeypatch):
+  """Trainer.train_step's own recording (train.Trainer._auto_step) with capture() replaced by a counter: it fires after
+  AUTO_WARMUP eager steps of ONE input signature, starts counting again when the shapes change, is never attempted with a
+  gradient exchange that cannot replay bucket launches, and a failing capture leaves an eager trainer with ONE warning
+  (recorded=True: the exception)."""
+  import warnings
+  from assembled_cnn_amd.train import HParams, Trainer
+  hp = HParams(resnet_version=1, batch_size=2, learning_rate_decay_type='fixed', base_learning_rate=0.01)
+  img2, _, lab2 = MP.inputs(2, 64)
+  img4, _, lab4 = MP.inputs(4, 64)
+
+  class FakeCuda(object):          # _auto_step only asks the tensors whether they live on the device
+    def __init__(self, t):
+      self.t = t
+    is_cuda = True
+
+    def __getattr__(self, k):
+      return getattr(self.t, k)
+
+  # the step itself runs on the CPU double; only the bookkeeping is driven with device-flagged tensors
+  tr = Trainer(hp, seed=0, device='cpu')
+  calls = []
+  monkeypatch.setattr(tr, 'capture', lambda *a, **k: calls.append(tuple(a[0].shape)) or tr)
+  tr._auto = True
+  n = Trainer.AUTO_WARMUP
+  for i in range(n):
+    tr._auto_step(FakeCuda(img2), lab2, None, None)
+  assert calls == [tuple(img2.shape)] and tr._auto_made
+  tr._auto_made = False
+  for i in range(n - 1):
+    tr._auto_step(FakeCuda(img4), lab4, None, None)
+  tr._auto_step(FakeCuda(img2), lab2, None, None)          # the signature changed again: the count starts over
+  assert len(calls) == 1
+  for i in range(n - 1):
+    tr._auto_step(FakeCuda(img2), lab2, None, None)
+  assert len(calls) == 2
+  tr._auto_step(img2, lab2, None, None)                    # host tensors: nothing to record
+  assert len(calls) == 2
+  tr.grad_sync = object()                                  # an exchange without launch_recorded: not attempted
+  tr._auto_n = n
+  tr._auto_step(FakeCuda(img2), lab2, None, None)
+  assert len(calls) == 2
+  tr.grad_sync = None
+
+  def boom(*a, **k):
+    raise RuntimeError('no capture on this box')
+  monkeypatch.setattr(tr, 'capture', boom)
+  tr._auto_n = n
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    tr._auto_step(FakeCuda(img2), lab2, None, None)
+  assert len(w) == 1 and 'staying with the eager step' in str(w[0].message)
+  assert tr._auto is False and tr.step_mode.startswith('eager (recording failed')
+  tr.train_step(img2, lab2)                                # still an ordinary eager trainer
+  strict = Trainer(hp, seed=0, device='cpu', recorded=True)
+  monkeypatch.setattr(strict, 'capture', boom)
+  strict._auto = True
+  for i in range(n - 1):
+    strict._auto_step(FakeCuda(img2), lab2, None, None)
+  with pytest.raises(RuntimeError):
+    strict._auto_step(FakeCuda(img2), lab2, None, None)
