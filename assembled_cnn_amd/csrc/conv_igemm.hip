@@ -1104,7 +1104,11 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
     // (its 8-wave loop reads 0.75 instead of 1 LDS fragment per MFMA and has half the barriers), so those stay.
     // asm_tuning.igemm3 = 2 forces it wherever the shape allows (tests).
     const int h3 = asm_tune().igemm3;
-    if (ftile == 0 && h3 && (h3 == 2 || !bigv || (b256v >= 768 && a.Ci <= 128))) {
+    // h3 == 4 (round 5, in-situ sweep tools/insitu_sweep.py --settings): also the deep layers of the 14 x 14 / 7 x 7 maps that the
+    // 256 x 256 tile carries -- stand-alone that tile wins them by 3 - 15 %, beside the weight-gradient streams two 80 KB
+    // workgroups per CU finish sooner than one 128 KB one (heaviest input gradient 618 -> 472 us in situ)
+    const bool deep_small = h3 == 4 && bigv && a.Wi <= 14 && a.Ci >= 256;
+    if (ftile == 0 && h3 && (h3 == 2 || !bigv || (b256v >= 768 && a.Ci <= 128) || deep_small)) {
       rc = try_igemm3(a, out_f32, stats, st);
       if (rc != 1) return rc;
     }

@@ -327,7 +327,7 @@ extern "C" void asm_tuning_defaults(asm_tuning* t) {
 extern "C" int asm_set_tuning(const asm_tuning* t) {
   if (t && (t->bn_rows <= 0 || t->igemm_mode < 0 || t->igemm_mode > 2 || t->igemm_tile < 0 || t->igemm_tile > 3 ||
             t->wgrad_halo < 0 || t->wgrad_halo > 2 || t->wgrad_splits < 0 || t->igemm_bk64_1x1 < 0 || t->conv_sched < 0 ||
-            t->conv_sched > 2 || t->igemm3 < 0 || t->igemm3 > 3 || t->bn_slices < 0 || t->bn_order < 0 || t->bn_order > 2 || t->wgrad_rows < 0 || t->wgrad_rows > 2 ||
+            t->conv_sched > 2 || t->igemm3 < 0 || t->igemm3 > 4 || t->bn_slices < 0 || t->bn_order < 0 || t->bn_order > 2 || t->wgrad_rows < 0 || t->wgrad_rows > 2 ||
             t->gemm1 < -2 || t->wgrad_ring < -1 || t->igemm_bk32_3x3 < 0 || t->igemm_bk32_3x3 > 2 || t->spare[0] || t->spare[1] ||
             t->spare[2]))
     ASM_FAIL(ASM_EINVAL, "asm_set_tuning: field out of range");

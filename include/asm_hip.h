@@ -106,7 +106,9 @@ typedef struct asm_tuning {
   int32_t igemm3;          /* 3x3 stride-1 layers with >= 128 input channels on maps up to 30 wide with the activation rows
                               resident across the nine taps (igemm3_kernel): 1: where it measured faster than igemm2's
                               tile for the layer; 2: wherever the shape allows; 0: never; 3: as 1, plus the layers with ONE
-                              64-channel chunk (Ci = 64, maps up to 62 wide) with a single row buffer               */
+                              64-channel chunk (Ci = 64, maps up to 62 wide) with a single row buffer (default); 4: as 3,
+                              plus the deep layers of the 14- / 7-wide maps that the 256 x 256 tile carries (faster in
+                              situ per layer, no faster as a step: opt-in)                                          */
   int32_t bn_slices;       /* channel slices of the batch-norm reducers (fewer partial rows per channel for the finalize
                               kernels): 0: C / 64 capped at 8; n: capped at n (1: every workgroup covers all channels)   */
   int32_t bn_order;        /* rows of a batch-norm reducer workgroup: 0 tiles interleaved over the workgroups, 1 one contiguous block, 2 that, back to front */
