@@ -513,6 +513,13 @@ def test_resident_row_weight_gradient_matches_the_general_kernel(hip_lib, shape,
     err = float((outs[knob].double() - ref).abs().max()) / scale
     assert err <= 2e-5, (knob, err)
   assert util.rel_l2(outs['2'].cpu(), outs['0'].cpu()) <= 2e-6
+  # and against the ORACLE: autograd of its conv2d_fixed_padding with respect to the filter
+  from oracle import assembled_oracle as O
+  wr = torch.zeros((3, 3, Cn, K), requires_grad=True)
+  yr = O._conv_raw(x.float().cpu().permute(0, 3, 1, 2), wr, 3, 1)
+  gw, = torch.autograd.grad(yr, [wr], dy.float().cpu().permute(0, 3, 1, 2))
+  for knob in ('2', '0'):
+    assert util.rel_l2(outs[knob].cpu().permute(1, 2, 3, 0), gw) <= 1e-4, knob
 
 
 GEMM1_CODES = (1, 2, 5, 8, 10, 11, 12, 13, 14, 15, 16)
@@ -590,3 +597,9 @@ def test_ring_weight_gradient_is_the_register_staged_one_bit_for_bit(hip_lib, sh
   want = dy.double().reshape(-1, K).t() @ x.double().reshape(-1, Cn)
   got = outs[('0', '2')].double().reshape(K, Cn)
   assert float((got - want).norm() / want.norm()) <= 1e-5
+  # and against the oracle: autograd of its convolution with respect to the filter
+  from oracle import assembled_oracle as O
+  wr = torch.zeros((1, 1, Cn, K), requires_grad=True)
+  yr = O._conv_raw(x.float().cpu().permute(0, 3, 1, 2), wr, 1, 1)
+  gw, = torch.autograd.grad(yr, [wr], dy.float().cpu().permute(0, 3, 1, 2))
+  assert util.rel_l2(outs[('0', '2')].cpu().permute(1, 2, 3, 0), gw) <= 1e-4
