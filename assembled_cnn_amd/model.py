@@ -105,6 +105,9 @@ class Model(object):
     self._ctx: Optional[Ctx] = None
     self._db_rng = None
     self._bl_stream = None
+    # side streams of THIS model: None = as the ASM_WGRAD_STREAM / ASM_BL_STREAMS switches of the process say (default on),
+    # True / False = set for this model only (Trainer.set_streams / calibrate_streams)
+    self.side_streams: Optional[bool] = None
 
   # -----------------------------------------------------------------------------------------------
   def build(self, input_hw=(224, 224), use_resnet_d=False, batch=2):
@@ -121,8 +124,11 @@ class Model(object):
     # dgrad -> BN-backward chain and fill the tail rounds of the 1-workgroup-per-CU convolution tiles: -0.4 .. -0.8 % step
     # time in same-box A/B runs (round 1: 8330 vs 8190 img/s; round 2: 29.59 / 29.71 vs 29.83 / 29.84 ms).
     # ASM_WGRAD_STREAM=0 keeps everything on the compute stream.  dp.GradSync joins these streams before every bucket launch.
-    if ops.knob('ASM_WGRAD_STREAM', '1') != '0':
+    if self._streams_on('ASM_WGRAD_STREAM'):
       self.arena.enable_side_stream()     # no-op on the CPU test double
+
+  def _streams_on(self, knob: str) -> bool:
+    return self.side_streams if self.side_streams is not None else ops.knob(knob, '1') != '0'
 
   def __call__(self, inputs, training, reuse=False, use_resnet_d=False, keep_prob=1.0, return_embedding=False,
                record_tape=None, prepadded=False, dropblock_uniforms=None, db_static=None):
@@ -183,7 +189,7 @@ class Model(object):
   # -----------------------------------------------------------------------------------------------
   def _branch_stream(self, ctx: Ctx, x: Var):
     """the HIP stream the big branch of a BigLittle stage runs on (forward, and blocks 2..n of its backward), or None"""
-    if ctx.dry or x.data is None or not x.data.is_cuda or ops.knob('ASM_BL_STREAMS', '1') == '0':
+    if ctx.dry or x.data is None or not x.data.is_cuda or not self._streams_on('ASM_BL_STREAMS'):
       return None
     if getattr(ctx, 'keep_prob', 1.0) < 1.0 and getattr(ctx, 'db_static', None) is None:
       return None          # DropBlock draws come from one generator in creation order (static buffers are drawn beforehand)

@@ -211,15 +211,13 @@ class Trainer(object):
     """Side streams on (the default: weight gradients on two streams beside the input-gradient chain, the big branch of
     every BigLittle stage beside the little one) or off (every kernel on the compute stream).  Results are bit-identical
     either way (tests/test_gpu_model.py); only the overlap changes.  Switching off parks the stream objects and switching
-    on again reuses them; ``fresh`` creates new ones instead."""
-    import os
+    on again reuses them; ``fresh`` creates new ones instead.  The setting belongs to this trainer's model (the process-wide
+    ASM_WGRAD_STREAM / ASM_BL_STREAMS switches are only the default) and cannot change under a recorded step."""
     if self._graph is not None:
       if not self._auto_made:
         raise RuntimeError('the stream setting is frozen into the captured step: release_graph() first')
       self.release_graph()                 # the trainer's own recording: drop it, the next steps record again
-    os.environ['ASM_WGRAD_STREAM'] = '1' if on else '0'
-    os.environ['ASM_BL_STREAMS'] = '1' if on else '0'
-    ops.refresh_tuning()
+    self.model.side_streams = bool(on)     # this model only: no other Trainer / Model of the process changes
     a = self.model.arena
     if a.finalized:
       if on:
