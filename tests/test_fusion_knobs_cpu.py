@@ -289,6 +289,11 @@ def test_kd_input_side_is_library_calls_only(cpu_double, monkeypatch):
       want2 = l2 * hard[:half] + (1 - l2) * torch.flip(p[half:], [0])     # y1, not y1_t: the reference's own quirk
       assert teacher.shape == (B, C)
       assert torch.allclose(teacher[:half], want1, atol=1e-6) and torch.allclose(teacher[half:], want2, atol=1e-6)
+    # and against the oracle's mixup (pinned to utils/data_util.mixup run from the reference: tests/test_reference_taps.py)
+    from oracle import assembled_oracle as O
+    xo = O.mean_image_subtraction(img.float())
+    _, oy, ot = O.mixup(xo, hard, lam1, keep_batch_size=(mt == 2), y_t=p, lam2=lam2 if mt == 2 else None)
+    assert torch.allclose(onehot, oy, atol=1e-6) and torch.allclose(teacher, ot, atol=1e-6)
 
 
 def test_self_recording_bookkeeping_without_a_gpu(cpu_double, monkeypatch):
