@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB_PATH = os.path.join(HERE, 'libasm_hip.so')
-SOURCES = ['conv_igemm.hip', 'conv_gemm1.hip', 'conv_dgrad_s2.hip', 'conv_wgrad.hip', 'bn.hip', 'pool.hip', 'sk_se.hip', 'sk_fused.hip', 'dense_small.hip', 'misc.hip', 'extra.hip', 'input.hip', 'plan.hip', 'tape.hip', 'collective.hip']
+SOURCES = ['conv_igemm.hip', 'conv_igemm8.hip', 'conv_gemm1.hip', 'conv_dgrad_s2.hip', 'conv_wgrad.hip', 'bn.hip', 'pool.hip', 'sk_se.hip', 'sk_fused.hip', 'dense_small.hip', 'misc.hip', 'extra.hip', 'input.hip', 'plan.hip', 'tape.hip', 'collective.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'igemm_common.h'), os.path.join(HERE, '..', 'include', 'asm_hip.h'),
            os.path.join(HERE, '..', 'include', 'asm_hip_debug.h')]
 ARCH = 'gfx950'

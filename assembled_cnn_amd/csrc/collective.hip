@@ -28,6 +28,8 @@ all_reduce_fn g_all_reduce = nullptr;
 error_string_fn g_error_string = nullptr;
 bool g_tried = false;
 
+char g_dl_error[256] = "";
+
 bool resolve() {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_tried) return g_all_reduce != nullptr;
@@ -37,9 +39,14 @@ bool resolve() {
     h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (h) break;
   }
-  if (!h) return false;
+  if (!h) {
+    const char* e = dlerror();               // (reading it clears it: read once, keep the text)
+    snprintf(g_dl_error, sizeof(g_dl_error), "%s", e ? e : "dlopen failed");
+    return false;
+  }
   g_all_reduce = reinterpret_cast<all_reduce_fn>(dlsym(h, "ncclAllReduce"));
   g_error_string = reinterpret_cast<error_string_fn>(dlsym(h, "ncclGetErrorString"));
+  if (!g_all_reduce) snprintf(g_dl_error, sizeof(g_dl_error), "no ncclAllReduce in librccl");
   return g_all_reduce != nullptr;
 }
 
@@ -51,7 +58,10 @@ extern "C" int asm_allreduce_bucket(void* buf, size_t count, int dtype, void* nc
   ASM_REQUIRE(comm_stream != nullptr, "allreduce_bucket: the exchange needs a stream of its own (not the null stream)");
   if (dtype != ASM_F32 && dtype != ASM_BF16) ASM_FAIL(ASM_ENOTSUP, "allreduce_bucket: dtype %d (float32 or bfloat16 buckets)", dtype);
   if (count == 0) return ASM_OK;
-  if (!resolve()) ASM_FAIL(ASM_ENOTSUP, "allreduce_bucket: librccl.so not found (%s)", dlerror() ? dlerror() : "no ncclAllReduce");
+  // the exchange is issued, not recorded: inside asm_tape_begin .. asm_tape_end the join below would become a JOIN node of a
+  // tape that never holds the all-reduce itself
+  if (asm_tape_on) ASM_FAIL(ASM_EINVAL, "allreduce_bucket: not while a launch tape is being recorded (split the tape at the bucket)");
+  if (!resolve()) ASM_FAIL(ASM_ENOTSUP, "allreduce_bucket: librccl.so not usable (%s)", g_dl_error);
   if (producer_stream != comm_stream) {
     if (int rc = asm_stream_join(comm_stream, producer_stream)) return rc;   // the bucket's gradients are final before the exchange reads them
   }

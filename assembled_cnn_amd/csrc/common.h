@@ -34,6 +34,10 @@ inline thread_local int asm_unchecked_launches = 0;
 // argument checks at the top of an entry point are where that stale state is dropped -- but ONLY while this thread has no
 // launch of its own waiting for its ASM_CHECK_LAUNCH (asm_unchecked_launches, counted by ASM_LAUNCH): an ASM_REQUIRE that
 // a later edit places after a launch can therefore never swallow that launch's error.
+// which convolution kernel family the last forward / input-gradient call of this thread launched (tests assert the plan a
+// shape gets: asm_debug_last_conv_kernel, include/asm_hip_debug.h): 0 igemm_kernel, 1 igemm1 (conv_gemm1), 2 igemm2, 3 igemm3,
+// 4 conv_halo, 5 dgrad_s2, 8 igemm8
+inline thread_local int asm_last_conv_kernel = -1;
 void asm_count_launch();             // plan.hip: process-wide kernel-launch counter (asm_launch_count)
 // tape.hip: while THIS host thread records a launch tape (asm_tape_begin .. asm_tape_end) every launch is also written
 // down -- kernel, geometry, stream and a copy of its arguments converted to the kernel's parameter types -- so that
@@ -155,6 +159,17 @@ static inline hipError_t asm_ensure_dyn_lds(Kern kern, int lds_bytes, bool (&don
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e == hipSuccess && slot >= 0) done[slot] = true;
   return e;
+}
+// compute units of the current device (cached per device; 256 on MI355X)
+static inline int asm_num_cus() {
+  static int cached[ASM_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ASM_MAX_DEVICES) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
 }
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 

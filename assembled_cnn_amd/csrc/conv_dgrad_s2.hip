@@ -221,6 +221,7 @@ int asm_dgrad_s2_try(const asm_conv_desc* d, const void* dy, const void* wt, con
   a.ppr = d->Wo / 8; a.ppi = a.ppr * (d->Ho / 8); a.patches = a.ppi * d->N;
   const int grid = a.patches < 256 ? a.patches : 256;      // one persistent workgroup per CU
   ASM_LAUNCH(dgrad_s2_kernel, dim3(grid), dim3(256), S2_LDS, (hipStream_t)stream, a);
+  asm_last_conv_kernel = 5;
   ASM_CHECK_LAUNCH("dgrad_s2_kernel");
   return ASM_OK;
 }

@@ -208,6 +208,7 @@ int launch1_one(const IGemmArgs& a, hipStream_t st) {
   if (hipError_t e = asm_ensure_dyn_lds(kern, C1::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm1_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
   ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(64 * WGM * WGN), C1::LDS, st, a);
+  asm_last_conv_kernel = 1;
   ASM_CHECK_LAUNCH("igemm1_kernel");
   return ASM_OK;
 }

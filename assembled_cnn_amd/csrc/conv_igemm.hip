@@ -23,6 +23,8 @@ using namespace asm_igemm;
 
 // conv_gemm1.hip: the 1x1 layers as a GEMM with a ring of LDS stages (returns 1 when it does not take the layer)
 int asm_gemm1_try(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st);
+// conv_igemm8.hip: the wide 3x3 stride-1 layers on the wave-staggered multi-phase main loop (returns 1 when it does not take the layer)
+int asm_igemm8_try(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st);
 
 namespace {
 
@@ -335,8 +337,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
     const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = (int)fd_div((unsigned)logical, p.fd_ntn);
-  const int tile_n = logical - tile_m * p.n_tiles_n;
+  const int tile_m0 = (int)fd_div((unsigned)logical, p.fd_ntn);
+  const int tile_n = logical - tile_m0 * p.n_tiles_n;
+  const int tile_m = tile_m0 + p.m_tile0;
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
@@ -563,8 +566,9 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
     const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = (int)fd_div((unsigned)logical, p.fd_ntn);
-  const int tile_n = logical - tile_m * p.n_tiles_n;
+  const int tile_m0 = (int)fd_div((unsigned)logical, p.fd_ntn);
+  const int tile_n = logical - tile_m0 * p.n_tiles_n;
+  const int tile_m = tile_m0 + p.m_tile0;
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
@@ -722,6 +726,7 @@ int launch3_one(const IGemmArgs& a, hipStream_t st) {
   if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm3_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
   ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(256), LDS, st, a);
+  asm_last_conv_kernel = 3;
   ASM_CHECK_LAUNCH("igemm3_kernel");
   return ASM_OK;
 }
@@ -737,7 +742,7 @@ int try_igemm3(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   if (a.HoWo != a.Hi * a.Wi || a.Wo != a.Wi || a.M % a.HoWo) return 1;
   if (a.x_pix_pitch != a.Ci || a.x_row_pitch != a.Wi * a.Ci || a.x_img_pitch != a.Hi * a.Wi * a.Ci) return 1;
   a.n_tiles_n = cdiv(a.Co, 128);
-  a.n_blocks = cdiv(a.M, 128) * a.n_tiles_n;
+  a.n_blocks = (cdiv(a.M, 128) - a.m_tile0) * a.n_tiles_n;
   a.kchunks = a.Ci / 64;
   a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
   const int pfa_env = asm_tune().igemm_pfa;
@@ -943,6 +948,7 @@ int launch_halo(IGemmArgs& a, bool stats, hipStream_t st) {
       ASM_FAIL(ASM_EHIP, "conv_halo_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
     ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(256), H::LDS, st, a);
   }
+  asm_last_conv_kernel = 4;
   ASM_CHECK_LAUNCH("conv_halo_kernel");
   return ASM_OK;
 }
@@ -978,6 +984,7 @@ int launch2_one(const IGemmArgs& a, hipStream_t st) {
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm2_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
   ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(NTHR), C::LDS, st, a);
+  asm_last_conv_kernel = 2;
   ASM_CHECK_LAUNCH("igemm2_kernel");
   return ASM_OK;
 }
@@ -986,7 +993,7 @@ int launch2_one(const IGemmArgs& a, hipStream_t st) {
 template <int BM, int BN, int BK, int WGM, int WGN>
 int launch2_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   a.n_tiles_n = cdiv(a.Co, BN);
-  a.n_blocks = cdiv(a.M, BM) * a.n_tiles_n;
+  a.n_blocks = (cdiv(a.M, BM) - a.m_tile0) * a.n_tiles_n;     // (m_tile0 != 0 only on the way to a 128-row tile)
   a.kchunks = cdiv(a.Ci, BK);
   a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
   if (a.Ci % BK != 0 && a.kchunks != 1) return 1;
@@ -1034,6 +1041,7 @@ int launch_one(const IGemmArgs& a, hipStream_t st) {
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
   ASM_LAUNCH(kern, dim3(a.n_blocks), dim3(C::NT), C::LDS, st, a);
+  asm_last_conv_kernel = 0;
   ASM_CHECK_LAUNCH("igemm_kernel");
   return ASM_OK;
 }
@@ -1108,6 +1116,43 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
     // 256 x 256 tile carries -- stand-alone that tile wins them by 3 - 15 %, beside the weight-gradient streams two 80 KB
     // workgroups per CU finish sooner than one 128 KB one (heaviest input gradient 618 -> 472 us in situ)
     const bool deep_small = h3 == 4 && bigv && a.Wi <= 14 && a.Ci >= 256;
+    // igemm8_kernel: the layers of the 256 x 256 tile on the wave-staggered multi-phase loop (bit-identical results)
+    const int h8 = asm_tune().igemm8;
+    // (the short-reduction layers on >= 768 tiles stay on igemm3, below: 28x28x128 -> 256 forward 127 us there, 131 us here)
+    const bool to_igemm3 = h3 && b256v >= 768 && a.Ci <= 128;
+    if (ftile == 0 && !deep_small && ((h8 == 1 && bigv && !to_igemm3) || h8 == 2)) {
+      // The ragged last round.  One 128 KB workgroup per CU: n tiles take ceil(n / CUs) rounds, and 784 tiles on 256 CUs
+      // (14x14x512 -> 1024 and 28x28x128 -> 256 at batch 256) spend a whole round on their last 16.  When the tail is short,
+      // the row tiles of the full rounds go to igemm8 and the remaining rows to the 128 x 128 kernels (igemm3 / igemm2: four
+      // times the workgroups, two per CU, the same accumulation order -- the tensor stays bit-identical): 3 rounds + one
+      // small round (~0.3 of a big one when there is at most one small tile per CU, ~0.5 per round of two) instead of 4.
+      // Measured (14x14x512 -> 1024 forward, same box): 490.2 us igemm2, 455.5 us split (three igemm8 rounds ~355 us + ~100 us
+      // for the 64 small tiles, which run one per CU and are latency-bound: 72 lock-step steps).
+      const int cus = asm_num_cus();
+      const int nt8 = cdiv(a.Co, 256), mt8 = cdiv(a.M, 256);
+      const long long n8 = (long long)nt8 * mt8;
+      const int m_full = (int)((n8 / cus) * cus / nt8);                 // row tiles of the full rounds
+      const long long rem = n8 - (long long)m_full * nt8;              // 256 x 256 tiles left over
+      const double small = 4 * rem <= cus ? 0.3 : 0.5 * (double)((4 * rem + 2 * cus - 1) / (2 * cus));
+      const double split_cost = (double)((long long)m_full * nt8 / cus) + small, whole_cost = (double)((n8 + cus - 1) / cus);
+      if (h8 == 1 && m_full > 0 && rem > 0 && split_cost < whole_cost - 0.15) {
+        IGemmArgs head = a;
+        head.M = m_full * 256;            // rows of the full rounds (the gather itself is bounded by the tensor, not by M)
+        rc = asm_igemm8_try(head, out_f32, stats, st);
+        if (rc == ASM_OK) {
+          IGemmArgs tail = a;
+          tail.m_tile0 = m_full * 2;      // in 128-row tiles
+          rc = try_igemm3(tail, out_f32, stats, st);
+          if (rc == 1) rc = launch2_cfg<128, 128, 64, 2, 2>(tail, out_f32, stats, st);
+          if (rc == 1) ASM_FAIL(ASM_EINVAL, "conv: no 128-row kernel for the last rows of an igemm8 layer");
+          return rc;
+        }
+        if (rc != 1) return rc;
+      } else {
+        rc = asm_igemm8_try(a, out_f32, stats, st);
+        if (rc != 1) return rc;
+      }
+    }
     if (ftile == 0 && h3 && (h3 == 2 || !bigv || (b256v >= 768 && a.Ci <= 128) || deep_small)) {
       rc = try_igemm3(a, out_f32, stats, st);
       if (rc != 1) return rc;
@@ -1161,6 +1206,8 @@ static inline int64_t img_pitch(const asm_conv_desc* d) {
 static inline int row_pitch(const asm_conv_desc* d) { return d->x_row_pitch ? d->x_row_pitch : d->W * d->C; }
 static inline int pix_pitch(const asm_conv_desc* d) { return d->x_pix_pitch ? d->x_pix_pitch : d->C; }
 
+extern "C" int asm_debug_last_conv_kernel(void) { return asm_last_conv_kernel; }
+
 extern "C" int asm_conv2d_stats_blocks(const asm_conv_desc* d) {
   if (!d) return ASM_EINVAL;
   return cdiv(d->N * d->Ho * d->Wo, STATS_BM);
@@ -1191,6 +1238,7 @@ static int fprop_impl(const asm_conv_desc* d, const void* x, const void* w, void
   a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = a.pool_H = 0;
   a.x_img_pitch = (int)img_pitch(d); a.x_row_pitch = row_pitch(d); a.x_pix_pitch = pix_pitch(d);
   a.w_row_pitch = d->R * d->S * d->C;
+  a.m_tile0 = 0;
   return launch(a, d->out_f32 != 0, stats_partial != nullptr, (hipStream_t)stream);
 }
 
@@ -1265,7 +1313,7 @@ static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, co
   a.R = d->R; a.S = d->S;
   a.x_img_pitch = d->Ho * d->Wo * d->K; a.x_row_pitch = d->Wo * d->K; a.x_pix_pitch = d->K;
   a.w_row_pitch = d->R * d->S * d->K;
-  a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0;
+  a.wt0 = 0; a.wtr = a.S; a.wts = 1; a.y_strided = 0; a.m_tile0 = 0;
   a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
   a.bn_scale = a.bn_shift = nullptr; a.bn_relu = 0;
   a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = a.pool_H = 0;

@@ -24,6 +24,7 @@ struct IGemmArgs {
   int x_img_pitch, x_row_pitch, x_pix_pitch;  // elements
   int w_row_pitch;  // elements between consecutive n rows of Wt (= R*S*Ci)
   int n_tiles_n, n_blocks, kchunks;
+  int m_tile0;     // first row tile of this launch (igemm2 / igemm3 with 128-row tiles: the ragged last round of an igemm8 layer)
   FastDiv fd_howo, fd_wo, fd_ntn;  // m -> (img, ho, wo), block -> (tile_m, tile_n) without integer division (igemm2_kernel)
   // igemm2_kernel only (parity-class decomposition of the stride-2 input gradient, asm_conv2d_dgrad):
   int pad_w;                       // column pad (== pad except in a parity class)
@@ -85,13 +86,18 @@ struct Cfg {
 // m_local = wm*WTM + b*32 + l31.
 // patch_base >= 0: the tile's 128 rows are an 8 x 16 pixel patch of one image (conv_halo_kernel): row r is pixel
 // patch_base + (r >> 4) * W + (r & 15) of the [N*H*W] output.
-template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS, bool PFA = false, bool POOL = false>
+// SPLIT8 (igemm8_kernel, conv_igemm8.hip): a wave's 128 x 64 outputs are two 64-row pieces (one per 128-row half of the pixel
+// tile) by two 32-channel pieces (one per 128-row half of the filter tile): acc[a][b] is filter half a, pixel half b >> 1,
+// 32-row sub-tile b & 1.
+template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS, bool PFA = false, bool POOL = false,
+          bool SPLIT8 = false>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[TN][TM], unsigned char* smem,
                                                int tile_m, int tile_n, int tid, int wm, int wn, int l31, int lhi,
                                                int patch_base = -1) {
   // ---------------- epilogue ----------------
   // acc[a][b][reg]: n_local = wn*WTN + a*32 + (reg&3) + 8*(reg>>2) + 4*lhi ; m_local = wm*WTM + b*32 + l31
   if constexpr (OUT_F32) {
+    static_assert(!SPLIT8, "igemm8 writes bf16");
     float* y = reinterpret_cast<float*>(p.y);
     const int co4 = (p.Co + 3) & ~3;
 #pragma unroll
@@ -158,10 +164,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int ml = wm * WTM + b * 32 + l31;
+        const int ml = SPLIT8 ? (b >> 1) * 128 + wm * 64 + (b & 1) * 32 + l31 : wm * WTM + b * 32 + l31;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int nl = wn * WTN + a * 32 + 8 * g + 4 * lhi;
+          const int nl = SPLIT8 ? a * 128 + wn * 32 + 8 * g + 4 * lhi : wn * WTN + a * 32 + 8 * g + 4 * lhi;
           u32x2 v;
           v.x = pack2bf(acc[a][b][4 * g], acc[a][b][4 * g + 1]);
           v.y = pack2bf(acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);

@@ -1090,6 +1090,7 @@ class DropBlockState(object):
     self._given = list(uniforms) if uniforms is not None else None
     self._rng = rng
     if not self.known:
+      self.slots = []          # a discovery step that raised mid-walk left a partial list: discover from scratch
       return
     n = len(self.slots)
     if self._given is not None and len(self._given) != n:

@@ -167,6 +167,7 @@ class Trainer(object):
   between backward and the optimiser with the flat fp32 gradient arena."""
 
   AUTO_WARMUP = 3      # eager steps of one input signature before train_step records itself
+  tape_check_skipped = None   # why the last capture could not compare its tape with the captured graph (None: it was compared)
 
   def __init__(self, hparams: HParams, seed: int = 0, device='cuda', grad_sync=None, world_size: int = 1,
                recorded: Optional[bool] = None):
@@ -192,6 +193,7 @@ class Trainer(object):
     self._auto = dev.type == 'cuda' and recorded is not False and ops.knob('ASM_STEP_TAPE', '1') != '0'
     self._auto_sig, self._auto_n, self._auto_made = None, 0, False
     self._capturing = False
+    self._baked = None
     self.step_mode = 'eager'                 # 'eager' | 'recorded' | 'eager (recording failed: ...)'
     # DropBlock with its draws and gamma in static device buffers (nn.DropBlockState): what lets the published recipe
     # (scripts/train_assemble_from_scratch.sh: --use_dropblock=True) run as a recorded step
@@ -259,13 +261,27 @@ class Trainer(object):
       torch.cuda.synchronize()
       return round(1000.0 * (time.time() - t0) / steps, 3)
 
-    res = {'side_streams_ms': timed(True), 'single_stream_ms': timed(False), 'redraws': 0}
-    keep = res['side_streams_ms'] <= res['single_stream_ms'] * (1.0 + margin)
-    while not keep and res['redraws'] < redraws:
-      res['redraws'] += 1
-      res['side_streams_ms'] = timed(True, fresh=True)
+    # The steps timed here must be EAGER ones: a trainer that records itself (the default on a GPU) would reach AUTO_WARMUP
+    # inside the timed window and time a capture instead.  Self-recording is suspended for the duration and
+    # the trainer's own recording, if any, dropped; a caller-made capture() is frozen with its stream setting (set_streams
+    # raises, as before).
+    auto = self._auto
+    self._auto = False
+    if self._graph is not None and self._auto_made:
+      self.release_graph()
+    try:
+      res = {'side_streams_ms': timed(True), 'single_stream_ms': timed(False), 'redraws': 0}
       keep = res['side_streams_ms'] <= res['single_stream_ms'] * (1.0 + margin)
-    self.set_streams(keep)
+      while not keep and res['redraws'] < redraws:
+        res['redraws'] += 1
+        res['side_streams_ms'] = timed(True, fresh=True)
+        keep = res['side_streams_ms'] <= res['single_stream_ms'] * (1.0 + margin)
+      self.set_streams(keep)
+    finally:
+      self._auto = auto
+      self._auto_n = 0
+    if self._graph is not None:
+      raise RuntimeError('calibrate_streams: a step was recorded while eager steps were being timed')
     res['chosen'] = 'side streams' if keep else 'single stream'
     return res
 
@@ -341,6 +357,11 @@ class Trainer(object):
     """One optimisation step.  A recorded step (capture(), or the trainer's own recording after AUTO_WARMUP eager steps) is
     replayed; ``dropblock_uniforms`` (tests: the draws of every DropBlock call in creation order) go into the static
     draw buffers of a recorded step, or straight to the layers of an eager one."""
+    if self._graph is not None and self._baked_state() != self._baked:
+      if not self._auto_made:
+        raise RuntimeError('grad_sync or a by-value hyper-parameter (loss scale, label smoothing, KD temperature, weight '
+                           'decay, momentum, mixup type) changed after capture(): release_graph() and capture again')
+      self.release_graph()                 # the trainer's own recording: drop it, the eager steps below record again
     if self._graph is not None:
       if self._auto_made and self._signature(images, labels, lam1, lam2) != self._auto_sig:
         self.release_graph()               # other shapes: back to the eager step, which records itself again
@@ -541,6 +562,7 @@ class Trainer(object):
     self._graph, self._static, self._graph_out = g, static, out
     self._tape, self._cap_stream = tape, cap
     self._auto_sig, self._auto_made = sig, False
+    self._baked = self._baked_state()
     self.step_mode = 'recorded'
     return self
 
@@ -553,7 +575,11 @@ class Trainer(object):
     try:
       import ctypes
       raw = g.raw_cuda_graph()
-      hip = ctypes.CDLL('libamdhip64.so')
+      # the runtime torch itself is linked against (already loaded: resolve the symbols from the process image, never
+      # dlopen a second libamdhip64 by name -- a system copy would be another runtime instance)
+      hip = ctypes.CDLL(None)
+      hip.hipGraphGetNodes.restype = ctypes.c_int
+      hip.hipGraphNodeGetType.restype = ctypes.c_int
       n = ctypes.c_size_t(0)
       if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
         return None
@@ -567,14 +593,22 @@ class Trainer(object):
           return None
         kernels += ty.value == 0                  # hipGraphNodeTypeKernel
         copies += ty.value in (1, 2)              # hipGraphNodeTypeMemcpy, hipGraphNodeTypeMemset
-    except (AttributeError, OSError, RuntimeError):
-      return None                                 # this torch / runtime does not expose the raw graph: nothing to compare with
+    except (AttributeError, OSError, RuntimeError) as e:
+      Trainer.tape_check_skipped = repr(e)        # this torch / runtime does not expose the raw graph: nothing to compare with
+      return None
     # (compared as one total: whether the runtime keeps a device-to-device copy as a copy node or as a blit kernel is its business)
     if kernels + copies != info['launches'] + info['fills']:
       raise RuntimeError('the captured step holds %d kernels and %d copies, the launch tape %d and %d: a framework kernel '
                          'ran inside the recorded region and would be missing from every replay'
                          % (kernels, copies, info['launches'], info['fills']))
     return kernels + copies
+
+  def _baked_state(self):
+    """what a recording holds BY VALUE: the gradient exchange it was recorded with and the hyper-parameters that reach the
+    kernels as arguments.  A recorded step replayed after one of them changed would silently run with the old value."""
+    p = self.p
+    return (id(self.grad_sync), float(p.get_loss_scale()), float(p.label_smoothing), float(p.kd_temp), float(p.weight_decay),
+            float(p.momentum), int(p.mixup_type))
 
   def release_graph(self):
     if getattr(self, '_tape', None) is not None:

@@ -126,7 +126,11 @@ typedef struct asm_tuning {
                               (default), 0 never, n > 0 force ring depth n                                               */
   int32_t igemm_bk32_3x3;  /* 3x3 layers on 128-row igemm2 tiles stage 32 instead of 64 channels per step (half the LDS: four
                               workgroups per CU instead of two): 0 never, 1 where Ci == 64, 2 every such layer              */
-  int32_t spare[3];        /* must be 0                                                                                   */
+  int32_t igemm8;          /* 3x3 stride-1 layers (forward / input gradient) with >= 256 output channels on the wave-staggered
+                              multi-phase 256 x 256 kernel (igemm8_kernel, csrc/conv_igemm8.hip; bit-identical to igemm2's
+                              256 x 256 tile): 1 where the layer took the 256 x 256 tile (default), 2 wherever the shape
+                              allows, 0 never                                                                             */
+  int32_t spare[2];        /* must be 0                                                                                   */
 } asm_tuning;
 void asm_tuning_defaults(asm_tuning* t);
 int asm_set_tuning(const asm_tuning* t);

@@ -26,6 +26,11 @@ int asm_debug_tr_probe(void* out256_i16, void* stream);
  * plan = {dy-tile rows (32/64/128/256), column-tile width (128/256), tiles_n, tiles_c, pixel splits, pixels per split}. */
 int asm_conv2d_wgrad_plan(const asm_conv_desc* d, int32_t plan[6]);
 
+/* Kernel family of the calling thread's last asm_conv2d_fprop* / asm_conv2d_dgrad* launch: 0 igemm_kernel (general fallback),
+ * 1 igemm1_kernel (1x1 ring GEMM), 2 igemm2_kernel, 3 igemm3_kernel (rows resident across the taps), 4 conv_halo_kernel,
+ * 5 dgrad_s2_kernel, 8 igemm8_kernel (wave-staggered multi-phase loop); -1 before the first call. */
+int asm_debug_last_conv_kernel(void);
+
 
 /* ---- measured-slower variant, kept for A/B runs (opt-in on the host: ASM_DENSE_BN=1) -------------------------------------
  * Not part of the drop-in boundary; DESIGN.md section 5.1 has the numbers (dense + BN in one launch: 27.61 vs 27.40 ms per

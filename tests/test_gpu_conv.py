@@ -603,3 +603,92 @@ def test_ring_weight_gradient_is_the_register_staged_one_bit_for_bit(hip_lib, sh
   yr = O._conv_raw(x.float().cpu().permute(0, 3, 1, 2), wr, 1, 1)
   gw, = torch.autograd.grad(yr, [wr], dy.float().cpu().permute(0, 3, 1, 2))
   assert util.rel_l2(outs[('0', '2')].cpu().permute(1, 2, 3, 0), gw) <= 1e-4
+
+
+IGEMM8_SHAPES = [
+    # N, H,  W,  C,   K     (3x3, stride 1)
+    (2, 14, 14, 128, 256),    # M = 392: one full + one ragged 256-row tile; 2 chunks (18 steps)
+    (3, 7, 7, 192, 448),      # M = 147 (< one tile), 3 / 7 chunks (odd: forward / input gradient), ragged second N tile (448, 192)
+    (1, 16, 16, 64, 512),     # ONE chunk (nine steps), exactly one row tile, two N tiles
+    (5, 9, 13, 256, 320),     # odd H / W, images inside a tile, 4 chunks, N tail 64 of 256
+    (24, 14, 14, 512, 256),   # 8 chunks (72 steps), 19 row tiles
+]
+
+
+@pytest.mark.parametrize('shape', IGEMM8_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_igemm8_bit_identical_to_igemm2_and_vs_oracle(hip_lib, shape, monkeypatch):
+  """igemm8_kernel (wave-staggered multi-phase main loop, csrc/conv_igemm8.hip) against the oracle AND bit for bit against
+  igemm2_kernel's 256 x 256 tile (same operands, same (chunk, tap, k) accumulation order): forward with / without the fused
+  statistics, input gradient with / without the fan-in addend.  Repeated launches must agree with each other: a staging race
+  (a half-tile read before its DMA landed, or re-staged before its last read) shows as run-to-run differences."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K = shape
+  x = _rand((N, H, W, Cn), 11)
+  w = _rand((K, 3, 3, Cn), 12, scale=(1.0 / (9 * Cn)) ** 0.5)
+  d = ops.make_conv_desc(N, H, W, Cn, K, 3, 3, 1)
+  xd, wd = x.cuda(), w.cuda()
+  ref = _ref_conv(x, w, 1)
+  dy = _rand(tuple(ref.shape), 13).cuda()
+  wt = torch.zeros((Cn, 3, 3, K), dtype=BF, device='cuda')
+  ops.filter_transpose(wd, wt, K, 3, 3, Cn)
+  add = _rand((N, H, W, Cn), 14).cuda()
+
+  def run():
+    y, st = ops.conv_fprop(d, xd, wd, want_stats=True)
+    y2, _ = ops.conv_fprop(d, xd, wd, want_stats=False)
+    dx = ops.conv_dgrad(d, dy, wt)
+    dxa = ops.conv_dgrad(d, dy, wt, addend=add)
+    return y, st, y2, dx, dxa
+
+  util.set_knob(monkeypatch, 'ASM_IGEMM8', '0')
+  util.set_knob(monkeypatch, 'ASM_IGEMM_TILE', '3')      # igemm2_kernel<256, 256, 64>
+  base = run()
+  assert hip_lib.asm_debug_last_conv_kernel() == 2
+  util.set_knob(monkeypatch, 'ASM_IGEMM_TILE', '0')
+  util.set_knob(monkeypatch, 'ASM_IGEMM8', '2')          # igemm8_kernel wherever the shape allows
+  for rep in range(6):
+    got = run()
+    assert hip_lib.asm_debug_last_conv_kernel() == 8, 'the layer did not run on igemm8_kernel'
+    for name, a, b in zip(('fprop+stats', 'stats', 'fprop', 'dgrad', 'dgrad+addend'), got, base):
+      assert torch.equal(a, b), 'igemm8 %s differs from igemm2 (rep %d): max |d| %.3e' % (
+          name, rep, float((a.float() - b.float()).abs().max()))
+  _check(got[0], ref, name='igemm8 fprop')
+  xr = x.float().requires_grad_(True)
+  from oracle import assembled_oracle as O
+  yr = O._conv_raw(xr.permute(0, 3, 1, 2), w.float().permute(1, 2, 3, 0), 3, 1)
+  gx, = torch.autograd.grad(yr, [xr], dy.float().cpu().permute(0, 3, 1, 2))
+  _check(got[3], gx, name='igemm8 dgrad')
+
+
+def test_igemm8_ragged_last_round_split(hip_lib, monkeypatch):
+  """260 tiles of 256 x 256 on a 256-CU chip: the 256 tiles of the full round run on igemm8_kernel, the rows of the last
+  four on the 128-row kernel (conv_igemm.hip, "the ragged last round").  Forward (+ statistics) and input gradient
+  (+ addend) must equal the unsplit igemm2 result bit for bit, statistics partial rows included."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K = 65, 16, 16, 128, 1024
+  x = _rand((N, H, W, Cn), 21)
+  w = _rand((K, 3, 3, Cn), 22, scale=(1.0 / (9 * Cn)) ** 0.5)
+  d = ops.make_conv_desc(N, H, W, Cn, K, 3, 3, 1)
+  xd, wd = x.cuda(), w.cuda()
+  util.set_knob(monkeypatch, 'ASM_IGEMM8', '0')
+  y0, st0 = ops.conv_fprop(d, xd, wd, want_stats=True)
+  assert hip_lib.asm_debug_last_conv_kernel() == 2
+  util.set_knob(monkeypatch, 'ASM_IGEMM8', '1')
+  n0 = hip_lib.asm_launch_count()
+  y1, st1 = ops.conv_fprop(d, xd, wd, want_stats=True)
+  assert hip_lib.asm_launch_count() - n0 == 2 and hip_lib.asm_debug_last_conv_kernel() == 3, 'expected igemm8 + igemm3'
+  assert torch.equal(y0, y1) and torch.equal(st0, st1)
+  # the same rows with the wide operand on the other side: K = 128 -> C = 1024 input gradient of a 1024 -> 128 layer
+  d2 = ops.make_conv_desc(N, H, W, K, Cn, 3, 3, 1)
+  dy = _rand((N, H, W, Cn), 23).cuda()
+  w2 = _rand((Cn, 3, 3, K), 24, scale=(1.0 / (9 * K)) ** 0.5).cuda()
+  wt = torch.zeros((K, 3, 3, Cn), dtype=BF, device='cuda')
+  ops.filter_transpose(w2, wt, Cn, 3, 3, K)
+  add = _rand((N, H, W, K), 25).cuda()
+  util.set_knob(monkeypatch, 'ASM_IGEMM8', '0')
+  g0 = ops.conv_dgrad(d2, dy, wt, addend=add)
+  util.set_knob(monkeypatch, 'ASM_IGEMM8', '1')
+  n0 = hip_lib.asm_launch_count()
+  g1 = ops.conv_dgrad(d2, dy, wt, addend=add)
+  assert hip_lib.asm_launch_count() - n0 == 2
+  assert torch.equal(g0, g1)

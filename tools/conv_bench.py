@@ -21,8 +21,11 @@ def main():
   ap.add_argument('--iters', type=int, default=10)
   ap.add_argument('--only', default='')
   ap.add_argument('--uniform', action='store_true', help='uniform [-1, 1) operands instead of normal ones')
+  ap.add_argument('--shape', action='append', default=[], help='N,H,W,C,K,R,S,stride: bench this shape instead of the workload (repeatable)')
   args = ap.parse_args()
   shapes = [(k, c) for k, c in conv_shapes(args.workload, args.batch).items() if not k[8]]
+  if args.shape:
+    shapes = [(tuple(int(v) for v in sh.split(',')) + (0,), 1) for sh in args.shape]
 
   def gf(k):
     N, H, W, Cn, K, R, S, st, _ = k
