@@ -26,7 +26,6 @@ struct RowTiling {
   int blocks;     // row blocks = partial rows per channel
   int slices;     // channel slices: a workgroup reduces rows_per_block rows of ONE slice (grid = blocks * slices)
   int vc_slice;   // vector columns per slice
-  int order;      // 0: row tiles interleaved over the workgroups, 1: one contiguous row block each, 2: that, back to front
 };
 
 RowTiling make_tiling(int M, int C) {
@@ -37,9 +36,8 @@ RowTiling make_tiling(int M, int C) {
   // rows per channel, which the finalize kernel behind the reducer walks as a chain of dependent L2 round trips (16 rows
   // per lane: 6.5 us for a launch that moves a few hundred KB, ~80 such launches per backward pass).  With the channels
   // cut into slices of >= 64 (a row segment stays a whole 128-byte line) the same 1024 workgroups leave 1024 / slices
-  // partial rows per channel.  asm_tuning.bn_slices: 0 = this rule, n = at most n slices (1 = the old tiling).
-  int want = asm_tune().bn_slices;
-  if (want <= 0) want = 8;
+  // partial rows per channel.
+  const int want = 8;
   int sl = t.vcols / 8;
   if (sl > want) sl = want;
   if (sl < 1) sl = 1;
@@ -53,14 +51,10 @@ RowTiling make_tiling(int M, int C) {
   if (rows < t.rpb * 4) rows = t.rpb * 4;
   t.rows_per_block = rows;
   t.blocks = cdiv(M, rows);
-  // Which rows a workgroup takes (asm_tuning.bn_order).  1 = one contiguous block of rows each (rounds 1-3): ~1000 streams
-  // that start M / blocks rows apart -- 1.6 MB for the 56 x 56 x 256 tensor, a multiple of 32 KB, so in lock step they
-  // ask the same HBM channels for different DRAM pages -- 4.3 - 4.5 TB/s in the training step where the apply passes, whose
-  // grid-stride loops sweep ONE compact window over the tensor, reach 6.2.  0 (default, round 4) = the reducers sweep the
-  // same way: workgroup b takes the row tiles b, b + blocks, b + 2 blocks, ... (a tile = rpb x 2 rows).  Partial row b then
-  // holds the sum over those tiles: other bits than the blocked order, still a fixed order.  2 = blocked, back to front
-  // (measured neutral against 1: 25.36 vs 25.33 ms per step).
-  t.order = asm_tune().bn_order;
+  // Which rows a workgroup takes: workgroup b takes the row tiles b, b + blocks, b + 2 blocks, ... (a tile = rpb x 2 rows), the
+  // way the apply passes' grid-stride loops sweep ONE compact window over the tensor.  (One contiguous block of rows each --
+  // rounds 1 - 3 -- put ~1000 streams M / blocks rows apart: 1.6 MB for the 56 x 56 x 256 tensor, a multiple of 32 KB, so in lock
+  // step they asked the same HBM channels for different DRAM pages: 4.3 - 4.5 TB/s against 6.2.)
   return t;
 }
 
@@ -79,12 +73,12 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const bf16_t* __restrict
   const int rr = tid / t.vcb;
   const bool active = rr < t.rpb;
   const int rdisp = blockIdx.x / t.slices, slice = blockIdx.x - rdisp * t.slices;
-  const int rblk = t.order == 2 ? t.blocks - 1 - rdisp : rdisp;
+  const int rblk = rdisp;
   const int vc_lo = slice * t.vc_slice, vc_hi = min(t.vcols, vc_lo + t.vc_slice);
   constexpr int U = 2;
-  const int row_begin = t.order ? rblk * t.rows_per_block : rblk * (U * t.rpb);
-  const int row_end = t.order ? min(M, row_begin + t.rows_per_block) : M;
-  const int row_step = t.order ? U * t.rpb : t.blocks * (U * t.rpb);
+  const int row_begin = rblk * (U * t.rpb);
+  const int row_end = M;
+  const int row_step = t.blocks * (U * t.rpb);
   for (int vcbase = vc_lo; vcbase < vc_hi; vcbase += t.vcb) {
     const int vc = vcbase + vc0;
     float s[8], ss[8];
@@ -480,12 +474,12 @@ __global__ __launch_bounds__(256) void rowreduce2_kernel(const bf16_t* __restric
   const int rr = tid / t.vcb;
   const bool active = rr < t.rpb;
   const int rdisp = blockIdx.x / t.slices, slice = blockIdx.x - rdisp * t.slices;
-  const int rblk = t.order == 2 ? t.blocks - 1 - rdisp : rdisp;
+  const int rblk = rdisp;
   const int vc_lo = slice * t.vc_slice, vc_hi = min(t.vcols, vc_lo + t.vc_slice);
   constexpr int U = 2;
-  const int row_begin = t.order ? rblk * t.rows_per_block : rblk * (U * t.rpb);
-  const int row_end = t.order ? min(M, row_begin + t.rows_per_block) : M;
-  const int row_step = t.order ? U * t.rpb : t.blocks * (U * t.rpb);
+  const int row_begin = rblk * (U * t.rpb);
+  const int row_end = M;
+  const int row_step = t.blocks * (U * t.rpb);
   for (int vcbase = vc_lo; vcbase < vc_hi; vcbase += t.vcb) {
     const int vc = vcbase + vc0;
     float s[8], sa[8], sb[8];

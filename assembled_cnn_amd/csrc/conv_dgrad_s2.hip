@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void dgrad_s2_kernel(S2Args p) {
 // returns 1 when the layer is not one this kernel covers (the caller falls back to the parity-class launches)
 int asm_dgrad_s2_try(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend, const uint8_t* addend_mask,
                      void* dx, void* stream) {
-  if (!asm_tune().dgrad_s2) return 1;
+  if (asm_tune().dgrad_parity < 2) return 1;
   if (d->R != 3 || d->S != 3 || d->stride != 2 || d->pad != 1 || d->C != 64 || d->K != 64) return 1;
   if (d->H != 2 * d->Ho || d->W != 2 * d->Wo || d->Ho % 8 || d->Wo % 8) return 1;
   if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(dx) |

@@ -300,7 +300,6 @@ int asm_gemm1_try(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
     // pays on these layers is MORE RESIDENT WORKGROUPS (one's prologue / epilogue under the others' K loops), not a deeper
     // ring: 128 x 128 x 64 with 3 or 4 stages (one workgroup per CU) LOSES 20 - 60 % against two stages (two per CU).
     case 1: return launch1_cfg<128, 128, 64, 2, 2, 2>(a, stats, st);   //  64 KB: 2 per CU (igemm2's tile and depth)
-    case 2: return launch1_cfg<128, 128, 64, 2, 2, 3>(a, stats, st);   //  96 KB: 1
     case 5: return launch1_cfg<128, 128, 32, 2, 2, 3>(a, stats, st);   //  48 KB: 3
     case 8: return launch1_cfg<256, 128, 64, 4, 2, 3>(a, stats, st);   // 144 KB: 1 (8 waves)
     case 10: return launch1_cfg<128, 128, 32, 2, 2, 2>(a, stats, st);  //  34 KB: 4
@@ -308,7 +307,6 @@ int asm_gemm1_try(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
     case 12: return launch1_cfg<128, 64, 32, 2, 2, 3>(a, stats, st);   //  36 KB: 4
     case 13: return launch1_cfg<128, 64, 32, 2, 2, 2>(a, stats, st);   //  24 KB: 6
     case 14: return launch1_cfg<256, 128, 32, 4, 2, 3>(a, stats, st);  //  72 KB: 2 (8 waves each)
-    case 15: return launch1_cfg<256, 128, 64, 4, 2, 2>(a, stats, st);  //  96 KB: 1 (8 waves)
     case 16: return launch1_cfg<128, 256, 32, 2, 2, 2>(a, stats, st);  //  66 KB: 2 (4 waves of 64 x 128)
     default: return 1;
   }

@@ -12,10 +12,11 @@
 // same pass accumulates per-channel sum / sum-of-squares of the bf16-ROUNDED outputs (the first
 // half of the following batch-norm), written as deterministic per-M-block partials (no atomics).
 //
-// Global -> LDS staging goes through registers with raw buffer loads: an out-of-image tap or a
-// channel tail simply gets an out-of-range offset and the hardware returns zeros (branch-free
-// zero padding).  LDS rows are XOR-swizzled at 16-byte granularity so the ds_read_b128 fragment
-// reads are bank-conflict free.
+// igemm_kernel below is the GENERAL form (any filter size, stride, channel count that is a multiple of 8): global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4), an out-of-image tap or a channel tail reads 16 zero bytes instead.  LDS rows are
+// XOR-swizzled at 16-byte granularity so the ds_read_b128 fragment reads are bank-conflict free.  The workloads' own layers
+// run on the specialised kernels further down (igemm2 / igemm3 / igemm8 / conv_halo, conv_gemm1.hip); the register-staged
+// forms of this kernel (rounds 1 - 5) measured slower than its LDS-DMA form wherever it is still used and were removed.
 #include "common.h"
 #include "igemm_common.h"
 
@@ -91,64 +92,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
     wb[j] = (wrow_ok[j] && n < p.Co) ? n * p.w_row_pitch : -1;
   }
 
-  // Register tile sets.  DEEP: while tile kt is consumed from LDS, tile kt+1 sits in one set (being
-  // written to the other LDS stage) and the loads of tile kt+2 are already in flight in the other set.
-  constexpr bool DEEP = MODE == 1;
-  u32x4 xa[XP], wa[WP], xb2[DEEP ? XP : 1], wb2[DEEP ? WP : 1];
-  int kt_r = 0, kt_s = 0, kt_c = 0;  // tap / channel-chunk cursor of the NEXT tile to load
-
-  auto load_tile = [&](u32x4* xr, u32x4* wr, bool live) {
-    const int c = kt_c * BK + chunk * 8;
-    const bool cok = live && c < p.Ci;
-    const int th = p.tsign * kt_r, tw = p.tsign * kt_s;
-#pragma unroll
-    for (int j = 0; j < XP; ++j) {
-      int nh = bh[j] + th, nw = bw[j] + tw;
-      bool ok = cok;
-      if (p.sd == 2) {
-        ok = ok && (((nh | nw) & 1) == 0);
-        nh >>= 1;
-        nw >>= 1;
-      }
-      ok = ok && ((unsigned)nh < (unsigned)p.Hi) && ((unsigned)nw < (unsigned)p.Wi);
-      const unsigned off = ((unsigned)xb[j] + (unsigned)nh * (unsigned)p.x_row_pitch +
-                            (unsigned)nw * (unsigned)p.x_pix_pitch + (unsigned)c) * 2u;
-      xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : ASM_OOB, 0, 0);
-    }
-    const int tap_off = (kt_r * p.S + kt_s) * p.Ci + c;
-#pragma unroll
-    for (int j = 0; j < WP; ++j) {
-      const bool ok = cok && (wb[j] >= 0);
-      const unsigned off = (unsigned)(wb[j] + tap_off) * 2u;
-      wr[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? off : ASM_OOB, 0, 0);
-    }
-    // advance cursor: taps innermost, channel chunk outermost.  Consecutive K-steps then re-read (almost)
-    // the same pixels shifted by one tap, which hit L1/L2; with the chunk loop innermost the 9 tap passes of
-    // a 3x3 layer were a whole activation tile apart and each re-fetched it from HBM (PMC: 4.5x over-fetch).
-    if (++kt_s == p.S) {
-      kt_s = 0;
-      if (++kt_r == p.R) {
-        kt_r = 0;
-        ++kt_c;
-      }
-    }
-  };
-
-  auto store_tile = [&](int stage, const u32x4* xr, const u32x4* wr) {
-    unsigned char* xs = smem + stage * STAGE;
-    unsigned char* ws = xs + BM * ROWB;
-#pragma unroll
-    for (int j = 0; j < XP; ++j) {
-      const int row = r0 + j * RPP;
-      *reinterpret_cast<u32x4*>(xs + row * ROWB + ((chunk ^ swz<BK>(row)) << 4)) = xr[j];
-    }
-#pragma unroll
-    for (int j = 0; j < WP; ++j) {
-      const int row = r0 + j * RPP;
-      if (wrow_ok[j]) *reinterpret_cast<u32x4*>(ws + row * ROWB + ((chunk ^ swz<BK>(row)) << 4)) = wr[j];
-    }
-  };
-
+  int kt_r = 0, kt_s = 0, kt_c = 0;  // tap / channel-chunk cursor of the NEXT tile to load (taps innermost, chunk outermost)
   // LDS-DMA staging: the thread -> (row, chunk) map above is already lane-linear per wave and pass (a wave
   // covers 64/CPR whole rows = 1 KiB), which is what global_load_lds requires of its destination; the XOR
   // swizzle therefore moves to the SOURCE side: the lane sitting at LDS chunk position `chunk` of row r fetches
@@ -236,50 +180,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
     }
   };
 
-  if constexpr (MODE == 2) {
-    issue_tile(0, true);
+  issue_tile(0, true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll 1
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) issue_tile(cur ^ 1, true);   // DMA of tile kt+1 runs under the MFMAs of tile kt
+    compute(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#pragma unroll 1
-    for (int kt = 0; kt < KT; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < KT) issue_tile(cur ^ 1, true);   // DMA of tile kt+1 runs under the MFMAs of tile kt
-      compute(cur);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else if constexpr (DEEP) {
-    load_tile(xa, wa, true);              // tile 0
-    store_tile(0, xa, wa);
-    load_tile(xa, wa, KT > 1);            // tile 1 in flight in set A (zeros if there is none)
-    __syncthreads();
-    // With an odd KT the last odd step multiplies a zero tile (its loads are predicated off), which keeps
-    // the loop body branch-free around the MFMA blocks.
-#pragma unroll 1
-    for (int kt = 0; kt < KT; kt += 2) {
-      // even step: LDS stage 0 holds tile kt, set A holds tile kt+1
-      load_tile(xb2, wb2, kt + 2 < KT);                // tile kt+2 -> set B
-      compute(0);
-      store_tile(1, xa, wa);                           // waits only for set A (loads retire in order)
-      __syncthreads();
-      // odd step: LDS stage 1 holds tile kt+1 (zeros past the end), set B holds tile kt+2
-      load_tile(xa, wa, kt + 3 < KT);                  // tile kt+3 -> set A
-      compute(1);
-      store_tile(0, xb2, wb2);
-      __syncthreads();
-    }
-  } else {
-    load_tile(xa, wa, true);
-    store_tile(0, xa, wa);
-    __syncthreads();
-#pragma unroll 1
-    for (int kt = 0; kt < KT; ++kt) {
-      const int cur = kt & 1;
-      load_tile(xa, wa, kt + 1 < KT);
-      compute(cur);
-      store_tile(cur ^ 1, xa, wa);
-      __syncthreads();
-    }
   }
 
   igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
@@ -308,7 +218,7 @@ struct Cfg2 {
 };
 
 // SCHED 1: the LDS-DMA pieces of step k+1 are issued IN BETWEEN the MFMA groups of step k instead of all at once right
-// after the barrier (default for the 3x3 layers, asm_tuning.conv_sched).  Also tried (round 3, same box, conv_bench): pinning
+// after the barrier (the 3x3 layers; the 1x1 layers issue them all at the head of the step).  Also tried (round 3, same box, conv_bench): pinning
 // the fragment reads of group kk+1 at the head of group kk with sched_barrier(0) -- 2.62 vs 2.55 ms over the 12 heaviest
 // shapes, slower than the compiler's own interleave, dropped.  Every wave comes out of the barrier at the same moment, and one piece
 // costs its wave 60-180 issue cycles (v_readfirstlane + M0 write + the buffer_load itself): with 8 pieces up front both waves
@@ -974,10 +884,9 @@ int launch2_one(const IGemmArgs& a, hipStream_t st) {
   constexpr int NTHR = 64 * WGM * WGN;
   // measured (tools/conv_bench.py, same box, round 3): spreading the DMA issue is +2..4 % on the 3x3 layers (7 of 8 shapes,
   // fprop and dgrad) and -3..6 % on the deep 1x1 layers (their steps are short: the last pieces land too late), hence the
-  // per-layer default; asm_tuning.conv_sched = 1 / 2 forces it on / off for every instantiated shape
+  // per-layer choice
   if constexpr (SCHED == 0 && BK == 64 && BN >= 128 && !OUT_F32 && !POOL && ((R == 3 && S == 3) || (R == 1 && S == 1))) {
-    const int cs = asm_tune().conv_sched;
-    if (cs == 1 || (cs == 0 && R == 3)) return launch2_one<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL, 1>(a, st);
+    if (R == 3) return launch2_one<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL, 1>(a, st);
   }
   auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL, SCHED>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
@@ -1056,41 +965,33 @@ int launch_mode(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   return launch_one<BM, BN, BK, WGM, WGN, false, false, MODE>(a, st);
 }
 
-// staging: 1 = register-staged 2-deep prefetch, 2 = LDS-DMA (see Cfg); 0 = per-layer heuristic.
-// ASM_IGEMM_MODE / ASM_IGEMM_TILE (1 = 128-row tiles, 3 = 256x256) force a choice (tests, tuning).
-
-template <int BM, int BN, int BK, int WGM, int WGN, bool ALLOW_DEEP = true>
-int launch_cfg(IGemmArgs& a, bool out_f32, bool stats, int mode, hipStream_t st) {
-  if (mode == 2) return launch_mode<BM, BN, BK, WGM, WGN, 2>(a, out_f32, stats, st);
-  if (ALLOW_DEEP) return launch_mode<BM, BN, BK, WGM, WGN, 1>(a, out_f32, stats, st);
-  return launch_mode<BM, BN, BK, WGM, WGN, 0>(a, out_f32, stats, st);
+// ASM_IGEMM_MODE != 0 / ASM_IGEMM_TILE (1 = 128-row tiles, 3 = 256x256) force a choice (tests, tuning).
+template <int BM, int BN, int BK, int WGM, int WGN>
+int launch_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
+  return launch_mode<BM, BN, BK, WGM, WGN, 2>(a, out_f32, stats, st);
 }
 
 int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_only = false) {
   // Measured on MI355X (tools/conv_bench.py, Assemble-ResNet-50 shapes, batch 256):
   //  * HBM-bound layers (1x1, and everything at 112x112): LDS-DMA staging + the smallest footprint wins
   //    (3-8 workgroups per CU hide the load round trip of the very short K loops);
-  //  * MFMA-bound layers (K = R*S*C >= 512): register staging with a 2-deep prefetch wins at 128x128,
-  //    and 256x256 / 8 waves / LDS-DMA wins once there are >= 192 such tiles (C>=256 outputs).
+  //  * MFMA-bound layers (K = R*S*C >= 512): 256x256 / 8 waves wins once there are >= 192 such tiles (C>=256 outputs).
   // 1x1 layers stage 32 channels per step (smallest footprint: the bandwidth-bound ones want many workgroups per CU) --
   // except deep reductions on few tiles (7x7 / 14x14 / 28x28 maps), where each of the K / 32 steps is an exposed DMA
-  // round trip behind a barrier: up to ASM_IGEMM_BK64_1X1 (default 4000) 128 x 128 tiles they take 64-channel steps
-  // (tools/conv_bench.py, all 1x1 shapes of the network: fprop 2.36 -> 2.31 ms, input gradients 2.11 -> 2.03 ms per step;
-  // 0 = off).
+  // round trip behind a barrier: up to 4000 tiles of 128 x 128 they take 64-channel steps (tools/conv_bench.py, all 1x1
+  // shapes of the network: fprop 2.36 -> 2.31 ms, input gradients 2.11 -> 2.03 ms per step).  (3x3 layers on 128-row tiles
+  // with 32-channel steps -- half the LDS, four workgroups per CU -- measured slower and were removed in round 6.)
   const long long t128_all = (long long)cdiv(a.M, 128) * cdiv(a.Co, 128);
-  const int bk64_tiles = asm_tune().igemm_bk64_1x1;
-  const int bk32_3x3 = asm_tune().igemm_bk32_3x3;
-  const bool k3_bk32 = a.R == 3 && a.S == 3 && a.Ci % 32 == 0 && (bk32_3x3 == 2 || (bk32_3x3 == 1 && a.Ci == 64));
-  const bool bk64 = a.Ci % 64 == 0 && !k3_bk32 &&
-                    (a.R * a.S > 1 || (bk64_tiles > 0 && a.Ci >= 256 && t128_all <= bk64_tiles));
+  constexpr long long bk64_tiles = 4000;
+  const bool bk64 = a.Ci % 64 == 0 && (a.R * a.S > 1 || (a.Ci >= 256 && t128_all <= bk64_tiles));
   const bool heavy = a.Ci % 64 == 0 && (long long)a.R * a.S * a.Ci >= 512;
   const int fmode = asm_tune().igemm_mode, ftile = asm_tune().igemm_tile;
   a.fd_howo = make_fastdiv((unsigned)a.HoWo);
   a.fd_wo = make_fastdiv((unsigned)a.Wo);
-  const int v2 = asm_tune().igemm_v2;
+  const bool v2 = true;     // (asm_tuning.igemm_mode != 0 is what sends a layer to the general kernel)
   if (a.pool_dy && !(v2 && fmode == 0 && !out_f32 && !stats && a.R == 1 && a.S == 1 && !a.y_strided))
     ASM_FAIL(ASM_ENOTSUP, "conv dgrad_pooled: only the 1x1 stride-1 igemm2 path folds an average-pool backward in");
-  if (v2 && fmode == 0 && ftile == 0 && asm_tune().conv_halo) {
+  if (v2 && fmode == 0 && ftile == 0) {
     const int rc = try_halo(a, out_f32, stats, st);
     if (rc != 1) return rc;
   }
@@ -1157,34 +1058,25 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
       rc = try_igemm3(a, out_f32, stats, st);
       if (rc != 1) return rc;
     }
-    // Small-M, deep-K layers (7x7 maps at batch 256: 98 row tiles): with 128 x 128 tiles a 256-channel output makes only
-    // 196 workgroups for the 512 resident slots; 128 x 64 tiles double the workgroup count (ASM_IGEMM_SMALLM=1, A/B knob).
-    const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Co, 128);
-    const bool narrow = asm_tune().igemm_smallm && !bigv && ftile == 0 && a.Co > 64 && a.Co % 64 == 0 &&
-                        t128 < 320 && (long long)a.R * a.S * a.Ci >= 1024;
     if (a.Co <= 32) rc = bk64 ? launch2_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, st) : launch2_cfg<128, 32, 32, 4, 1>(a, out_f32, stats, st);
-    else if (a.Co <= 64 || narrow) rc = bk64 ? launch2_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, st);
-    else if (ftile == 2 && a.Ci % 64 == 0) rc = launch2_cfg<256, 128, 64, 4, 2>(a, out_f32, stats, st);
+    else if (a.Co <= 64) rc = bk64 ? launch2_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, st);
     else if (bigv) rc = launch2_cfg<256, 256, 64, 4, 2>(a, out_f32, stats, st);
     else rc = bk64 ? launch2_cfg<128, 128, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 128, 32, 2, 2>(a, out_f32, stats, st);
     if (rc != 1 || igemm2_only) return rc;
     if (a.pool_dy) ASM_FAIL(ASM_ENOTSUP, "conv dgrad_pooled: no igemm2 instantiation for this shape");
   }
   if (igemm2_only) return 1;
-  int mode = heavy ? 1 : 2;
-  if (fmode == 1 || fmode == 2) mode = fmode;
-  if (a.Co <= 32) return bk64 ? launch_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, mode, st)
-                              : launch_cfg<128, 32, 32, 4, 1>(a, out_f32, stats, mode, st);
-  if (a.Co <= 64) return bk64 ? launch_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, mode, st)
-                              : launch_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, mode, st);
+  if (a.Co <= 32) return bk64 ? launch_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, st)
+                              : launch_cfg<128, 32, 32, 4, 1>(a, out_f32, stats, st);
+  if (a.Co <= 64) return bk64 ? launch_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, st)
+                              : launch_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, st);
   const long long b256 = (long long)cdiv(a.M, 256) * cdiv(a.Co, 256);
   bool big = heavy && a.Co >= 256 && b256 >= 192;
   if (ftile == 1) big = false;
   if (ftile == 3 && a.Ci % 64 == 0) big = true;
-  if (ftile == 2 && a.Ci % 64 == 0) return launch_cfg<256, 128, 64, 4, 2>(a, out_f32, stats, mode, st);
-  if (big) return launch_cfg<256, 256, 64, 4, 2, false>(a, out_f32, stats, (fmode == 1) ? 1 : 2, st);
-  return bk64 ? launch_cfg<128, 128, 64, 2, 2>(a, out_f32, stats, mode, st)
-              : launch_cfg<128, 128, 32, 2, 2>(a, out_f32, stats, mode, st);
+  if (big) return launch_cfg<256, 256, 64, 4, 2>(a, out_f32, stats, st);
+  return bk64 ? launch_cfg<128, 128, 64, 2, 2>(a, out_f32, stats, st)
+              : launch_cfg<128, 128, 32, 2, 2>(a, out_f32, stats, st);
 }
 
 int check_desc(const asm_conv_desc* d) {

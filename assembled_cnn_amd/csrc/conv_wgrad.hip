@@ -508,207 +508,6 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// wgrad_rows_kernel: weight gradient of the DEEP 3x3 stride-1 layers (14 x 14 and 7 x 7 maps, >= 128 x 256 channels) with the
-// x rows resident across the nine taps (round 4 probe tools/probes/wgrad_probe.hip, round 5 library).  The general kernel
-// stages a 64-pixel x tile per (tap, channel) column group and a dy tile per 256 output channels: 3.7 GB through L2 / the
-// memory-side cache into LDS for the 154 MB of operands of the heaviest layer, which is what holds it at 41 % MFMA busy.
-// Here a workgroup owns 128 (n) x [9 taps x 64 channels] over a pixel range: over the flattened pixel index m the tap (r, s)
-// reads x row m + (r - 1) W + (s - 1), so per 64-pixel step the 64 + 2W + 2 rows all nine taps touch are staged ONCE (LDS-DMA,
-// two stages) beside the 64 dy rows -- 28 KB per 9.4 MFLOP instead of 64 KB per 8.4 -- and tap t's transposed x fragment is
-// read at row offset r W + s (an immediate, W being a template constant).  The convolution's zero padding is a predicate
-// inside the reduction, valid(m, (r, s)) = rowok_r(h) & colok_s(w): four bf16-wide masks per pixel (r = 0, r = 2, s = 0,
-// s = 2), built per step into LDS by 256 lanes, ANDed onto the dy fragment (a lane's 8 consecutive pixels = one 16-byte
-// broadcast read per mask and 16-pixel sub-step).  Waves: 2 (n: 64 each) x 2 (channel tile of 32) x 2 (taps 0-4 / 5-8):
-// 2 dy + 5 (4) x fragments per 10 (8) MFMAs; waves w and w + 4 share a SIMD.  fp32 slabs [split][Co][9 Ci] like the
-// general kernel (one split: straight into dW).  Stand-alone (whole op incl. the slab reduce, general kernel -> this one):
-// 14 x 14 x 512 -> 1024 538 -> 492 us, 7 x 7 x 512 -> 1024 172 -> 154, 14 x 14 x 256 -> 512 138 -> 133.  IN THE TRAINING STEP,
-// where the weight gradients run on side streams beside the input-gradient chain, the step got 0.1 ms SLOWER with it (same
-// box, recorded step, 24.82 -> 24.92 ms; with two rounds of workgroups instead of one: the same) -- its 512-thread / 256-VGPR
-// workgroups hold a CU for a whole pixel range and the kernels of the dependent chain wait longer for one.  asm_tuning.
-// wgrad_rows therefore defaults to 0; the kernel is kept, tested (tests/test_gpu_conv.py, and at batch 256 against the direct
-// kernel with wgrad_rows = 1), for single-stream use and as the base of round 5's work on it.
-template <int WC>
-__global__ __launch_bounds__(512) void wgrad_rows_kernel(WgradArgs p) {
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  constexpr int XROWS = 96, YRB = 256, XRB = 128, PX = 64;
-  constexpr int YT = PX * YRB, XT = XROWS * XRB, MT = 4 * PX * 2, STAGE = YT + XT + MT;
-  static_assert(PX + 2 * WC + 2 <= XROWS, "the halo of a 64-pixel step must fit the x stage");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tg = wave >> 2, ng = (wave >> 1) & 1, cg = wave & 1;
-  int bid;
-  {
-    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
-    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tiles = p.tiles_n * p.tiles_c;          // (Co / 128) x (Ci / 64)
-  const int split = bid / tiles;
-  bid -= split * tiles;
-  const int tile_n = bid / p.tiles_c, cchunk = bid - tile_n * p.tiles_c;
-  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
-  const int m_begin = split * p.m_per_split;
-  const int m_end = min(p.M, m_begin + p.m_per_split);
-  const int steps = (m_end - m_begin + PX - 1) / PX;
-
-  // DMA geometry (a lane's LDS destination is base + 16 lane; the XOR swizzle of the transposing reads is applied to the source):
-  // dy: 256-byte rows, 4 rows per instruction, wave w fills rows 4 (w + 8 j) .., j = 0, 1
-  // x:  128-byte rows, 8 rows per instruction, wave w fills rows 8 (w + 8 j) .., j = 0 (and 1 for w < 4): 96 rows
-  const int yr = lane >> 4, yslot = lane & 15;
-  const int xr = lane >> 3, xslot = lane & 7;
-  auto issue = [&](int step) {
-    unsigned char* ys = smem + (step & 1) * STAGE;
-    unsigned char* xs = ys + YT;
-    const int m0 = m_begin + step * PX;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = 4 * (wave + 8 * j) + yr;
-      const int m = m0 + row;
-      const int cs = yslot ^ ((row & 3) << 2);
-      const bool ok = m < m_end && step < steps;
-      const unsigned off = ((unsigned)m * (unsigned)p.ldy + (unsigned)(tile_n * 128 + cs * 8)) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lptr_t)(ys + 4 * (wave + 8 * j) * YRB), 16, (int)(ok ? off : ASM_OOB), 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (wave + 8 * j < XROWS / 8) {
-        const int row = 8 * (wave + 8 * j) + xr;
-        const int xm = m0 + row - (WC + 1);                       // stage row 0 = pixel m0 - W - 1 (tap (0, 0) of pixel m0)
-        const int cs = xslot ^ (((row >> 1) & 1) << 2);
-        const bool ok = xm >= 0 && xm < p.M && step < steps;
-        const unsigned off = ((unsigned)xm * (unsigned)p.Ci + (unsigned)(cchunk * 64 + cs * 8)) * 2u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + 8 * (wave + 8 * j) * XRB), 16, (int)(ok ? off : ASM_OOB), 0, 0, 0);
-      }
-    }
-    if (tid < 4 * PX) {       // the four factor masks of this step's 64 pixels
-      unsigned short* ms = reinterpret_cast<unsigned short*>(xs + XT);
-      const int which = tid / PX, px = tid - which * PX;
-      const unsigned m = (unsigned)(m0 + px);
-      const unsigned img = fd_div(m, p.fd_howo);
-      const unsigned rem = m - img * (unsigned)p.HoWo;
-      const int h = (int)fd_div(rem, p.fd_wo);
-      const int w = (int)rem - h * p.Wo;
-      const bool v = which == 0 ? h >= 1 : which == 1 ? h <= p.Hi - 2 : which == 2 ? w >= 1 : w <= p.Wi - 2;
-      ms[tid] = v ? 0xffffu : 0u;
-    }
-  };
-
-  f32x16 acc[2][5];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][t][i] = 0.f;
-  const int t16 = lane & 15, g = lane >> 4;
-  const int colsel = (g & 1) * 16, pgrp = (g >> 1) * 8, trow = t16 >> 2, tcol = (t16 & 3) * 4;
-  // x fragment address = (row + sh) * 128 + (c ^ (((row + sh) & 2) << 5)); row & 3 == trow, so the XOR term is one of four
-  // lane values selected by sh & 3 and the rest is an immediate offset of the read
-  const int cx = cg * 32 + colsel + tcol;
-  const int cxb = ((cx >> 3) << 4) | ((cx & 4) << 1);
-  int xl[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) xl[q] = (pgrp + trow) * XRB + (cxb ^ (((trow + q) & 2) << 5));
-  int yl[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int cy = ng * 64 + a * 32 + colsel + tcol;
-    yl[a] = (pgrp + trow) * YRB + ((((cy >> 3) ^ (trow << 2)) << 4) | ((cy & 4) << 1));
-  }
-
-  auto taps = [&](const unsigned char* ys, const unsigned char* xs, auto T0, auto NT) {
-    constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value;
-#pragma unroll
-    for (int kk = 0; kk < PX / 16; ++kk) {
-      u32x4 fy[2], fyr0[2], fyr2[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const bf16x4 y0 = ds_read_tr(ys + yl[a] + kk * 16 * YRB);
-        const bf16x4 y1 = ds_read_tr(ys + yl[a] + kk * 16 * YRB + 4 * YRB);
-        fy[a] = __builtin_bit_cast(u32x4, __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
-      const unsigned char* mb = xs + XT + (pgrp + kk * 16) * 2;
-      const u32x4 r0 = *reinterpret_cast<const u32x4*>(mb), r2 = *reinterpret_cast<const u32x4*>(mb + PX * 2);
-      const u32x4 mc0 = *reinterpret_cast<const u32x4*>(mb + 2 * PX * 2), mc2 = *reinterpret_cast<const u32x4*>(mb + 3 * PX * 2);
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        fyr0[a] = fy[a] & r0;
-        fyr2[a] = fy[a] & r2;
-      }
-#pragma unroll
-      for (int i = 0; i < nt; ++i) {
-        const int t = t0 + i;
-        const int shc = (t / 3) * WC + (t % 3);
-        const bf16x4 x0 = ds_read_tr(xs + xl[shc & 3] + (kk * 16 + shc) * XRB);
-        const bf16x4 x1 = ds_read_tr(xs + xl[shc & 3] + (kk * 16 + shc + 4) * XRB);
-        const bf16x8 fx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          u32x4 v = t / 3 == 0 ? fyr0[a] : t / 3 == 2 ? fyr2[a] : fy[a];
-          if (t % 3 == 0) v &= mc0;
-          if (t % 3 == 2) v &= mc2;
-          acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), fx, acc[a][i], 0, 0, 0);
-        }
-      }
-    }
-  };
-
-  issue(0);
-#pragma unroll 1
-  for (int step = 0; step < steps; ++step) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's part of step `step` has landed ...
-    __syncthreads();                                   // ... everybody's has, masks included; step - 1's stage is free
-    issue(step + 1);
-    const unsigned char* ys = smem + (step & 1) * STAGE;
-    if (tg == 0) taps(ys, ys + YT, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-    else taps(ys, ys + YT, std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
-  }
-
-  float* out = p.out + (size_t)split * p.Co * p.cols;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int nt = tg ? 4 : 5, t0 = tg ? 5 : 0;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      if (i < nt) {
-        const int col = (t0 + i) * p.Ci + cchunk * 64 + cg * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = tile_n * 128 + ng * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          out[(size_t)n * p.cols + col] = acc[a][i][r];
-        }
-      }
-    }
-}
-constexpr int WROWS_LDS = 2 * (64 * 256 + 96 * 128 + 4 * 64 * 2);
-
-// pixel splits of the resident-row form for this layer, or 0 if it does not apply (asm_tuning.wgrad_rows: 0 off, 1 the deep
-// layers it was measured on, 2 wherever the shape allows)
-int wgrad_rows_splits(const asm_conv_desc* d) {
-  const int mode = asm_tune().wgrad_rows;
-  if (!mode) return 0;
-  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
-  if (d->W != 7 && d->W != 14) return 0;
-  if (d->x_img_pitch || d->x_row_pitch || d->x_pix_pitch || d->C % 64 || d->K % 128) return 0;
-  const int tiles = (d->K / 128) * (d->C / 64);
-  const int M = d->N * d->H * d->W;
-  const int msteps = cdiv(M, 64);
-  // measured on the workload (one MI355X, whole op incl. the slab reduce, general kernel -> this one): 14 x 14 x 512 -> 1024
-  // 538 -> 492 us, 7 x 7 x 512 -> 1024 172 -> 154, 14 x 14 x 256 -> 512 138 -> 133, 7 x 7 x 256 -> 512 56 -> 59 (16 tiles need 16
-  // splits of 13 steps: too short); fewer than 16 tiles would need more slabs than the general kernel's plan
-  if (mode != 2 && !(tiles >= 64 || (tiles >= 16 && msteps >= 512))) return 0;
-  int splits = tiles >= 256 ? 1 : (256 + tiles / 2) / tiles;     // one round of 256 workgroups (one per CU); two rounds measured the same in the step
-  const int forced = asm_tune().wgrad_splits;
-  if (forced > 0) splits = forced;
-  if (splits > msteps) splits = msteps;
-  if (splits < 1) splits = 1;
-  const int steps_per = cdiv(msteps, splits);
-  return cdiv(msteps, steps_per);
-}
-
 // workgroups of the persistent halo form for this layer, or 0 if it does not apply
 int wgrad_halo_blocks(const asm_conv_desc* d) {
   const int mode = asm_tune().wgrad_halo;     // 0 off, 1 on for the large maps, 2 whenever the shape allows (tests)
@@ -755,16 +554,13 @@ Plan make_plan(const asm_conv_desc* d) {
   const double work_us = fmax(flops / 6.0e8, io_bytes / 4.0e6);      // ~600 TFLOP/s or ~4 TB/s
   const int slots = 256 * (pl.bnw == 256 ? 1 : (pl.bnw == 128 ? 2 : (pl.bnw == 64 ? 3 : 4))) * (64 / WPX);
   const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;            // at least 4 steps per block
-  // asm_tuning.wgrad_slab_pct: weight of the slab term in percent (100 = the stand-alone optimum; beside other streams' work
-  // an under-filled launch costs less than the model assumes and slab traffic costs everyone)
-  const double slab_w = asm_tune().wgrad_slab_pct > 0 ? asm_tune().wgrad_slab_pct / 100.0 : 1.0;
   int splits = 1;
   double best = 1e30;
   for (int sp = 1; sp <= 256 && sp <= max_splits; ++sp) {
     const double blocks = (double)tiles * sp;
     const double fill = ceil(blocks / slots) / (blocks / slots);      // >= 1: quantisation of the last round
     const double under = blocks < slots ? (double)slots / blocks * 0.5 + 0.5 : 1.0;  // too few blocks: less overlap
-    const double slab = sp > 1 ? ((double)(sp + 1) * wbytes / 4.0e6 + 4.0) * slab_w : 0.0;
+    const double slab = sp > 1 ? ((double)(sp + 1) * wbytes / 4.0e6 + 4.0) : 0.0;
     const double est = work_us * (blocks < slots ? under : fill) + slab;
     if (est < best) {
       best = est;
@@ -800,7 +596,6 @@ int wgrad_ring_depth(const asm_conv_desc* d, const Plan& pl) {
 extern "C" size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d) {
   if (!d) return 0;
   if (const int hb = wgrad_halo_blocks(d)) return (size_t)hb * d->K * 9 * d->C * sizeof(float);
-  if (const int rs = wgrad_rows_splits(d)) return rs > 1 ? (size_t)rs * d->K * 9 * d->C * sizeof(float) : 0;
   Plan pl = make_plan(d);
   if (pl.splits <= 1) return 0;
   return (size_t)pl.splits * d->K * d->R * d->S * d->C * sizeof(float);
@@ -811,11 +606,6 @@ extern "C" int asm_conv2d_wgrad_plan(const asm_conv_desc* d, int32_t plan[6]) {
   if (const int hb = wgrad_halo_blocks(d)) {      // persistent halo form: {K, -1, 1, 1, workgroups, pixels per workgroup}
     plan[0] = d->K; plan[1] = -1; plan[2] = 1; plan[3] = 1; plan[4] = hb;
     plan[5] = (d->N * d->H * d->W + hb - 1) / hb;
-    return ASM_OK;
-  }
-  if (const int rs = wgrad_rows_splits(d)) {      // resident-row form: {128, -2, K / 128, C / 64, splits, pixels per split}
-    const int msteps = cdiv(d->N * d->H * d->W, 64);
-    plan[0] = 128; plan[1] = -2; plan[2] = d->K / 128; plan[3] = d->C / 64; plan[4] = rs; plan[5] = cdiv(msteps, rs) * 64;
     return ASM_OK;
   }
   const Plan pl = make_plan(d);
@@ -864,39 +654,6 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
     ASM_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ASM_OK;
   }
-  if (const int rs = wgrad_rows_splits(d)) {
-    WgradArgs h;
-    h.dy = dy; h.x = x; h.out = rs > 1 ? reinterpret_cast<float*>(workspace) : dw;
-    h.dy_bytes = (unsigned)(dyelems * 2); h.x_bytes = (unsigned)(xelems * 2);
-    h.M = d->N * d->H * d->W; h.Hi = d->H; h.Wi = d->W; h.Ci = d->C; h.Co = d->K; h.ldy = ldy;
-    h.R = 3; h.S = 3; h.so = 1; h.pad = 1;
-    h.x_img_pitch = d->H * d->W * d->C; h.x_row_pitch = d->W * d->C; h.x_pix_pitch = d->C;
-    h.cols = 9 * d->C; h.tiles_n = d->K / 128; h.tiles_c = d->C / 64; h.splits = rs;
-    h.m_per_split = cdiv(cdiv(h.M, 64), rs) * 64;
-    h.HoWo = d->H * d->W; h.Wo = d->W;
-    h.fd_howo = make_fastdiv((unsigned)h.HoWo); h.fd_wo = make_fastdiv((unsigned)h.Wo);
-    hipStream_t hs = (hipStream_t)stream;
-    const dim3 rgrid(h.tiles_n * h.tiles_c * rs);
-    if (d->W == 14) {
-      static bool done14[ASM_MAX_DEVICES] = {};
-      if (hipError_t e = asm_ensure_dyn_lds(wgrad_rows_kernel<14>, WROWS_LDS, done14); e != hipSuccess)
-        ASM_FAIL(ASM_EHIP, "wgrad_rows_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-      ASM_LAUNCH((wgrad_rows_kernel<14>), rgrid, dim3(512), WROWS_LDS, hs, h);
-    } else {
-      static bool done7[ASM_MAX_DEVICES] = {};
-      if (hipError_t e = asm_ensure_dyn_lds(wgrad_rows_kernel<7>, WROWS_LDS, done7); e != hipSuccess)
-        ASM_FAIL(ASM_EHIP, "wgrad_rows_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-      ASM_LAUNCH((wgrad_rows_kernel<7>), rgrid, dim3(512), WROWS_LDS, hs, h);
-    }
-    ASM_CHECK_LAUNCH("wgrad_rows_kernel");
-    if (rs > 1) {
-      const size_t n = (size_t)d->K * 9 * d->C;
-      ASM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)cdivz(n, 128)), dim3(256), 0, hs,
-                         reinterpret_cast<const float*>(workspace), dw, n, rs);
-      ASM_CHECK_LAUNCH("wgrad_reduce_kernel");
-    }
-    return ASM_OK;
-  }
   WgradArgs a;
   a.dy = dy; a.x = x;
   a.out = pl.splits > 1 ? reinterpret_cast<float*>(workspace) : dw;
@@ -917,8 +674,7 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(pl.tiles_n * pl.tiles_c * pl.splits);
   const bool lin = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->Ho == d->H && d->Wo == d->W &&
-                   a.x_pix_pitch == d->C && a.x_row_pitch == d->W * d->C && a.x_img_pitch == d->H * d->W * d->C &&
-                   asm_tune().wgrad_linear != 0;
+                   a.x_pix_pitch == d->C && a.x_row_pitch == d->W * d->C && a.x_img_pitch == d->H * d->W * d->C;
   const int ring = lin && pl.bcw != 256 ? wgrad_ring_depth(d, pl) : 0;
   if (ring >= 2) {
 #define LAUNCH_RING(BNW_, NS_)                                                                                         \

@@ -311,10 +311,8 @@ extern "C" unsigned long long asm_launch_count(void) { return g_launches.load(st
 namespace {
 asm_tuning make_default_tuning() {
   asm_tuning t = {};
-  t.igemm_mode = 0; t.igemm_tile = 0; t.igemm_v2 = 1; t.conv_halo = 1; t.igemm_smallm = 0; t.igemm_pfa = -1;
-  t.igemm_bk64_1x1 = 4000; t.dgrad_parity = 1; t.wgrad_halo = 1; t.wgrad_big = -1; t.wgrad_splits = 0; t.wgrad_linear = 1;
-  t.bn_rows = 1024; t.conv_sched = 0; t.igemm3 = 3; t.bn_slices = 0; t.bn_order = 0; t.dgrad_s2 = 1; t.wgrad_slab_pct = 100; t.wgrad_rows = 0;
-  t.gemm1 = -1; t.wgrad_ring = -1; t.igemm_bk32_3x3 = 0; t.igemm8 = 1;
+  t.igemm_mode = 0; t.igemm_tile = 0; t.igemm_pfa = -1; t.dgrad_parity = 2; t.wgrad_halo = 1; t.wgrad_big = -1; t.wgrad_splits = 0;
+  t.bn_rows = 1024; t.igemm3 = 3; t.gemm1 = -1; t.wgrad_ring = -1; t.igemm8 = 1;
   return t;
 }
 asm_tuning g_tuning = make_default_tuning();
@@ -325,11 +323,10 @@ extern "C" void asm_tuning_defaults(asm_tuning* t) {
   if (t) *t = make_default_tuning();
 }
 extern "C" int asm_set_tuning(const asm_tuning* t) {
-  if (t && (t->bn_rows <= 0 || t->igemm_mode < 0 || t->igemm_mode > 2 || t->igemm_tile < 0 || t->igemm_tile > 3 ||
-            t->wgrad_halo < 0 || t->wgrad_halo > 2 || t->wgrad_splits < 0 || t->igemm_bk64_1x1 < 0 || t->conv_sched < 0 ||
-            t->conv_sched > 2 || t->igemm3 < 0 || t->igemm3 > 4 || t->bn_slices < 0 || t->bn_order < 0 || t->bn_order > 2 || t->wgrad_rows < 0 || t->wgrad_rows > 2 ||
-            t->gemm1 < -2 || t->wgrad_ring < -1 || t->igemm_bk32_3x3 < 0 || t->igemm_bk32_3x3 > 2 || t->igemm8 < 0 || t->igemm8 > 2 ||
-            t->spare[0] || t->spare[1]))
+  if (t && (t->bn_rows <= 0 || t->igemm_mode < 0 || t->igemm_mode > 1 || (t->igemm_tile != 0 && t->igemm_tile != 1 && t->igemm_tile != 3) ||
+            t->igemm_pfa < -1 || t->igemm_pfa > 1 || t->dgrad_parity < 0 || t->dgrad_parity > 2 || t->wgrad_halo < 0 || t->wgrad_halo > 2 ||
+            t->wgrad_big < -1 || t->wgrad_big > 1 || t->wgrad_splits < 0 || t->igemm3 < 0 || t->igemm3 > 4 || t->gemm1 < -2 ||
+            t->wgrad_ring < -1 || t->igemm8 < 0 || t->igemm8 > 2))
     ASM_FAIL(ASM_EINVAL, "asm_set_tuning: field out of range");
   g_tuning = t ? *t : make_default_tuning();
   return ASM_OK;

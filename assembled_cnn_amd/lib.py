@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ASM_HIP_LIB') or os.path.join(HERE, 'libasm_hip.so')
 
 ASM_OK, ASM_EINVAL, ASM_ENOTSUP, ASM_EHIP = 0, -1, -2, -3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class AsmError(RuntimeError):
@@ -62,18 +62,15 @@ class PlanSummary(C.Structure):
 class Tuning(C.Structure):
   """struct asm_tuning: the kernel-selection overrides (the library itself reads no environment variable)"""
   _fields_ = [(n, C.c_int32) for n in (
-      'igemm_mode', 'igemm_tile', 'igemm_v2', 'conv_halo', 'igemm_smallm', 'igemm_pfa', 'igemm_bk64_1x1', 'dgrad_parity',
-      'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'wgrad_linear', 'bn_rows', 'conv_sched', 'igemm3', 'bn_slices', 'bn_order', 'dgrad_s2', 'wgrad_slab_pct', 'wgrad_rows',
-      'gemm1', 'wgrad_ring', 'igemm_bk32_3x3', 'igemm8', 'spare0', 'spare1')]
+      'igemm_mode', 'igemm_tile', 'igemm_pfa', 'dgrad_parity', 'wgrad_halo', 'wgrad_big', 'wgrad_splits', 'bn_rows', 'igemm3',
+      'gemm1', 'wgrad_ring', 'igemm8')]
 
 
 # environment variable of the HOST -> asm_tuning field (same-box A/B runs, tests); unset = the library's default
-TUNING_ENV = {'ASM_IGEMM_MODE': 'igemm_mode', 'ASM_IGEMM_TILE': 'igemm_tile', 'ASM_IGEMM_V2': 'igemm_v2',
-              'ASM_CONV_HALO': 'conv_halo', 'ASM_IGEMM_SMALLM': 'igemm_smallm', 'ASM_IGEMM_PFA': 'igemm_pfa',
-              'ASM_IGEMM_BK64_1X1': 'igemm_bk64_1x1', 'ASM_DGRAD_PARITY': 'dgrad_parity', 'ASM_WGRAD_HALO': 'wgrad_halo',
-              'ASM_WGRAD_BIG': 'wgrad_big', 'ASM_WGRAD_SPLITS': 'wgrad_splits', 'ASM_WGRAD_LINEAR': 'wgrad_linear',
-              'ASM_BN_ROWS': 'bn_rows', 'ASM_CONV_SCHED': 'conv_sched', 'ASM_IGEMM3': 'igemm3', 'ASM_BN_SLICES': 'bn_slices', 'ASM_BN_ORDER': 'bn_order', 'ASM_DGRAD_S2': 'dgrad_s2', 'ASM_WGRAD_SLAB_PCT': 'wgrad_slab_pct', 'ASM_WGRAD_ROWS': 'wgrad_rows',
-              'ASM_GEMM1': 'gemm1', 'ASM_WGRAD_RING': 'wgrad_ring', 'ASM_IGEMM_BK32_3X3': 'igemm_bk32_3x3', 'ASM_IGEMM8': 'igemm8'}
+TUNING_ENV = {'ASM_IGEMM_MODE': 'igemm_mode', 'ASM_IGEMM_TILE': 'igemm_tile', 'ASM_IGEMM_PFA': 'igemm_pfa',
+              'ASM_DGRAD_PARITY': 'dgrad_parity', 'ASM_WGRAD_HALO': 'wgrad_halo', 'ASM_WGRAD_BIG': 'wgrad_big',
+              'ASM_WGRAD_SPLITS': 'wgrad_splits', 'ASM_BN_ROWS': 'bn_rows', 'ASM_IGEMM3': 'igemm3', 'ASM_GEMM1': 'gemm1',
+              'ASM_WGRAD_RING': 'wgrad_ring', 'ASM_IGEMM8': 'igemm8'}
 
 
 def apply_env_tuning(lib) -> 'Tuning':
@@ -209,10 +206,6 @@ DEBUG_SIGNATURES = {
     'asm_debug_tr_probe': (_I, [_P, _P]),
     'asm_conv2d_wgrad_plan': (_I, [_D, C.POINTER(C.c_int32 * 6)]),
     'asm_debug_last_conv_kernel': (_I, []),
-    # measured-slower variants (opt-in: ASM_DENSE_BN=1)
-    'asm_dense_bn_max_rows': (_I, []),
-    'asm_dense_bn_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
-    'asm_dense_dgrad_bn_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -198,19 +198,6 @@ class Model(object):
       self.arena.extra_streams.append(self._bl_stream)
     return self._bl_stream
 
-  def _shortcut_stream(self, ctx: Ctx, x: Var, db):
-    """the stream a projection shortcut's forward runs on beside the main branch, or None (same stream)"""
-    if (ctx.dry or x.data is None or not x.data.is_cuda or not ctx.training or db is not None
-        or ops.knob('ASM_SC_STREAM', '0') != '1'):
-      return None
-    if self._bl_stream is not None and _current_stream() == self._bl_stream:
-      return None      # inside the big branch of a BigLittle stage: a fork off a forked stream, recorded in the forward pass,
-                       # crashes hipStreamEndCapture (ROCm 7.0); the branch's own shortcut stays on the branch stream
-    if getattr(self, '_sc_stream', None) is None:
-      self._sc_stream = torch.cuda.Stream(device=x.data.device)
-      self.arena.extra_streams.append(self._sc_stream)
-    return self._sc_stream
-
   def _bl_backward(self, ctx: Ctx, side, big_out: Var, big_first, big_rest, little):
     """Backward of the two branches of a BigLittle stage as ONE tape entry: the big branch's blocks 2..n (half resolution,
     small-M deep-K tiles) on the branch stream beside the little branch (full resolution, bandwidth-bound) on the compute
@@ -227,7 +214,7 @@ class Model(object):
       # The big branch's output gradient (whatever lazy form it is in) was allocated on the compute stream and is read on
       # the branch stream; its consumer drops it while the little branch keeps allocating on the compute stream, and the
       # caching allocator would hand the block out again while the branch stream still reads it.  Kept alive until the join.
-      keep = (big_out._grad, big_out.grad_mask, big_out.pre_dy, big_out.pool_grad, big_out.pending)
+      keep = (big_out._grad, big_out.grad_mask, big_out.pre_dy, big_out.pool_grad)
       ops.stream_join(side, main)       # the merge's backward produced both branches' output gradients on the compute stream
       bi = li = 0
       try:
@@ -265,17 +252,8 @@ class Model(object):
     kp = getattr(ctx, 'keep_prob', 1.0)
     shortcut = x
     t0 = len(ctx.tape) if ctx.tape is not None else None
-    sc_side = None
     if projection is not None:
-      # The projection shortcut (pool + 1x1 convolution + its batch-norm statistics) depends on the block input only: in the
-      # forward pass it may run on a stream of its own beside conv1 .. SK .. blur of the main branch; the streams meet again at the block-final batch norm that adds the two (ASM_SC_STREAM=1).
-      sc_side = self._shortcut_stream(ctx, x, db)
-      if sc_side is not None:
-        ops.stream_join(sc_side, _current_stream())
-        with _stream_ctx(sc_side):
-          shortcut = projection(x)
-      else:
-        shortcut = projection(x)
+      shortcut = projection(x)
       if db is not None:
         shortcut = nn.dropblock(ctx, shortcut, kp, db, relu=False)                      # :46-47
     t1 = len(ctx.tape) if ctx.tape is not None else None
@@ -306,8 +284,6 @@ class Model(object):
       tape, arena = ctx.tape, ctx.arena
       t2 = len(tape)
       tape[t0:t2] = [arena.release_grads] + tape[t1:t2] + [arena.pass_grads] + tape[t0:t1] + [arena.hold_grads]
-    if sc_side is not None:
-      ops.stream_join(_current_stream(), sc_side)
     cout = expansion * filters
     conv3 = L(lambda: ConvKernel(ctx, 1, filters, cout))
     bn3 = L(lambda: BatchNorm(ctx, cout, zero_gamma=zero_gamma))

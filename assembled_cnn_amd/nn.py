@@ -139,9 +139,7 @@ class ParamArena(object):
       # backward graph, independent of each other) may also overlap each other.  Same box, ms per step: 1 stream 27.09 /
       # 27.13, 2 streams 26.96 / 26.96, 3 streams 27.07; no side stream 27.40.
       n = max(1, int(ops.knob('ASM_WGRAD_STREAMS', '2')))
-      # ASM_WGRAD_PRIO: HIP stream priority of the weight-gradient streams (-1 high, 0 normal, 1 low)
-      prio = int(ops.knob('ASM_WGRAD_PRIO', '0'))
-      self._sides = [torch.cuda.Stream(device=self.w32.device, priority=prio) for _ in range(n)]
+      self._sides = [torch.cuda.Stream(device=self.w32.device) for _ in range(n)]
       self._side_rr = 0
       self.side_stream = self._sides[0]
 
@@ -325,7 +323,7 @@ class Var(object):
   that dominate (the input gradient of the next 1x1 convolution, which adds it in its epilogue, and the batch-norm
   backward of a projection shortcut) read (dy, mask) directly, so dz is never written; anything else just reads
   ``.grad``, which materialises it."""
-  __slots__ = ('_data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'fuse_dgrad', 'pending', 'bn_ctx',
+  __slots__ = ('_data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'bn_ctx',
                'pre_dy', 'deferred', 'pool_grad')
 
   def __init__(self, data, shape=None, needs_grad=True):
@@ -339,11 +337,6 @@ class Var(object):
     self.grad_mask = None
     self.grad_owned = False
     self.needs_grad = needs_grad
-    # squeeze-layer fusion (csrc/dense_small.hip): the output of a fused dense + batch-norm layer may receive its gradient
-    # as a PENDING input gradient (dy, CRSK weights, descriptor of its one consumer), which the batch-norm backward then
-    # computes inside its own launch
-    self.fuse_dgrad = False
-    self.pending = None
     # projection-shortcut fusion: the output of a ReLU-less conv + batch norm carries what its BN backward needs (bn_ctx);
     # the block-final layer that adds it behind one ReLU then runs BOTH batch-norm backwards in one reduce + one apply
     # (ops.bn_bwd_dual) and leaves this layer's dy here (pre_dy)
@@ -658,12 +651,7 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
   # [N, 1, 1, d] squeeze layers (SK / SE fc): the whole BN is one launch per direction instead of 3-4 latency-bound ones
   small = ctx.training and residual is None and d.Ho * d.Wo == 1 and not conv.stem and ops.bn_small_ok(M)
   mask_t = None
-  # ... and when the layer is a plain dense product over <= 256 rows, the product itself joins that launch
-  dense = small and conv.k == 1 and d.H == 1 and d.W == 1 and ops.dense_bn_ok(M, conv.cin, Cn)
-  if dense:
-    y, out_t, mask_t, mean, invstd = ops.dense_bn_fwd(d, x.data, conv.weight(), gamma, beta, BN_EPS, ctx.bn_momentum,
-                                                      a.st(bn.mm), a.st(bn.mv), relu, want_mask=taped)
-  elif small:
+  if small:
     y, _ = conv.fprop(d, x.data, False)
     out_t, mask_t, mean, invstd = ops.bn_small_fwd(y, M, Cn, gamma, beta, BN_EPS, ctx.bn_momentum, a.st(bn.mm),
                                                    a.st(bn.mv), relu, want_mask=taped)
@@ -700,7 +688,6 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
   out = Var(out_t, out_shape)
   if out_t is None:
     out.deferred = (y, M, Cn, scale, shift)
-  out.fuse_dgrad = dense and taped
   if taped and ctx.training and not small and not relu and residual is None:
     out.bn_ctx = (y, gamma, mean, invstd, bn, M, Cn)
 
@@ -716,16 +703,6 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
           x.grad                                        # (not gatherable here) scatter it now
         xg, xmask = x.take_masked_grad()
         dx = conv.backward(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask, pool=pool)
-        if dx is not None:
-          x.grad, x.grad_owned = dx, True
-        return
-      if out.pending is not None:     # fused squeeze layer: (input gradient of the one consumer) + this BN's backward, one launch
-        d_next, dy_next, wt_next = out.pending
-        out.pending = None
-        dy = ops.dense_dgrad_bn_bwd(d_next, dy_next, wt_next, y, mask_t if relu else None, gamma, mean, invstd,
-                                    a.g(bn.gamma), a.g(bn.beta))
-        a.notify_grad(bn.gamma)
-        dx = conv.backward(d, x_t, dy, x.needs_grad, addend=x.grad)
         if dx is not None:
           x.grad, x.grad_owned = dx, True
         return
@@ -799,13 +776,6 @@ def conv_plain(ctx: Ctx, x: Var, conv: ConvKernel, out_f32: bool, ldy: int = 0):
     # the backward descriptor is always a bf16 one; dy's row stride is ldy when the logits were padded
     dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo,
                             ldy=ldy if (ldy and ldy != conv.cout) else 0)
-    if (x.fuse_dgrad and x.needs_grad and x._grad is None and conv.need_dgrad and conv.kpad == conv.cout and not dd.ldy
-        and conv.cout % 16 == 0 and ops.dense_small_on()):
-      # x is the output of a fused dense + batch-norm layer and this is its only consumer: hand the input gradient over
-      # un-computed; that layer's batch-norm backward evaluates it inside its own launch (csrc/dense_small.hip)
-      conv.wgrad_streamed(dd, x_t, dy)
-      x.pending = (dd, dy, conv.arena.wt_view(conv._wts))
-      return
     dx = conv.backward(dd, x_t, dy, x.needs_grad, addend=x.grad)
     if dx is not None:
       x.grad, x.grad_owned = dx, True

@@ -254,51 +254,6 @@ def _is_dense(d: ConvDesc) -> bool:
           and d.x_row_pitch in (0, d.C) and d.x_pix_pitch in (0, d.C) and d.C % 8 == 0)
 
 
-_DENSE_BN_ROWS = None
-
-
-def dense_bn_ok(M: int, K: int, N: int) -> bool:
-  """fc + training-mode batch norm (and its backward twin) in one launch: every row of 32 channels in one workgroup.
-  OPT-IN (ASM_DENSE_BN=1): measured 0.2 ms per step SLOWER than dense_small + bn_small (27.61 vs 27.40 ms, same box) -- one
-  CU has to pull the whole [256 x K] operand through its own L1, and the batch-norm phases are a chain of barriers."""
-  global _DENSE_BN_ROWS
-  if not dense_small_on() or knob('ASM_DENSE_BN', '0') != '1':
-    return False
-  if _DENSE_BN_ROWS is None:
-    _DENSE_BN_ROWS = int(L().asm_dense_bn_max_rows())
-  return M <= _DENSE_BN_ROWS and K % 16 == 0 and N % 8 == 0
-
-
-def dense_bn_fwd(d: ConvDesc, x, w, gamma, beta, eps, momentum, mm, mv, relu, want_mask):
-  """[N,1,1,C] -> 1x1 conv -> training-mode BN [-> ReLU] in ONE launch -> (ypre, z, mask or None, mean, invstd)"""
-  M, K, N = d.N, d.C, d.K
-  ypre = empty((M, 1, 1, N), BF16, x)
-  z = empty((M, 1, 1, N), BF16, x)
-  co = empty((2, N), F32, x)
-  mask = empty((M, N // 8), torch.uint8, x) if (want_mask and relu) else None
-  ev = _TIMER.start('fprop', d) if _TIMER is not None else None
-  check(L().asm_dense_bn_fwd(_ptr(x), K, _ptr(w), K, M, K, N, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(mm), _ptr(mv),
-                             _ptr(ypre), _ptr(z), _ptr(co[0]), _ptr(co[1]), 1 if relu else 0, _ptr(mask), _stream()),
-        'dense_bn_fwd')
-  if ev is not None:
-    ev.record()
-  return ypre, z, mask, co[0], co[1]
-
-
-def dense_dgrad_bn_bwd(d_next: ConvDesc, dy_next, wt_next, ypre, mask, gamma, mean, invstd, dgamma, dbeta):
-  """input gradient of the NEXT 1x1 layer (dy_next [M][K], wt_next = its CRSK copy [N][K]) + the backward of the batch
-  norm that produced that layer's input (ypre [M][N], mask) in ONE launch -> dx [M,1,1,N]"""
-  M, K, N = d_next.N, d_next.K, d_next.C
-  dx = torch.empty_like(ypre)
-  ev = _TIMER.start('dgrad', d_next) if _TIMER is not None else None
-  check(L().asm_dense_dgrad_bn_bwd(_ptr(dy_next), K, _ptr(wt_next), K, M, K, N, _ptr(ypre), _ptr(mask), _ptr(gamma),
-                                   _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dx), _stream()),
-        'dense_dgrad_bn_bwd')
-  if ev is not None:
-    ev.record()
-  return dx
-
-
 def conv_fprop(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, want_stats: bool = False
                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
   """y [N,Ho,Wo,ldy] (bf16 or f32) and, if want_stats, the BN partials [blocks,2,K] (f32)."""
@@ -333,19 +288,18 @@ def conv_fprop_bn(d: ConvDesc, x: torch.Tensor, w: torch.Tensor, scale, shift, r
 def dgrad_pool_ok(d: ConvDesc) -> bool:
   """can asm_conv2d_dgrad_pooled take this layer (1x1, stride 1, on the igemm2 path)?  ASM_POOL_FUSE=0: never"""
   return (knob('ASM_POOL_FUSE', '1') != '0' and d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0
-          and d.C % 8 == 0 and d.K % 32 == 0 and not _is_dense(d) and knob('ASM_IGEMM_V2', '1') != '0'
-          and knob('ASM_IGEMM_MODE', '0') in ('', '0'))
+          and d.C % 8 == 0 and d.K % 32 == 0 and not _is_dense(d) and knob('ASM_IGEMM_MODE', '0') in ('', '0'))
 
 
 def dgrad_s2_ok(d: ConvDesc) -> bool:
   """does the one-launch 3x3 / stride-2 input gradient (csrc/conv_dgrad_s2.hip) take this layer?  It adds a MASKED fan-in
-  addend in its copy-out, so the caller need not materialise the masked gradient first.  ASM_DGRAD_S2=0: never"""
+  addend in its copy-out, so the caller need not materialise the masked gradient first.  ASM_DGRAD_PARITY < 2: never"""
   if not _IS_DOUBLE:        # the library decides from asm_tuning (asm_dgrad_s2_try): ask it, not only the environment
     t = _lib.Tuning()
     L().asm_get_tuning(C.byref(t))
-    if not t.dgrad_s2 or t.igemm_mode:
+    if t.dgrad_parity < 2 or t.igemm_mode:
       return False
-  return (knob('ASM_DGRAD_S2', '1') != '0' and knob('ASM_IGEMM_MODE', '0') in ('', '0') and d.R == 3 and d.S == 3
+  return (knob('ASM_DGRAD_PARITY', '2') == '2' and knob('ASM_IGEMM_MODE', '0') in ('', '0') and d.R == 3 and d.S == 3
           and d.stride == 2 and d.pad == 1 and d.C == 64 and d.K == 64 and d.H == 2 * d.Ho and d.W == 2 * d.Wo
           and d.Ho % 8 == 0 and d.Wo % 8 == 0)
 

@@ -517,8 +517,8 @@ class Trainer(object):
       cap = cur           # already on a stream of the caller's: record there (a capture cannot run on the default stream)
     elif self._step_stream is not None:
       cap = self._step_stream
-    else:   # ASM_TAPE_PRIO: HIP priority of the stream the recorded compute chain runs on (-1 high, 0 normal)
-      cap = torch.cuda.Stream(device=images.device, priority=int(ops.knob('ASM_TAPE_PRIO', '0')))
+    else:
+      cap = torch.cuda.Stream(device=images.device)
     if cap != cur:
       ops.stream_join(cap, cur)
     with torch.cuda.stream(cap):

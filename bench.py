@@ -521,6 +521,51 @@ def main():
   abi_calls = (ops.abi_calls() - calls0) / max(args.steps, 1)
   kernels_per_step = ((ops.L().asm_launch_count() - kern0) / max(args.steps, 1)) if not dry else None
   ops.set_conv_timer(None)
+  if world > 1:
+    # An N-rank line a reader can verify at a glance: who took part (gathered over the process group itself), what each
+    # rank's own clock said, and how much of the gradient exchange was NOT hidden behind the backward pass at this N --
+    # the same K steps again in the same step mode with the exchange detached (ranks then drift apart: the leg comes after
+    # the timed region and nothing measured afterwards depends on the weights).
+    import socket
+    mine = {'rank': rank, 'local_rank': local_rank, 'host': socket.gethostname(),
+            'device': 'cpu' if dry else '%s #%d (%s)' % (torch.cuda.get_device_name(dev), dev.index,
+                                                         getattr(torch.cuda.get_device_properties(dev), 'pci_bus_id', '?')),
+            'ms_per_step': round(1000.0 * el / args.steps, 3)}
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    plain_ms, leg_s = None, -1.0
+    try:      # no collective inside this block: a rank that fails here must not leave the others waiting in one
+      if taped:
+        tr.release_graph()
+      tr.grad_sync = None
+      tr.model.arena.on_grad = None
+      if taped:
+        capture_step()
+      step()
+      if not dry:
+        torch.cuda.synchronize()
+      t1 = time.time()
+      for _ in range(args.steps):
+        step()
+      if not dry:
+        torch.cuda.synchronize()
+      leg_s = time.time() - t1
+      if taped:
+        tr.release_graph()
+    except Exception as e:       # a reported extra must never lose the measured number
+      mine['exchange_leg_error'] = repr(e)
+    tp = torch.tensor([leg_s, -leg_s], device=dev, dtype=torch.float64)     # every rank reaches this: MAX time, MIN time (< 0: a rank failed)
+    dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+    if -float(tp[1]) > 0:
+      plain_ms = 1000.0 * float(tp[0]) / args.steps
+    ms_all = [r_['ms_per_step'] for r_ in seen if r_ and 'ms_per_step' in r_]
+    dp_info.update({'world': world, 'world_seen_by_backend': dist.get_world_size(), 'backend_name': dist.get_backend(),
+                    'ranks': seen, 'rank_ms_per_step_min': min(ms_all), 'rank_ms_per_step_max': max(ms_all),
+                    'ms_per_step_without_exchange': None if plain_ms is None else round(plain_ms, 3),
+                    'exchange_ms_exposed': None if plain_ms is None else round(max(ms_all) - plain_ms, 3),
+                    'what': 'ranks: gathered with all_gather_object over the group the gradients were exchanged on; '
+                            'exchange_ms_exposed = the timed region (max over ranks) minus the same %d steps, same step mode, '
+                            'with the exchange detached' % args.steps})
   eager_leg = None
   if taped:
     tr.release_graph()          # the legs below instrument or re-wire the eager step

@@ -35,7 +35,7 @@ extern "C" {
 #define ASM_ENOTSUP (-2)
 #define ASM_EHIP (-3)
 
-#define ASM_ABI_VERSION 4
+#define ASM_ABI_VERSION 5
 
 const char* asm_last_error(void);
 int asm_abi_version(void);
@@ -88,49 +88,31 @@ int asm_tape_free(int tape);
  * not synchronised against concurrent launches from other threads.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct asm_tuning {
-  int32_t igemm_mode;      /* 0: per-layer choice; 1: register-staged 2-deep fallback kernel; 2: its LDS-DMA form       */
-  int32_t igemm_tile;      /* 0: per-layer choice; 1: 128-row tiles only; 2: 256 x 128; 3: 256 x 256 where Ci % 64 == 0  */
-  int32_t igemm_v2;        /* 1: address-free main loop (igemm2) where instantiated; 0: general fallback kernel          */
-  int32_t conv_halo;       /* 1: resident-halo 3x3 kernels for the 112 x 112 narrow layers                               */
-  int32_t igemm_smallm;    /* 1: 128 x 64 tiles for small-M deep-K layers                                                 */
+  int32_t igemm_mode;      /* 0: per-layer choice; 1: every forward / input-gradient layer on the general kernel (igemm_kernel) */
+  int32_t igemm_tile;      /* 0: per-layer choice; 1: 128-row tiles only; 3: 256 x 256 where Ci % 64 == 0                  */
   int32_t igemm_pfa;       /* -1: per-layer choice; 0 / 1: addend-prefetching epilogue off / on                           */
-  int32_t igemm_bk64_1x1;  /* 1x1 layers with at most this many 128 x 128 tiles take 64-channel steps (0: never)         */
-  int32_t dgrad_parity;    /* 1: stride-2 input gradients as four parity classes                                          */
+  int32_t dgrad_parity;    /* stride-2 input gradients: 2 (default) 3x3 with 64 -> 64 channels in ONE launch (filter slice in
+                              registers, the four parity classes side by side: dgrad_s2_kernel), the others as four
+                              parity-class launches; 1: always four launches; 0: the generic gather                      */
   int32_t wgrad_halo;      /* 0: off; 1: resident-halo weight gradient on the large maps; 2: wherever the shape allows    */
   int32_t wgrad_big;       /* -1: per-layer choice; 0 / 1: 256 x 256 weight-gradient tile off / on                        */
   int32_t wgrad_splits;    /* 0: cost model; n > 0: force n pixel splits                                                   */
-  int32_t wgrad_linear;    /* 1: linear-address form for 1x1 stride-1 weight gradients                                    */
   int32_t bn_rows;         /* partial rows (= workgroups) of the batch-norm reducers                                       */
-  int32_t conv_sched;      /* LDS-DMA issue of the MFMA conv kernels: 0 per layer (3x3: spread between the MFMA groups,
-                              1x1: all at the head of the step); 1: always spread; 2: never                              */
   int32_t igemm3;          /* 3x3 stride-1 layers with >= 128 input channels on maps up to 30 wide with the activation rows
                               resident across the nine taps (igemm3_kernel): 1: where it measured faster than igemm2's
                               tile for the layer; 2: wherever the shape allows; 0: never; 3: as 1, plus the layers with ONE
                               64-channel chunk (Ci = 64, maps up to 62 wide) with a single row buffer (default); 4: as 3,
                               plus the deep layers of the 14- / 7-wide maps that the 256 x 256 tile carries (faster in
                               situ per layer, no faster as a step: opt-in)                                          */
-  int32_t bn_slices;       /* channel slices of the batch-norm reducers (fewer partial rows per channel for the finalize
-                              kernels): 0: C / 64 capped at 8; n: capped at n (1: every workgroup covers all channels)   */
-  int32_t bn_order;        /* rows of a batch-norm reducer workgroup: 0 tiles interleaved over the workgroups, 1 one contiguous block, 2 that, back to front */
-  int32_t dgrad_s2;        /* 1: 3x3 stride-2 input gradients with 64 -> 64 channels in one launch (filter slice in registers,
-                              the four parity classes side by side: dgrad_s2_kernel); 0: four parity-class launches       */
-  int32_t wgrad_slab_pct;  /* weight (percent) of the fp32 slab traffic in the weight gradient's split cost model: 100 = as
-                              measured stand-alone; larger = fewer pixel splits                                          */
-  int32_t wgrad_rows;      /* resident-row weight gradient of the deep 3x3 stride-1 layers on 14- and 7-wide maps
-                              (wgrad_rows_kernel): 0 off (default: faster stand-alone, slower beside the other streams of
-                              the training step), 1 where it measured faster stand-alone, 2 wherever the shape allows    */
   int32_t gemm1;           /* 1x1 convolutions (forward / input gradient) as a GEMM with a ring of LDS stages, the loads of a
                               K step requested several steps ahead (igemm1_kernel): -1 per layer (default), 0 never
                               (igemm2_kernel), n > 0 force tile / depth n of the table in csrc/conv_gemm1.hip            */
   int32_t wgrad_ring;      /* 1x1 stride-1 weight gradients with a ring of LDS-DMA stages (wgrad1_kernel): -1 per layer
                               (default), 0 never, n > 0 force ring depth n                                               */
-  int32_t igemm_bk32_3x3;  /* 3x3 layers on 128-row igemm2 tiles stage 32 instead of 64 channels per step (half the LDS: four
-                              workgroups per CU instead of two): 0 never, 1 where Ci == 64, 2 every such layer              */
   int32_t igemm8;          /* 3x3 stride-1 layers (forward / input gradient) with >= 256 output channels on the wave-staggered
                               multi-phase 256 x 256 kernel (igemm8_kernel, csrc/conv_igemm8.hip; bit-identical to igemm2's
-                              256 x 256 tile): 1 where the layer took the 256 x 256 tile (default), 2 wherever the shape
-                              allows, 0 never                                                                             */
-  int32_t spare[2];        /* must be 0                                                                                   */
+                              256 x 256 tile): 1 where the layer took the 256 x 256 tile, the ragged last round on the
+                              128-row kernel (default); 2 wherever the shape allows, unsplit; 0 never                     */
 } asm_tuning;
 void asm_tuning_defaults(asm_tuning* t);
 int asm_set_tuning(const asm_tuning* t);

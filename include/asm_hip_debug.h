@@ -32,24 +32,6 @@ int asm_conv2d_wgrad_plan(const asm_conv_desc* d, int32_t plan[6]);
 int asm_debug_last_conv_kernel(void);
 
 
-/* ---- measured-slower variant, kept for A/B runs (opt-in on the host: ASM_DENSE_BN=1) -------------------------------------
- * Not part of the drop-in boundary; DESIGN.md section 5.1 has the numbers (dense + BN in one launch: 27.61 vs 27.40 ms per
- * step).  (The factorised SK batch-norm reduction that lived here until round 3 is the default now: asm_hip.h.)
- *   asm_dense_bn_fwd:       ypre = bf16(x . w^T) [M][N]; training-mode batch norm of ypre over the M rows (statistics of
- *                           the bf16-rounded values, moving-statistics update, mean / invstd out), z = bn(ypre) [relu],
- *                           optional packed ReLU mask [M][N/8] -- one launch (== asm_dense_small + asm_bn_small_fwd).
- *   asm_dense_dgrad_bn_bwd: g = bf16(dy . wt^T) [M][N] (the input gradient of the NEXT dense layer: dy [M][lddy],
- *                           wt = its CRSK copy [N][ldwt], reduction K), then the backward of the batch norm that produced
- *                           that layer's input: dgamma, dbeta, dx [M][N] from g, ypre and the mask (NULL = no ReLU)
- *                           (== asm_dense_small + asm_bn_small_bwd).
- * Both need M <= asm_dense_bn_max_rows() (one workgroup owns every row of 32 channels). */
-int asm_dense_bn_max_rows(void);
-int asm_dense_bn_fwd(const void* x, int ldx, const void* w, int ldw, int M, int K, int N, const float* gamma,
-                     const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
-                     void* ypre, void* z, float* mean, float* invstd, int relu, uint8_t* relu_mask_out, void* stream);
-int asm_dense_dgrad_bn_bwd(const void* dy, int lddy, const void* wt, int ldwt, int M, int K, int N, const void* ypre,
-                           const uint8_t* relu_mask, const float* gamma, const float* mean, const float* invstd,
-                           float* dgamma, float* dbeta, void* dx, void* stream);
 #ifdef __cplusplus
 }
 #endif

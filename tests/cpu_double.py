@@ -385,9 +385,6 @@ class CpuDouble(object):
     return 0
 
   # ---- small dense layers (csrc/dense_small.hip) ----------------------------------------------------
-  def asm_dense_bn_max_rows(self):
-    return 256
-
   def asm_dense_small(self, p, ldp, q, ldq, M, N, K, out, ldo, out_f32, addend, stream):
     if K % 16 or ldp % 8 or ldq % 8 or ldp < K or ldq < K or ldo < N or ldo % 4:
       self._err = b'dense_small: bad arguments'
@@ -410,27 +407,6 @@ class CpuDouble(object):
     gv = T(dy, (M, ldy), 'bf16').float()[:, :Cout]
     T(dw, (Cout, ldw), 'f32')[:, :Cin] = gv.t() @ xv
     return 0
-
-  def asm_dense_bn_fwd(self, x, ldx, w, ldw, M, K, N, gamma, beta, eps, momentum, mm, mv, ypre, z, mean, invstd, relu,
-                       mask, stream):
-    if M <= 0 or M > 256 or N % 8 or K % 16:
-      self._err = b'dense_bn_fwd: bad shape'
-      return -1
-    rc = self.asm_dense_small(x, ldx, w, ldw, M, N, K, ypre, N, 0, None, stream)
-    if rc:
-      return rc
-    return self.asm_bn_small_fwd(ypre, z, M, N, gamma, beta, eps, momentum, mm, mv, mean, invstd, relu, mask, stream)
-
-  def asm_dense_dgrad_bn_bwd(self, dy, lddy, wt, ldwt, M, K, N, ypre, mask, gamma, mean, invstd, dgamma, dbeta, dx,
-                             stream):
-    if M <= 0 or M > 256 or N % 8 or K % 16:
-      self._err = b'dense_dgrad_bn_bwd: bad shape'
-      return -1
-    g = torch.empty((M, N), dtype=torch.bfloat16)
-    rc = self.asm_dense_small(dy, lddy, wt, ldwt, M, N, K, g.data_ptr(), N, 0, None, stream)
-    if rc:
-      return rc
-    return self.asm_bn_small_bwd(g.data_ptr(), ypre, mask, M, N, gamma, mean, invstd, dgamma, dbeta, dx, stream)
 
   def asm_bn_partials_compact(self, part, blocks, Cn, out, groups, stream):
     per = -(-blocks // groups)

@@ -43,6 +43,11 @@ def test_bench_two_ranks_dry_run_prints_one_valid_line():
   dp = r['dp']
   assert dp['world'] == 2 and dp['comm_dtype'] == 'bf16' and dp['buckets'] >= 2 and dp['bytes_per_step'] > 80e6
   assert 'DRY RUN' in r['data']
+  # the N > 1 line verifies itself: every rank reported in, with its own clock, and the exchange was measured at this N
+  assert dp['world_seen_by_backend'] == 2 and [q['rank'] for q in dp['ranks']] == [0, 1]
+  assert all(q['ms_per_step'] > 0 and q['host'] for q in dp['ranks'])
+  assert dp['rank_ms_per_step_min'] <= dp['rank_ms_per_step_max'] and dp['ms_per_step_without_exchange'] > 0
+  assert dp['exchange_ms_exposed'] is not None
 
 
 def test_bench_rejects_a_rank_count_mismatch():

@@ -1,6 +1,6 @@
 """Host-side fusion plumbing (CPU test double of the C ABI): every lazy / fused path of nn.py -- lazily masked shortcut
 gradients, the deferred + dual batch norm of a projection shortcut, the pooled gradient gathered by conv1's input
-gradient, the pending input gradient of the squeeze layers, the masked block sum at a BigLittle merge, the reordered tape
+gradient, the masked block sum at a BigLittle merge, the reordered tape
 of a projection block -- must give the gradients of the plain one-kernel-per-op path.  The double computes both in fp32
 with bf16 rounding where the kernels store bf16, so the two differ by rounding only."""
 import pytest
@@ -16,7 +16,6 @@ def _run(monkeypatch, fused: bool, name='a-r50-d', batch=2, size=64, gatherable=
     monkeypatch.setattr(ops, 'dgrad_pool_ok', lambda d: False)
   for k in ('ASM_POOL_FUSE', 'ASM_BN_DUAL', 'ASM_DENSE_SMALL', 'ASM_SK_FUSED'):
     util.set_knob(monkeypatch, k, '1' if fused else '0')
-  util.set_knob(monkeypatch, 'ASM_DENSE_BN', '1' if fused else '0')
   monkeypatch.setattr(nn, 'DEFER_BN', fused)
   monkeypatch.setattr(nn, 'LAZY_DZ', fused)
   _, pm = MP.make_pair(name, 'cpu', batch, size)
@@ -126,62 +125,6 @@ def test_biglittle_backward_on_two_streams_is_the_same_backward(cpu_double, monk
   waits = [e for e in log2 if e[0] == 'wait']
   assert waits.count(('wait', 'side', 'main')) == joins and waits.count(('wait', 'main', 'side')) == joins
   assert sum(1 for e in log2 if e == ('enter', 'side')) >= 3 + 3
-
-
-def test_projection_shortcut_on_its_own_stream_forks_and_joins_per_block(cpu_double, monkeypatch):
-  """ASM_SC_STREAM=1 (model._shortcut_stream): the forward pass of a projection shortcut runs inside a stream context of its
-  own, forked from the block's stream before it and joined back before the block-final batch norm that adds the two -- but
-  NOT for blocks that already run on the BigLittle branch stream (a fork off a forked stream, recorded in the forward pass,
-  crashes hipStreamEndCapture on ROCm 7.0).  On the CPU double with stand-in streams: identical logits and gradients, one
-  fork + one join per projection block on the main stream, none from the branch stream."""
-  import contextlib
-  from assembled_cnn_amd import model as pmodel
-
-  def run(sc):
-    log = []
-    main, side, scs = _FakeStream('main', log), _FakeStream('side', log), _FakeStream('sc', log)
-    cur = [main]
-
-    @contextlib.contextmanager
-    def ctx(s):
-      log.append(('enter', s.name))
-      cur.append(s)
-      try:
-        yield
-      finally:
-        cur.pop()
-    monkeypatch.setattr(pmodel, '_current_stream', lambda: cur[-1])
-    monkeypatch.setattr(pmodel, '_stream_ctx', ctx)
-    monkeypatch.setattr(pmodel.Model, '_branch_stream', lambda self, c, x: None if c.dry else side)
-    if sc:
-      def shortcut_stream(self, c, x, db):
-        return None if (c.dry or not c.training or cur[-1] is side) else scs
-      monkeypatch.setattr(pmodel.Model, '_shortcut_stream', shortcut_stream)
-    _, pm = MP.make_pair('a-r50-d', 'cpu', 2, 64)
-    _, x, _ = MP.inputs(2, 64)
-    lp = pm(x, True, use_resnet_d=True)
-    dl = torch.zeros((2, 1, 1, pm.ldc), dtype=torch.bfloat16)
-    dl[:, 0, 0, :1001] = (torch.softmax(lp.float(), 1) / 2).to(torch.bfloat16)
-    pm.backward(dl)
-    monkeypatch.undo()
-    return lp.clone(), pm.arena.g32.clone(), log
-
-  l0, g0, log0 = run(False)
-  l1, g1, log1 = run(True)
-  assert torch.equal(l0, l1) and torch.equal(g0, g1)
-  assert not [e for e in log0 if 'sc' in e]
-  forks = log1.count(('wait', 'sc', 'main'))
-  assert forks >= 3 and log1.count(('wait', 'main', 'sc')) == forks and log1.count(('enter', 'sc')) == forks
-  assert not [e for e in log1 if e[0] == 'wait' and set(e[1:]) == {'sc', 'side'}], 'no fork off the branch stream'
-  # every fork is closed before the next one opens
-  depth = 0
-  for e in log1:
-    if e == ('wait', 'sc', 'main'):
-      depth += 1
-      assert depth == 1
-    elif e == ('wait', 'main', 'sc'):
-      depth -= 1
-  assert depth == 0
 
 
 def test_capture_refuses_what_it_cannot_record(cpu_double):

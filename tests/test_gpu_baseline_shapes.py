@@ -256,9 +256,9 @@ def test_bn_partial_row_cap_is_a_per_call_knob(hip_lib, rows, monkeypatch):
   assert torch.allclose(s[1], (x.double() ** 2).sum(0), rtol=1e-5, atol=1e-2)
 
 
-@pytest.mark.parametrize('v2,parity', [(0, 1), (1, 0), (1, 1)], ids=['igemm-v1', 'generic-s2-dgrad', 'default'])
+@pytest.mark.parametrize('v2,parity', [(0, 1), (1, 0), (1, 1)], ids=['general-kernel', 'generic-s2-dgrad', 'parity-classes'])
 def test_igemm_variants_are_per_call_knobs(hip_lib, v2, parity, monkeypatch):
-  """ASM_IGEMM_V2 / ASM_DGRAD_PARITY flipped inside one process give identical bits (same accumulation order)."""
+  """ASM_IGEMM_MODE / ASM_DGRAD_PARITY flipped inside one process give identical bits (same accumulation order)."""
   from assembled_cnn_amd import ops
   N, H, W, Cn, K, k, stride = 4, 14, 14, 128, 256, 3, 2
   g = torch.Generator(device='cuda').manual_seed(3)
@@ -268,7 +268,7 @@ def test_igemm_variants_are_per_call_knobs(hip_lib, v2, parity, monkeypatch):
   ops.filter_transpose(w, wt, K, k, k, Cn)
   d = ops.make_conv_desc(N, H, W, Cn, K, k, k, stride)
   ref = ops.conv_dgrad(d, dy, wt)
-  util.set_knob(monkeypatch, 'ASM_IGEMM_V2', str(v2))
+  util.set_knob(monkeypatch, 'ASM_IGEMM_MODE', str(1 - v2))
   util.set_knob(monkeypatch, 'ASM_DGRAD_PARITY', str(parity))
   out = ops.conv_dgrad(d, dy, wt)
   dxn = torch.empty_like(ref)

@@ -37,7 +37,7 @@ def test_config1_literally_r50v1_eval_64_images_224(hip_lib):
   resnet_version=1, eval mode with perturbed moving statistics, 64 seeded uint8 images at 224 x 224: every named tap,
   the logits, and top-1 agreement >= 63/64."""
   st = {}
-  mp.check_forward('r50v1', 'cuda', 64, 224, False, 4e-2, stats=st)
+  mp.check_forward('r50v1', 'cuda', 64, 224, False, 4e-2, stats=st, golden='config1_r50v1_eval_b64_224')
   assert st['rows'] == 64 and st['top1_agree'] >= 63, st
   assert abs(st['loss_product'] - st['loss_oracle']) <= 2e-2 * abs(st['loss_oracle']), st
 
@@ -47,7 +47,7 @@ def test_config3_forward_at_batch_256_224_vs_oracle(hip_lib):
   statistics over all 256 images), batch 256 at 224 x 224 -- taps, logits and loss against the oracle's forward
   (forward only on the CPU side: the autograd graph of a batch-256 step does not fit a host budget)."""
   st = {}
-  mp.check_forward('a-r50-d', 'cuda', 256, 224, True, 6e-2, stats=st)
+  mp.check_forward('a-r50-d', 'cuda', 256, 224, True, 6e-2, stats=st, golden='config3_a-r50-d_train_b256_224')
   assert st['rows'] == 256
   assert abs(st['loss_product'] - st['loss_oracle']) <= 2e-2 * abs(st['loss_oracle']), st
 
@@ -56,7 +56,8 @@ def test_config4_shard_at_size_512_images_mixup_label_smoothing(hip_lib):
   """BASELINE config 4, one GPU's shard literally: 2 x 256 uint8 images at 224 x 224 -> mixup type 1 (lambda ~
   Beta(0.2, 0.2), seed 4) -> 256 images, label smoothing 0.1, Assemble-ResNet-50 + D in training mode: the mixed input,
   the mixed targets, the logits and the loss against the oracle's forward."""
-  rep = mp.check_train_forward_at_size('a-r50-d', 'cuda', 512, 224, mixup_type=1, label_smoothing=0.1)
+  rep = mp.check_train_forward_at_size('a-r50-d', 'cuda', 512, 224, mixup_type=1, label_smoothing=0.1,
+                                       golden='config4_a-r50-d_mixup1_ls_512in_224')
   assert rep['batch'] == 256
 
 
@@ -64,7 +65,8 @@ def test_config5_shard_at_size_128_images_kd(hip_lib):
   """BASELINE config 5, one GPU's shard literally: Assemble-ResNet-152 (alpha 1, beta 2) at batch 128, 224 x 224, with the
   KD loss on N(0, 3^2) teacher logits (kd_temp 1): forward + loss against the oracle, logits bound calibrated against the
   oracle's own bf16-vs-fp32 rounding noise (70 blocks at random init amplify rounding beyond any fixed tolerance)."""
-  rep = mp.check_train_forward_at_size('a-r152', 'cuda', 128, 224, kd_temp=1.0, noise_floor=True, loss_tol=3e-2)
+  rep = mp.check_train_forward_at_size('a-r152', 'cuda', 128, 224, kd_temp=1.0, noise_floor=True, loss_tol=3e-2,
+                                       golden='config5_a-r152_kd_b128_224')
   assert rep['batch'] == 128
 
 
@@ -108,6 +110,14 @@ def test_backward_tape_vs_autograd_smoke(hip_lib, name):
   mp.check_backward(name, 'cuda', 16, 64)
 
 
+def test_forward_backward_literal_zero_gamma(hip_lib):
+  """config 2 - 4's recipe literally: zero_gamma=True with the block-final gammas at 0: forward
+  (every tap, logits) and backward (per-variable gradients; the variables inside a switched-off branch must get an exactly
+  zero gradient, as in the oracle) of the whole Assemble-ResNet-50 + D"""
+  mp.check_forward('a-r50-d', 'cuda', 16, 64, True, 6e-2, damp=None)
+  mp.check_backward('a-r50-d', 'cuda', 16, 64, damp=None)
+
+
 def test_train_steps_assemble_mixup_ls(hip_lib):
   mp.check_train_steps('a-r50-d', 'cuda', 8, 64, 3, dict(base_learning_rate=0.001, weight_decay=1e-4, label_smoothing=0.1),
                        mixup_type=1, rel_tol=3e-2)
@@ -149,6 +159,51 @@ def test_step_is_deterministic(hip_lib):
     torch.cuda.synchronize()
     outs.append((tr.model.arena.w32.clone(), tr.last['loss_rows'].clone()))
   assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_self_recording_trainer_alternating_shapes(hip_lib):
+  """A default (self-recording) trainer through what an epoch does to it: steps at one resolution until it records itself,
+  an evaluation batch at another resolution, replays, one training batch of other shapes (the recording is dropped, the step
+  runs eagerly), then the first shapes again until it records again.  A trainer that never records takes the same batches:
+  every cross entropy, the evaluation predictions and the final weights must be bit-identical, and the calibration must
+  time eager steps only."""
+  from assembled_cnn_amd.train import HParams, Trainer
+  img_a, _, lab_a = mp.inputs(8, 64, seed=1)
+  img_b, _, lab_b = mp.inputs(6, 96, seed=2)
+  img_e, x_e, lab_e = mp.inputs(8, 96, seed=3)
+  plan = ['a'] * 5 + ['eval', 'a', 'b', 'a', 'a', 'a', 'a', 'eval', 'b', 'a']
+  runs = []
+  for recorded in (None, False):
+    hp = HParams(resnet_version=2, use_sk_block=True, anti_alias_type='sconv', anti_alias_filter_size=3, use_resnet_d=True,
+                 zero_gamma=True, learning_rate_decay_type='fixed', base_learning_rate=0.01, batch_size=8)
+    tr = Trainer(hp, seed=3, device='cuda', recorded=recorded)
+    if recorded is None:
+      res = tr.calibrate_streams(lambda: tr.train_step(img_a.cuda(), lab_a.cuda()), steps=3)
+      assert tr.step_mode == 'eager' and tr._graph is None, 'calibrate_streams must time eager steps'
+      tr2 = Trainer(hp, seed=3, device='cuda', recorded=recorded)      # (the calibration took steps: start over, same streams)
+      tr2.set_streams(res['chosen'] == 'side streams')
+      tr = tr2
+      keep = res['chosen'] == 'side streams'
+    else:
+      tr.set_streams(keep)
+    ces, modes, preds = [], [], []
+    for what in plan:
+      if what == 'eval':
+        preds.append(tr.eval_step(x_e.cuda(), lab_e.cuda()).clone())
+      else:
+        im, lb = (img_a, lab_a) if what == 'a' else (img_b, lab_b)
+        tr.train_step(im.cuda(), lb.cuda())
+        ces.append(float(tr.cross_entropy()))
+      modes.append(tr.step_mode)
+    torch.cuda.synchronize()
+    runs.append((ces, [p.cpu() for p in preds], tr.model.arena.w32.clone(), modes))
+  (ce0, pr0, w0, modes0), (ce1, pr1, w1, modes1) = runs
+  assert 'recorded' in modes0[:5] and modes0[6] == 'recorded', modes0          # recorded itself, survived the evaluation batch
+  assert modes0[7] == 'eager' and modes0[11] == 'recorded', modes0            # other shapes drop it; it records again
+  assert all(m == 'eager' for m in modes1)
+  assert ce0 == ce1, (ce0, ce1)
+  assert all(torch.equal(a, b) for a, b in zip(pr0, pr1))
+  assert torch.equal(w0, w1)
 
 
 def test_full_size_layer_shapes_run(hip_lib):

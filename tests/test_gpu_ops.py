@@ -515,62 +515,11 @@ def test_dense_layers_route_through_dense_small_and_match_the_conv_kernels(hip_l
   _close(outs['1'][2], outs['0'][2], name='dense dgrad')
 
 
-@pytest.mark.parametrize('M,K,N,relu', [(256, 512, 256, True), (256, 64, 32, True), (128, 256, 128, True), (37, 48, 40, False),
-                                        (256, 128, 64, False)])
-def test_dense_bn_fused_equals_conv_plus_bn_small(hip_lib, M, K, N, relu, monkeypatch):
-  """fc + training-mode BN (+ReLU) in one launch == asm_conv2d_fprop + asm_bn_small_fwd; and its backward twin
-  (input gradient of the next dense layer + BN backward) == asm_conv2d_dgrad + asm_bn_small_bwd."""
-  from assembled_cnn_amd import ops
-  util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', '1')
-  util.set_knob(monkeypatch, 'ASM_DENSE_BN', '1')
-  x = _rand((M, 1, 1, K), 1).cuda()
-  w = _rand((N, 1, 1, K), 2, scale=K ** -0.5).cuda()
-  gamma = (torch.rand(N, generator=torch.Generator().manual_seed(2)) + 0.5).cuda()
-  beta = (torch.randn(N, generator=torch.Generator().manual_seed(3)) * 0.1).cuda()
-  mm, mv = torch.zeros(N).cuda(), torch.ones(N).cuda()
-  d = ops.make_conv_desc(M, 1, 1, K, N, 1, 1, 1)
-  assert ops.dense_bn_ok(M, K, N)
-  ypre, z, mask, mean, invstd = ops.dense_bn_fwd(d, x, w, gamma, beta, 1e-5, 0.997, mm, mv, relu, True)
-  # the two-launch path
-  util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', '0')
-  y2, _ = ops.conv_fprop(d, x, w, False)
-  mm2, mv2 = torch.zeros(N).cuda(), torch.ones(N).cuda()
-  z2, mask2, mean2, invstd2 = ops.bn_small_fwd(y2, M, N, gamma, beta, 1e-5, 0.997, mm2, mv2, relu, True)
-  _close(ypre, y2.float().cpu(), name='dense_bn ypre')
-  assert torch.allclose(mean, mean2, rtol=1e-3, atol=2e-3) and torch.allclose(invstd, invstd2, rtol=2e-3)
-  assert torch.allclose(mm, mm2, rtol=1e-3, atol=1e-5) and torch.allclose(mv, mv2, rtol=1e-3)
-  _close(z, z2.float().cpu(), rel=8e-3, name='dense_bn z')      # 1-ulp flips of ypre move the batch statistics slightly
-  # fp32 reference on the kernel's own bf16 product
-  yf = ypre.float().cpu().view(M, N)
-  mu, var = yf.mean(0), yf.var(0, unbiased=False)
-  ref = (yf - mu) / torch.sqrt(var + 1e-5) * gamma.cpu() + beta.cpu()
-  _close(z.view(M, N), ref.clamp(min=0) if relu else ref, name='dense_bn z vs fp32')
-  if relu:
-    bits = ((mask.cpu().to(torch.int32)[..., None] >> torch.arange(8, dtype=torch.int32)) & 1).view(M, N).bool()
-    zf = z.float().cpu().view(M, N)
-    assert bool((bits == (zf > 0)).all()) or float((bits != (zf > 0)).float().mean()) < 1e-3
-  # backward: next layer = dense N -> K2
-  K2 = 2 * K if 2 * K <= 1024 else 1024
-  w2 = _rand((K2, 1, 1, N), 5, scale=N ** -0.5).cuda()
-  wt2 = torch.zeros((N, 1, 1, K2), dtype=BF, device='cuda')
-  ops.filter_transpose(w2, wt2, K2, 1, 1, N)
-  dy2 = _rand((M, 1, 1, K2), 6).cuda()
-  d2 = ops.make_conv_desc(M, 1, 1, N, K2, 1, 1, 1)
-  dg, db = torch.empty(N).cuda(), torch.empty(N).cuda()
-  dx = ops.dense_dgrad_bn_bwd(d2, dy2, wt2, ypre, mask if relu else None, gamma, mean, invstd, dg, db)
-  g2 = ops.conv_dgrad(d2, dy2, wt2)                     # ASM_DENSE_SMALL=0: the implicit-GEMM input gradient
-  dg2, db2 = torch.empty(N).cuda(), torch.empty(N).cuda()
-  dx2 = ops.bn_small_bwd(g2, ypre, mask if relu else None, M, N, gamma, mean, invstd, dg2, db2)
-  _close(dx, dx2.float().cpu(), rel=6e-3, name='dense_dgrad_bn_bwd dx')
-  assert torch.allclose(dg, dg2, rtol=2e-3, atol=2e-2) and torch.allclose(db, db2, rtol=2e-3, atol=2e-2)
-
-
 def test_sk_attention_path_fused_vs_unfused_whole_unit(hip_lib, monkeypatch):
   """One SK bottleneck network step with the squeeze layers on csrc/dense_small.hip vs on the convolution kernels:
   logits and every parameter gradient agree to bf16 noise."""
   from tests import model_parity as MP
   res = {}
-  util.set_knob(monkeypatch, 'ASM_DENSE_BN', '1')      # the one-launch fc + batch norm forms too (opt-in)
   for knob in ('1', '0'):
     util.set_knob(monkeypatch, 'ASM_DENSE_SMALL', knob)
     om, pm = MP.make_pair('a-r50', 'cuda', 8, 64)

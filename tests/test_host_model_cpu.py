@@ -21,14 +21,21 @@ def test_backward_tape_vs_autograd(cpu_double, name):
   mp.check_backward(name, 'cpu', 8, 64)
 
 
+def test_forward_backward_literal_zero_gamma(cpu_double):
+  """the recipe's zero_gamma=True with the block-final gammas left at 0 (not the 0.25 the other whole-model tests damp them
+  to): every residual branch is switched off in the forward pass and receives an exactly-zero gradient"""
+  mp.check_forward('a-r50-d', 'cpu', 4, 64, True, 6e-2, damp=None)
+  mp.check_backward('a-r50-d', 'cpu', 4, 64, damp=None)
+
+
 def test_train_steps_mixup_label_smoothing(cpu_double):
   mp.check_train_steps('a-r50', 'cpu', 4, 64, 3, dict(base_learning_rate=0.001, weight_decay=1e-4, label_smoothing=0.1),
-                       mixup_type=1, rel_tol=3e-2)
+                       mixup_type=1, rel_tol=3e-2, state_tol=5e-2, mom_cos=0.4)     # (batch 4 at 64 x 64: 16 - 64 samples per channel in the deep stages)
 
 
 def test_train_steps_kd(cpu_double):
   mp.check_train_steps('r50v1', 'cpu', 4, 64, 2, dict(base_learning_rate=0.001, weight_decay=1e-4), kd_temp=1.0,
-                       rel_tol=3e-2)
+                       rel_tol=3e-2, state_tol=5e-2, mom_cos=0.4)
 
 
 def test_variable_names_counts_and_flag_errors(cpu_double):
