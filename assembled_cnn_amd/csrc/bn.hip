@@ -295,7 +295,7 @@ __global__ __launch_bounds__(16 * FL) void bn_bwd_finalize_kernel(const float* _
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* dgamma,
                                                               float* dbeta, float* coefA, float* coefB,
-                                                              float* coefC) {
+                                                              float* coefC, int raw) {
   __shared__ double red[2][FL][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cx;
@@ -310,9 +310,10 @@ __global__ __launch_bounds__(16 * FL) void bn_bwd_finalize_kernel(const float* _
       db += red[0][r][cx];
       dg += red[1][r][cx];
     }
+    const double g = gamma[ch], is = invstd[ch], mu = mean[ch];
+    if (raw) dg = is * (dg - mu * db);      // partials of (sum dz, sum dz * y) from an input-gradient epilogue: -> sum dz * xhat
     dbeta[ch] = (float)db;
     dgamma[ch] = (float)dg;
-    const double g = gamma[ch], is = invstd[ch], mu = mean[ch];
     const double A = g * is;
     const double B = -g * is * is * dg / (double)M;
     const double Cc = -g * is * db / (double)M - B * mu;
@@ -969,8 +970,19 @@ extern "C" int asm_bn_bwd_finalize(const float* partial, int blocks, int M, int 
   ASM_REQUIRE(partial && gamma && mean && invstd && dgamma && dbeta && coefA && coefB && coefC && blocks > 0,
               "bn_bwd_finalize: bad arguments");
   ASM_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(16 * FL), 0, (hipStream_t)stream, partial, blocks,
-                     M, C, gamma, mean, invstd, dgamma, dbeta, coefA, coefB, coefC);
+                     M, C, gamma, mean, invstd, dgamma, dbeta, coefA, coefB, coefC, 0);
   ASM_CHECK_LAUNCH("bn_bwd_finalize");
+  return ASM_OK;
+}
+
+extern "C" int asm_bn_bwd_finalize_raw(const float* partial, int blocks, int M, int C, const float* gamma,
+                                       const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                       float* coefA, float* coefB, float* coefC, void* stream) {
+  ASM_REQUIRE(partial && gamma && mean && invstd && dgamma && dbeta && coefA && coefB && coefC && blocks > 0,
+              "bn_bwd_finalize_raw: bad arguments");
+  ASM_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(16 * FL), 0, (hipStream_t)stream, partial, blocks,
+                     M, C, gamma, mean, invstd, dgamma, dbeta, coefA, coefB, coefC, 1);
+  ASM_CHECK_LAUNCH("bn_bwd_finalize_raw");
   return ASM_OK;
 }
 

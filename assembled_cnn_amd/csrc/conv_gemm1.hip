@@ -282,7 +282,7 @@ constexpr AutoRow kAuto[] = {
 
 int auto_cfg(const IGemmArgs& a, bool stats) {
   if (a.so != 1 || a.sd != 1 || a.y_strided || a.pool_dy) return 0;      // the stride-1 layers the sweep covered
-  const int kind = stats ? 0 : (a.tsign < 0 ? (a.addend ? 2 : 1) : -1);
+  const int kind = a.tsign < 0 ? (a.addend ? 2 : 1) : (stats ? 0 : -1);     // (an input gradient with statistics: asm_conv2d_dgrad_bnred)
   for (const AutoRow& r : kAuto)
     if (r.kind == kind && r.M == a.M && r.Ci == a.Ci && r.Co == a.Co) return r.code;
   return 0;

@@ -1128,6 +1128,7 @@ static int fprop_impl(const asm_conv_desc* d, const void* x, const void* w, void
   a.y_base = a.y_img_pitch = a.y_row_pitch = a.y_pix_pitch = 0;
   a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_relu = relu;
   a.pool_dy = nullptr; a.pool_k = a.pool_stride = a.pool_pad = a.pool_Hp = a.pool_Wp = a.pool_cv = a.pool_H = 0;
+  a.red_y = nullptr; a.red_mask = nullptr;
   a.x_img_pitch = (int)img_pitch(d); a.x_row_pitch = row_pitch(d); a.x_pix_pitch = pix_pitch(d);
   a.w_row_pitch = d->R * d->S * d->C;
   a.m_tile0 = 0;
@@ -1151,8 +1152,14 @@ struct PoolAdd {
   const void* dy;
   int k, stride, pad, Hp, Wp, cv;
 };
+struct BnRed {      // asm_conv2d_dgrad_bnred: batch-norm backward sums of the gradient this launch writes
+  const void* y;
+  const uint8_t* mask;
+  float* partial;
+};
 static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
-                      const uint8_t* addend_mask, void* dx, void* stream, const PoolAdd* pool = nullptr);
+                      const uint8_t* addend_mask, void* dx, void* stream, const PoolAdd* pool = nullptr,
+                      const BnRed* red = nullptr);
 // conv_dgrad_s2.hip: the one-launch 3x3 / stride-2 input gradient (returns 1 when the layer is not one it covers)
 int asm_dgrad_s2_try(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend, const uint8_t* addend_mask,
                      void* dx, void* stream);
@@ -1185,8 +1192,24 @@ extern "C" int asm_conv2d_dgrad_pooled(const asm_conv_desc* d, const void* dy, c
   return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream, &pa);
 }
 
+extern "C" int asm_conv2d_dgrad_bnred_blocks(const asm_conv_desc* d) {
+  if (!d) return ASM_EINVAL;
+  return cdiv(d->N * d->H * d->W, STATS_BM);
+}
+
+extern "C" int asm_conv2d_dgrad_bnred(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                                      const uint8_t* addend_mask, const void* bn_y, const uint8_t* bn_relu_mask,
+                                      float* partial, void* dx, void* stream) {
+  ASM_REQUIRE(d && bn_y && partial, "conv dgrad_bnred: null pointer");
+  ASM_REQUIRE(!addend_mask || addend, "conv dgrad_bnred: a mask needs its addend");
+  if (d->stride != 1 || d->C % 8)
+    ASM_FAIL(ASM_ENOTSUP, "conv dgrad_bnred: stride-1 convolutions with C %% 8 == 0 only (stride %d, C %d)", d->stride, d->C);
+  const BnRed r = {bn_y, bn_relu_mask, partial};
+  return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream, nullptr, &r);
+}
+
 static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
-                      const uint8_t* addend_mask, void* dx, void* stream, const PoolAdd* pool) {
+                      const uint8_t* addend_mask, void* dx, void* stream, const PoolAdd* pool, const BnRed* red) {
   if (int e = check_desc(d)) return e;
   ASM_REQUIRE(dy && wt && dx, "conv dgrad: null pointer");
   ASM_REQUIRE(d->K % 8 == 0, "conv dgrad: K=%d must be a multiple of 8 (pad dy)", d->K);
@@ -1195,7 +1218,9 @@ static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, co
   const int64_t dyelems = (int64_t)d->N * d->Ho * d->Wo * d->K;
   ASM_REQUIRE(dyelems * 2 < (int64_t)ASM_OOB, "conv dgrad: dy larger than 2 GiB");
   IGemmArgs a;
-  a.x = dy; a.w = wt; a.y = dx; a.addend = addend; a.addend_mask = addend_mask; a.stats = nullptr;
+  a.x = dy; a.w = wt; a.y = dx; a.addend = addend; a.addend_mask = addend_mask;
+  a.stats = red ? red->partial : nullptr;
+  a.red_y = red ? red->y : nullptr; a.red_mask = red ? red->mask : nullptr;
   a.x_bytes = (unsigned)(dyelems * 2);
   a.w_bytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
   a.M = d->N * d->H * d->W;
@@ -1265,5 +1290,5 @@ static int dgrad_impl(const asm_conv_desc* d, const void* dy, const void* wt, co
   }
   // generic form: p = (h + pad - r) / stride  when divisible
   a.so = 1; a.sd = d->stride; a.tsign = -1; a.pad = -d->pad; a.pad_w = a.pad;
-  return launch(a, false, false, (hipStream_t)stream);
+  return launch(a, false, red != nullptr, (hipStream_t)stream);
 }

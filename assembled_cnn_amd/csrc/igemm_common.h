@@ -37,6 +37,12 @@ struct IGemmArgs {
   int bn_relu;
   // average-pool backward folded into the epilogue of a 1x1 stride-1 input gradient (asm_conv2d_dgrad_pooled): the block
   // input of a projection bottleneck is read by conv1 and by the shortcut's average pool; dx += avgpool_bwd(pool_dy)
+  // batch-norm backward sums in the epilogue of an input gradient (asm_conv2d_dgrad_bnred): the tensor this launch writes is the
+  // gradient dout of a conv -> BN [-> + shortcut] [-> ReLU] output; with red_y the STATS partials are not (sum y, sum y^2) but
+  // (sum dz, sum dz * y), dz = bf16(dout) * [mask bit], y = that layer's pre-BN convolution output at the same element --
+  // what rowreduce_kernel<1> (bn.hip) reads dout and y again for.  asm_bn_bwd_finalize_raw turns sum dz * y into sum dz * xhat.
+  const void* red_y;           // bf16 [M][ldy] or null
+  const uint8_t* red_mask;     // packed ReLU mask [M][ldy / 8] or null (no ReLU: dz = dout)
   const void* pool_dy;   // bf16 [N][pool_Hp][pool_Wp][Co] or null
   int pool_k, pool_stride, pool_pad, pool_Hp, pool_Wp, pool_cv, pool_H;
 };
@@ -242,6 +248,24 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
     for (int q = 0; q < SG; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[q][e] = ss[q][e] = 0.f;
+    // batch-norm backward sums (p.red_y): this thread's y vector and ReLU-mask byte of pass ps, fetched one pass ahead
+    u32x4 ry_nxt = {0u, 0u, 0u, 0u};
+    unsigned rmk_nxt = 0xffu;
+    auto red_fetch = [&](int ps_, u32x4& yv, unsigned& mk) {
+      const int row = ps_ * RPO + orow;
+      const int m = tile_m * BM + row;
+      const u32x4 z4 = {0u, 0u, 0u, 0u};
+      yv = z4;
+      mk = 0xffu;
+      if (m < p.M && n0 < co8) {
+        const size_t ro = row_off(row, m);
+        yv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.red_y) + ro);
+        if (p.red_mask) mk = (unsigned)p.red_mask[ro >> 3];
+      }
+    };
+    if constexpr (STATS) {
+      if (p.red_y) red_fetch(0, ry_nxt, rmk_nxt);
+    }
 #pragma unroll
     for (int ps = 0; ps < OP; ++ps) {
       if constexpr (PF_ON) {
@@ -252,6 +276,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       }
       const int row = ps * RPO + orow;
       const int m = tile_m * BM + row;
+      u32x4 ry = ry_nxt;
+      unsigned rmk = rmk_nxt;
+      if constexpr (STATS) {
+        if (p.red_y && ps + 1 < OP) red_fetch(ps + 1, ry_nxt, rmk_nxt);   // one pass ahead: lands under this pass's stores
+      }
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
       if (m < p.M && n0 < co8) {
         const size_t yoff = row_off(row, m);
@@ -300,10 +329,21 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         constexpr int PPG = OP / SG;   // passes per statistics group (rows are pass-major)
         float f[8];
         unpack8(v, f);
+        if (p.red_y) {      // batch-norm backward sums of the gradient just written (rows past M: v = 0, ry = 0)
+          float fy[8];
+          unpack8(ry, fy);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          s[ps / PPG][e] += f[e];
-          ss[ps / PPG][e] += f[e] * f[e];
+          for (int e = 0; e < 8; ++e) {
+            const float dz = ((rmk >> e) & 1u) ? f[e] : 0.f;
+            s[ps / PPG][e] += dz;
+            ss[ps / PPG][e] += dz * fy[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s[ps / PPG][e] += f[e];
+            ss[ps / PPG][e] += f[e] * f[e];
+          }
         }
       }
     }

@@ -118,6 +118,8 @@ SIGNATURES = {
     'asm_conv2d_dgrad': (_I, [_D, _P, _P, _P, _P, _P]),
     'asm_conv2d_dgrad_masked': (_I, [_D, _P, _P, _P, _P, _P, _P]),
     'asm_conv2d_dgrad_pooled': (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'asm_conv2d_dgrad_bnred_blocks': (_I, [_D]),
+    'asm_conv2d_dgrad_bnred': (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_conv2d_wgrad_workspace_bytes': (_Z, [_D]),
     'asm_conv2d_wgrad': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
     'asm_filter_transpose': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -134,6 +136,7 @@ SIGNATURES = {
     'asm_bn_apply': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'asm_bn_bwd_reduce': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'asm_bn_bwd_finalize': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asm_bn_bwd_finalize_raw': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asm_bn_bwd_apply': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     'asm_maxpool3x3s2_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'asm_maxpool3x3s2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

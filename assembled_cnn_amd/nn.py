@@ -323,7 +323,7 @@ class Var(object):
   that dominate (the input gradient of the next 1x1 convolution, which adds it in its epilogue, and the batch-norm
   backward of a projection shortcut) read (dy, mask) directly, so dz is never written; anything else just reads
   ``.grad``, which materialises it."""
-  __slots__ = ('_data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'bn_ctx',
+  __slots__ = ('_data', 'shape', '_grad', 'grad_mask', 'grad_owned', 'needs_grad', 'bn_ctx', 'red_ctx', 'red',
                'pre_dy', 'deferred', 'pool_grad')
 
   def __init__(self, data, shape=None, needs_grad=True):
@@ -346,6 +346,14 @@ class Var(object):
     # avgpool_bwd(dpool); a 1x1 stride-1 convolution reading this activation gathers it in its input-gradient epilogue
     # (asm_conv2d_dgrad_pooled), anything else reads .grad, which scatters it through asm_avgpool_bwd
     self.pool_grad = None
+    # batch-norm backward sums in the producing input gradient's epilogue (asm_conv2d_dgrad_bnred).  red_ctx, set in the forward
+    # pass on the output of a conv -> BN [-> + shortcut] [-> ReLU] layer: (its pre-BN convolution output y, its packed ReLU mask
+    # or None) -- what a convolution that reads this activation needs to reduce (sum dz, sum dz * y) while it writes the
+    # activation's gradient.  red, set by that convolution's backward: (partials, the gradient tensor they were reduced from).
+    # Anything that changes the gradient afterwards (another fan-in term, a lazy mask) drops it; the layer's own backward uses it
+    # only if the gradient it finds IS that tensor, unmasked -- otherwise it runs its reduce pass as before.
+    self.red_ctx = None
+    self.red = None
 
   @property
   def data(self):
@@ -364,9 +372,11 @@ class Var(object):
       self._grad = ops.mask_apply(self._grad, self.grad_mask)
       self.grad_mask = None
       self.grad_owned = True
+      self.red = None
     if self.pool_grad is not None:
       dp, k, stride, pad, cv = self.pool_grad
       self.pool_grad = None
+      self.red = None
       if self._grad is None:
         self._grad = ops.avgpool_bwd(dp, self.shape, k, stride, pad, cv)
       elif self.grad_owned:
@@ -380,6 +390,7 @@ class Var(object):
   def grad(self, g):
     self._grad = g
     self.grad_mask = None
+    self.red = None
 
   def take_masked_grad(self):
     """-> (gradient tensor, packed mask or None) without materialising the product.  A pooled contribution nobody
@@ -401,6 +412,7 @@ def accum_grad(v: Var, g: torch.Tensor, owned: bool, mask: Optional[torch.Tensor
   """v.grad += g [* mask].  ``owned`` says whether g may later be updated in place by us."""
   if not v.needs_grad:
     return
+  v.red = None           # the gradient changes: sums reduced from an earlier form of it are void
   if mask is not None:
     if v._grad is None:
       v._grad, v.grad_mask, v.grad_owned = g, mask, False
@@ -593,18 +605,27 @@ class ConvKernel(object):
                addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None, pool=None
                ) -> Optional[torch.Tensor]:
     """dW into the gradient arena; returns dx [+ addend [where addend_mask]] (or None)."""
+    return self.backward_red(d, x, dy, need_dx, addend, addend_mask, pool, None)[0]
+
+  def backward_red(self, d, x: torch.Tensor, dy: torch.Tensor, need_dx: bool, addend=None, addend_mask=None, pool=None,
+                   red_ctx=None):
+    """backward() that also reduces the batch-norm backward sums of the layer that produced this convolution's input, in the
+    epilogue that writes dx (``red_ctx`` = that layer's (pre-BN output, ReLU mask or None), nn.Var.red_ctx) -> (dx, partials or
+    None).  Falls back to the plain input gradient (partials None) wherever the fused form does not apply."""
     a = self.arena
     self.wgrad_streamed(d, x, dy)
     if self.stem:
-      return None
+      return None, None
     if not need_dx:
-      return None
+      return None, None
     if addend_mask is not None and (d.stride != 1 or d.C % 8) and not ops.dgrad_s2_ok(d):
       addend, addend_mask = ops.mask_apply(addend, addend_mask), None     # the strided forms take a plain addend
+    dd = d
     if self.kpad != self.cout:  # dy carries kpad channels (zero padded)
       dd = ops.make_conv_desc(d.N, d.H, d.W, d.C, self.kpad, d.R, d.S, d.stride, pad=d.pad, Ho=d.Ho, Wo=d.Wo)
-      return ops.conv_dgrad(dd, dy, a.wt_view(self._wts), addend, addend_mask, pool)
-    return ops.conv_dgrad(d, dy, a.wt_view(self._wts), addend, addend_mask, pool)
+    if red_ctx is not None and pool is None and ops.dgrad_bnred_ok(dd):
+      return ops.conv_dgrad_bnred(dd, dy, a.wt_view(self._wts), addend, addend_mask, red_ctx[0], red_ctx[1])
+    return ops.conv_dgrad(dd, dy, a.wt_view(self._wts), addend, addend_mask, pool), None
 
 
 class BatchNorm(object):
@@ -690,6 +711,10 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
     out.deferred = (y, M, Cn, scale, shift)
   if taped and ctx.training and not small and not relu and residual is None:
     out.bn_ctx = (y, gamma, mean, invstd, bn, M, Cn)
+  # (not for a block-final layer whose projection shortcut's batch norm shares its backward -- bn_bwd_dual reduces both)
+  if (taped and ctx.training and not small and out_t is not None and Cn % 8 == 0 and (mask_t is not None or not relu)
+      and not (residual is not None and residual.bn_ctx is not None and dual_bn_on())):
+    out.red_ctx = (y, mask_t if relu else None)
 
   if ctx.tape is not None:
     x_t = x.data
@@ -736,7 +761,14 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
                                               (rc[1], rc[2], rc[3], a.g(sc_bn.gamma), a.g(sc_bn.beta)))
         dz = None
       else:
-        dy, dz = ops.bn_bwd(dout, y, bmask, brelu, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), want_dz)
+        # the input gradient that wrote dout may have reduced (sum dz, sum dz * y) already (Var.red)
+        raw = None
+        if (out.red is not None and out.red[1] is dout and in_mask is None and out.red_ctx is not None
+            and out.red_ctx[1] is bmask):
+          raw = out.red[0]
+        out.red = None
+        dy, dz = ops.bn_bwd(dout, y, bmask, brelu, M, Cn, gamma, mean, invstd, a.g(bn.gamma), a.g(bn.beta), want_dz,
+                            raw_part=raw)
       a.notify_grad(bn.gamma)
       if residual is not None:
         if dual:
@@ -753,10 +785,13 @@ def conv_bn(ctx: Ctx, x: Var, conv: ConvKernel, bn: BatchNorm, stride: int, relu
       if x.pool_grad is not None:
         x.grad                                          # (not gatherable here) scatter it now
       xg, xmask = x.take_masked_grad()
-      # fan-in add (and a pending average-pool backward) fused into the dgrad epilogue
-      dx = conv.backward(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask, pool=pool)
+      # fan-in add (and a pending average-pool backward) fused into the dgrad epilogue; and, when x is itself the output of
+      # a conv -> BN layer, the reduce pass of THAT batch norm's backward (x.red_ctx)
+      dx, part = conv.backward_red(d, x_t, dy, x.needs_grad, addend=xg, addend_mask=xmask, pool=pool, red_ctx=x.red_ctx)
       if dx is not None:
         x.grad, x.grad_owned = dx, True
+        if part is not None:
+          x.red = (part, dx)
       out.grad = None
     ctx.record(bwd)
   return out
@@ -877,9 +912,12 @@ class SKUnit(object):
                            grad_stats, mask_stats if factor else None)
         s.grad = None
         a.notify_grad(bn.gamma)
-        dx = conv.backward(d, x_t, dy, x.needs_grad, addend=x.grad)     # fan-in add fused into the dgrad epilogue
+        # fan-in add fused into the dgrad epilogue, and the reduce pass of conv1's batch-norm backward (x.red_ctx)
+        dx, part = conv.backward_red(d, x_t, dy, x.needs_grad, addend=x.grad, red_ctx=x.red_ctx)
         if dx is not None:
           x.grad, x.grad_owned = dx, True
+          if part is not None:
+            x.red = (part, dx)
         v.grad = None
       ctx.record(bwd)
     return v

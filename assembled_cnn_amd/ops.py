@@ -304,6 +304,29 @@ def dgrad_s2_ok(d: ConvDesc) -> bool:
           and d.Ho % 8 == 0 and d.Wo % 8 == 0)
 
 
+def dgrad_bnred_ok(d: ConvDesc) -> bool:
+  """should this layer's input gradient reduce the batch-norm backward sums of its input (asm_conv2d_dgrad_bnred)?  The call
+  takes any stride-1 convolution with C % 8 == 0; the default (ASM_BN_RED=1) uses it for the 1x1 layers -- the block-final
+  batch norms, 4 x the channels of the others -- ASM_BN_RED=2 also for the 3x3 layers, 0 never (measured, bench.py A/B on one
+  box: 3x3 layers included, the reduce passes saved 0.6 ms per step and the MFMA-bound 3x3 input gradients lost as much)."""
+  k = knob('ASM_BN_RED', '1')
+  return k != '0' and d.stride == 1 and d.C % 8 == 0 and not _is_dense(d) and (d.R == 1 or k == '2')
+
+
+def conv_dgrad_bnred(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend, addend_mask, bn_y: torch.Tensor, bn_mask):
+  """conv_dgrad + the reduce pass of the batch-norm backward of the layer that produced this convolution's input
+  (asm_conv2d_dgrad_bnred) -> (dx, partial [blocks][2][C] of (sum dz, sum dz * y))"""
+  dx = empty((d.N, d.H, d.W, d.C), BF16, dy)
+  blocks = L().asm_conv2d_dgrad_bnred_blocks(C.byref(d))
+  part = empty((blocks, 2, d.C), F32, dy)
+  ev = _TIMER.start('dgrad', d) if _TIMER is not None else None
+  check(L().asm_conv2d_dgrad_bnred(C.byref(d), _ptr(dy), _ptr(wt), _ptr(addend), _ptr(addend_mask), _ptr(bn_y), _ptr(bn_mask),
+                                   _ptr(part), _ptr(dx), _stream()), 'conv2d_dgrad_bnred')
+  if ev is not None:
+    ev.record()
+  return dx, part
+
+
 def conv_dgrad(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend: Optional[torch.Tensor] = None,
                addend_mask: Optional[torch.Tensor] = None, pool=None) -> torch.Tensor:
   """dx = conv_transpose(dy, w) [+ addend [where addend_mask]] [+ avgpool_bwd(pool)];
@@ -461,20 +484,28 @@ def bn_apply(x, M, Cn, scale, shift, residual=None, res_mode=0, relu=False, H=0,
   return (y, mask) if want_mask else y
 
 
-def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz):
+def bn_bwd(dy, x, yout, relu, M, Cn, gamma, mean, invstd, dgamma, dbeta, want_dz, raw_part=None):
   """-> dx, dz (dz None unless want_dz).  dgamma/dbeta: f32 [C] views, overwritten.
-  ``yout`` is the bf16 forward output or (uint8) the packed ReLU mask from bn_apply(want_mask=True)."""
+  ``yout`` is the bf16 forward output or (uint8) the packed ReLU mask from bn_apply(want_mask=True).
+  ``raw_part``: the (sum dz, sum dz * y) partials the input gradient that wrote ``dy`` already reduced in its epilogue
+  (conv_dgrad_bnred): the reduce pass over (dy, x) is skipped."""
   rk = 0 if not relu else (2 if yout.dtype == torch.uint8 else 1)
-  ev = _bn_ev(M * Cn * (2 * 4.0 + 2.0 + (2.0 if want_dz else 0.0) + 2 * (0.125 if rk == 2 else 2.0 if rk == 1 else 0.0)))
-  blocks = L().asm_bn_stats_blocks(M, Cn)
-  part = empty((blocks, 2, Cn), F32, dy)
-  check(L().asm_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(yout if relu else None), rk, M, Cn,
-                              _ptr(mean), _ptr(invstd), _ptr(part), _stream()), 'bn_bwd_reduce')
-  part = _compact(part, Cn)
-  blocks = part.shape[0]
+  red_bytes = 0.0 if raw_part is not None else (4.0 + (0.125 if rk == 2 else 2.0 if rk == 1 else 0.0))
+  ev = _bn_ev(M * Cn * (red_bytes + 4.0 + 2.0 + (2.0 if want_dz else 0.0) + (0.125 if rk == 2 else 2.0 if rk == 1 else 0.0)))
   co = empty((3, Cn), F32, dy)
-  check(L().asm_bn_bwd_finalize(_ptr(part), blocks, M, Cn, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma),
-                                _ptr(dbeta), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _stream()), 'bn_bwd_finalize')
+  if raw_part is not None:
+    part = _compact(raw_part, Cn)
+    check(L().asm_bn_bwd_finalize_raw(_ptr(part), part.shape[0], M, Cn, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma),
+                                      _ptr(dbeta), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _stream()), 'bn_bwd_finalize_raw')
+  else:
+    blocks = L().asm_bn_stats_blocks(M, Cn)
+    part = empty((blocks, 2, Cn), F32, dy)
+    check(L().asm_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(yout if relu else None), rk, M, Cn,
+                                _ptr(mean), _ptr(invstd), _ptr(part), _stream()), 'bn_bwd_reduce')
+    part = _compact(part, Cn)
+    blocks = part.shape[0]
+    check(L().asm_bn_bwd_finalize(_ptr(part), blocks, M, Cn, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma),
+                                  _ptr(dbeta), _ptr(co[0]), _ptr(co[1]), _ptr(co[2]), _stream()), 'bn_bwd_finalize')
   dx = torch.empty_like(x)
   dz = torch.empty_like(x) if want_dz else None
   check(L().asm_bn_bwd_apply(_ptr(dy), _ptr(x), _ptr(yout if relu else None), rk, M, Cn,

@@ -185,6 +185,20 @@ int asm_conv2d_dgrad_pooled(const asm_conv_desc* d, const void* dy, const void* 
                             const uint8_t* addend_mask, const void* pool_dy, int pool_k, int pool_stride, int pool_pad,
                             int pool_Ho, int pool_Wo, int count_valid, void* dx, void* stream);
 
+/* asm_conv2d_dgrad[_masked] + the REDUCE pass of the batch-norm backward of the layer that produced this convolution's input:
+ * the tensor written here, dx [N*H*W][C], is the complete gradient of an activation z = [relu](bn(y) [+ shortcut])
+ * (nets/resnet_model.py:50-55, 84-95), and that batch norm's backward starts by reducing dbeta = sum dz and
+ * dgamma = sum dz * xhat over dz = dx * [z > 0] (what tf.gradients builds for tf.layers.batch_normalization,
+ * nets/model_helper.py:26-37) -- asm_bn_bwd_reduce reads dx and y again for it.  Here the epilogue that writes dx also reads
+ * bn_y (that layer's pre-BN convolution output, bf16 [N*H*W][C]) and bn_relu_mask (its packed ReLU mask as written by
+ * asm_bn_apply, or NULL: no ReLU) and emits partial [asm_conv2d_dgrad_bnred_blocks(d)][2][C] = per 128 rows (sum dz, sum dz * y)
+ * of the bf16-ROUNDED dx; asm_bn_bwd_finalize_raw (below) takes these partials (asm_bn_partials_compact applies).
+ * Stride-1 convolutions with C % 8 == 0 (ASM_ENOTSUP otherwise); no float atomics: fixed summation order. */
+int asm_conv2d_dgrad_bnred_blocks(const asm_conv_desc* d);
+int asm_conv2d_dgrad_bnred(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
+                           const uint8_t* addend_mask, const void* bn_y, const uint8_t* bn_relu_mask, float* partial,
+                           void* dx, void* stream);
+
 /* dw[k][r][s][c] (float32) = sum_{n,ho,wo} dy(n,ho,wo,k) * x(n, ho*stride+r-pad, wo*stride+s-pad, c).
  * Split-K over output pixels; `workspace` holds the per-split slabs. */
 size_t asm_conv2d_wgrad_workspace_bytes(const asm_conv_desc* d);
@@ -250,6 +264,11 @@ int asm_bn_bwd_reduce(const void* dy, const void* x, const void* yout, int relu,
 int asm_bn_bwd_finalize(const float* partial, int blocks, int M, int C, const float* gamma,
                         const float* mean, const float* invstd, float* dgamma, float* dbeta,
                         float* coefA, float* coefB, float* coefC, void* stream);
+/* asm_bn_bwd_finalize for partials of (sum dz, sum dz * y) -- the raw second moment an input-gradient epilogue emits
+ * (asm_conv2d_dgrad_bnred): sum dz * xhat = invstd * (sum dz * y - mean * sum dz), taken in fp64. */
+int asm_bn_bwd_finalize_raw(const float* partial, int blocks, int M, int C, const float* gamma,
+                            const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                            float* coefA, float* coefB, float* coefC, void* stream);
 int asm_bn_bwd_apply(const void* dy, const void* x, const void* yout, int relu, int M, int C,
                      const float* coefA, const float* coefB, const float* coefC, void* dx,
                      void* dz_out, void* stream);

@@ -224,6 +224,31 @@ class CpuDouble(object):
   def asm_conv2d_dgrad_masked(self, d, dy, wt, addend, addend_mask, dx, stream):
     return self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream, addend_mask)
 
+  def asm_conv2d_dgrad_bnred_blocks(self, d):
+    d = _desc(d)
+    return (d.N * d.H * d.W + 127) // 128
+
+  def asm_conv2d_dgrad_bnred(self, d, dy, wt, addend, addend_mask, bn_y, bn_mask, partial, dx, stream):
+    dd = _desc(d)
+    if dd.stride != 1 or dd.C % 8:
+      self._err = b'conv dgrad_bnred: stride-1 convolutions with C % 8 == 0 only'
+      return -2
+    rc = self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream, addend_mask) if addend_mask else \
+        self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream)
+    if rc:
+      return rc
+    M, Cn = dd.N * dd.H * dd.W, dd.C
+    dz = T(dx, (M, Cn), 'bf16').float()
+    if bn_mask:
+      dz = dz * self._unpack_mask(bn_mask, M, Cn)
+    y = T(bn_y, (M, Cn), 'bf16').float()
+    blocks = (M + 127) // 128
+    out = T(partial, (blocks, 2, Cn), 'f32')
+    for b in range(blocks):
+      out[b, 0] = dz[b * 128:(b + 1) * 128].sum(0)
+      out[b, 1] = (dz[b * 128:(b + 1) * 128] * y[b * 128:(b + 1) * 128]).sum(0)
+    return 0
+
   @staticmethod
   def _unpack_mask(mask, M, Cn):
     mk = T(mask, (M, Cn // 8), 'u8').to(torch.int32)
@@ -496,6 +521,12 @@ class CpuDouble(object):
     T(cB, (Cn,), 'f32').copy_(B.float())
     T(cC, (Cn,), 'f32').copy_(Cc.float())
     return 0
+
+  def asm_bn_bwd_finalize_raw(self, part, blocks, M, Cn, gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, stream):
+    st = T(part, (blocks, 2, Cn), 'f32').double().sum(0)
+    mu, inv = (T(p, (Cn,), 'f32').double() for p in (mean, invstd))
+    fixed = torch.stack([st[0], inv * (st[1] - mu * st[0])]).float().reshape(1, 2, Cn).contiguous()
+    return self.asm_bn_bwd_finalize(fixed.data_ptr(), 1, M, Cn, gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, stream)
 
   def asm_bn_bwd_apply(self, dy, x, yout, relu, M, Cn, cA, cB, cC, dx, dz_out, stream):
     g = self._dz(dy, yout, relu, M, Cn)

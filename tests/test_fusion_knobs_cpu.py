@@ -1,6 +1,6 @@
 """Host-side fusion plumbing (CPU test double of the C ABI): every lazy / fused path of nn.py -- lazily masked shortcut
 gradients, the deferred + dual batch norm of a projection shortcut, the pooled gradient gathered by conv1's input
-gradient, the masked block sum at a BigLittle merge, the reordered tape
+gradient, the batch-norm backward sums reduced in the producing input gradient's epilogue, the masked block sum at a BigLittle merge, the reordered tape
 of a projection block -- must give the gradients of the plain one-kernel-per-op path.  The double computes both in fp32
 with bf16 rounding where the kernels store bf16, so the two differ by rounding only."""
 import pytest
@@ -14,7 +14,7 @@ def _run(monkeypatch, fused: bool, name='a-r50-d', batch=2, size=64, gatherable=
   from assembled_cnn_amd import nn, ops
   if not gatherable:      # the pooled gradient stays pending until somebody reads .grad, which scatters it
     monkeypatch.setattr(ops, 'dgrad_pool_ok', lambda d: False)
-  for k in ('ASM_POOL_FUSE', 'ASM_BN_DUAL', 'ASM_DENSE_SMALL', 'ASM_SK_FUSED'):
+  for k in ('ASM_POOL_FUSE', 'ASM_BN_DUAL', 'ASM_DENSE_SMALL', 'ASM_SK_FUSED', 'ASM_BN_RED'):
     util.set_knob(monkeypatch, k, '1' if fused else '0')
   monkeypatch.setattr(nn, 'DEFER_BN', fused)
   monkeypatch.setattr(nn, 'LAZY_DZ', fused)

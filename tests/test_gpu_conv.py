@@ -678,3 +678,64 @@ def test_igemm8_ragged_last_round_split(hip_lib, monkeypatch):
   g1 = ops.conv_dgrad(d2, dy, wt, addend=add)
   assert hip_lib.asm_launch_count() - n0 == 2
   assert torch.equal(g0, g1)
+
+
+BNRED_CASES = [
+    # N, H,  W,  C(dx), K(dy), k, knobs                       what runs
+    (4, 14, 14, 256, 64, 1, {}),                              # 1x1: igemm2 statistics epilogue (not a workload shape)
+    (256, 14, 14, 512, 128, 1, {}),                           # 1x1, a workload shape with an addend: igemm1 (code from the table)
+    (3, 14, 14, 128, 256, 3, {}),                             # 3x3: igemm3
+    (24, 14, 14, 256, 512, 3, {'ASM_IGEMM8': '2'}),           # 3x3: igemm8
+    (2, 16, 32, 32, 64, 3, {}),                               # 3x3 on a narrow layer: conv_halo
+    (2, 9, 11, 72, 40, 3, {'ASM_IGEMM_MODE': '1'}),           # the general kernel, channel tails
+]
+
+
+@pytest.mark.parametrize('case', BNRED_CASES, ids=lambda c: 'x'.join(map(str, c[:6])))
+@pytest.mark.parametrize('relu', [True, False])
+def test_dgrad_with_bn_backward_sums_in_its_epilogue(hip_lib, case, relu, monkeypatch):
+  """asm_conv2d_dgrad_bnred: the input gradient that also reduces (sum dz, sum dz * y) of the batch norm behind its output.
+  dx must be the bits asm_conv2d_dgrad[_masked] writes; the partial rows must sum to the sums of the bf16 dx it wrote; and
+  the batch-norm backward finished from them (asm_bn_bwd_finalize_raw + apply) must agree with the three-pass form
+  (reduce over (dx, y) + finalize + apply): dgamma / dbeta to 1e-3, dy rel-L2 <= 2e-3."""
+  from assembled_cnn_amd import ops
+  N, H, W, Cn, K, k, knobs = case
+  for name, val in knobs.items():
+    util.set_knob(monkeypatch, name, val)
+  d = ops.make_conv_desc(N, H, W, Cn, K, k, k, 1)
+  g = torch.Generator(device='cuda').manual_seed(5)
+  dy = torch.randn((N, H, W, K), generator=g, device='cuda').to(BF)
+  w = (torch.randn((K, k, k, Cn), generator=g, device='cuda') * (k * k * K) ** -0.5).to(BF)
+  wt = torch.zeros((Cn, k, k, K), dtype=BF, device='cuda')
+  ops.filter_transpose(w, wt, K, k, k, Cn)
+  add = torch.randn((N, H, W, Cn), generator=g, device='cuda').to(BF)
+  amask = torch.randint(0, 256, (N, H, W, Cn // 8), generator=g, device='cuda', dtype=torch.uint8)
+  y = (torch.randn((N, H, W, Cn), generator=g, device='cuda') * 1.5 + 0.7).to(BF)     # a mean well away from 0
+  rmask = torch.randint(0, 256, (N * H * W, Cn // 8), generator=g, device='cuda', dtype=torch.uint8) if relu else None
+  M = N * H * W
+  for addend, mask in ((None, None), (add, None), (add, amask)):
+    ref = ops.conv_dgrad(d, dy, wt, addend, mask)
+    kern = hip_lib.asm_debug_last_conv_kernel()
+    dx, part = ops.conv_dgrad_bnred(d, dy, wt, addend, mask, y, rmask)
+    assert hip_lib.asm_debug_last_conv_kernel() == kern or kern == 1, 'the fused form left the kernel family'
+    assert torch.equal(dx, ref), 'dx differs from the plain input gradient'
+    dz = dx.float().view(M, Cn)
+    if relu:
+      bits = ((rmask.to(torch.int32)[..., None] >> torch.arange(8, dtype=torch.int32, device='cuda')) & 1).view(M, Cn)
+      dz = dz * bits
+    s0, s1 = dz.double().sum(0), (dz.double() * y.double().view(M, Cn)).sum(0)
+    got = part.double().sum(0)
+    assert part.shape[0] == (M + 127) // 128
+    scale0, scale1 = float(dz.abs().double().sum(0).max()), float((dz.abs().double() * y.double().view(M, Cn).abs()).sum(0).max())
+    assert float((got[0] - s0).abs().max()) <= 1e-5 * scale0 and float((got[1] - s1).abs().max()) <= 1e-5 * scale1
+  # the batch-norm backward from these sums vs its own reduce pass
+  mean, var = y.float().view(M, Cn).mean(0), y.float().view(M, Cn).var(0, unbiased=False)
+  invstd = (var + 1e-5).rsqrt()
+  gamma = (torch.rand(Cn, generator=g, device='cuda') + 0.5)
+  dg0, db0, dg1, db1 = (torch.empty(Cn, device='cuda') for _ in range(4))
+  yv = y.view(M, Cn)
+  a0, _ = ops.bn_bwd(dx.view(M, Cn), yv, rmask, relu, M, Cn, gamma, mean, invstd, dg0, db0, False)
+  a1, _ = ops.bn_bwd(dx.view(M, Cn), yv, rmask, relu, M, Cn, gamma, mean, invstd, dg1, db1, False, raw_part=part)
+  assert torch.allclose(dg0, dg1, rtol=1e-3, atol=1e-3 * float(dg0.abs().max()))
+  assert torch.allclose(db0, db1, rtol=1e-3, atol=1e-3 * float(db0.abs().max()))
+  assert util.rel_l2(a1.float().cpu(), a0.float().cpu()) <= 2e-3

@@ -120,7 +120,7 @@ def test_forward_backward_literal_zero_gamma(hip_lib):
 
 def test_train_steps_assemble_mixup_ls(hip_lib):
   mp.check_train_steps('a-r50-d', 'cuda', 8, 64, 3, dict(base_learning_rate=0.001, weight_decay=1e-4, label_smoothing=0.1),
-                       mixup_type=1, rel_tol=3e-2)
+                       mixup_type=1, rel_tol=3e-2, state_tol=4e-2, mom_cos=0.5)    # (batch 8 at 64 x 64: gradient noise; the batch-32 run below is the tight one)
 
 
 def test_train_trajectory_10_steps_within_one_percent(hip_lib):
@@ -135,14 +135,14 @@ def test_train_trajectory_10_steps_within_one_percent(hip_lib):
 
 def test_train_steps_kd(hip_lib):
   mp.check_train_steps('r50v1', 'cuda', 8, 64, 2, dict(base_learning_rate=0.001, weight_decay=1e-4), kd_temp=1.0,
-                       rel_tol=3e-2)
+                       rel_tol=3e-2, state_tol=4e-2, mom_cos=0.5)
 
 
 def test_assemble_r152_forward_and_kd_steps(hip_lib):
   """BASELINE config 5: Assemble-ResNet-152 (alpha 1, beta 2) with knowledge distillation."""
   mp.check_forward_noise_floor('a-r152', 'cuda', 8, 128)
   mp.check_train_steps('a-r152', 'cuda', 8, 128, 2, dict(base_learning_rate=0.0002, weight_decay=1e-4), kd_temp=1.0,
-                       rel_tol=4e-2)
+                       rel_tol=4e-2, state_tol=5e-2, mom_cos=0.1)    # (70 blocks at batch 8: gradient DIRECTIONS are rounding noise -- the sizes are not)
 
 
 def test_step_is_deterministic(hip_lib):
