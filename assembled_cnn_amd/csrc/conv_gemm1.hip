@@ -54,7 +54,7 @@ struct Cfg1 {
   static_assert(LDS <= 160 * 1024, "lds");
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool STATS, int NS, bool PFA, bool POOL>
+template <int BM, int BN, int BK, int WGM, int WGN, bool STATS, int NS, bool PFA, bool POOL, bool BNRED = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm1_kernel(IGemmArgs p) {
   using C = Cfg<BM, BN, BK, WGM, WGN, false, STATS, 2>;
   using C1 = Cfg1<BM, BN, BK, WGM, WGN, NS>;
@@ -197,13 +197,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm1_kernel(IGemmArgs p) {
   mma(1);
   __syncthreads();   // every wave's fragment reads are done: the epilogue reuses the region
 
-  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, false, STATS, PFA, POOL>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, false, STATS, PFA, POOL, false, BNRED>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool STATS, int NS, bool PFA, bool POOL>
+template <int BM, int BN, int BK, int WGM, int WGN, bool STATS, int NS, bool PFA, bool POOL, bool BNRED = false>
 int launch1_one(const IGemmArgs& a, hipStream_t st) {
   using C1 = Cfg1<BM, BN, BK, WGM, WGN, NS>;
-  auto kern = igemm1_kernel<BM, BN, BK, WGM, WGN, STATS, NS, PFA, POOL>;
+  auto kern = igemm1_kernel<BM, BN, BK, WGM, WGN, STATS, NS, PFA, POOL, BNRED>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, C1::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm1_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
@@ -223,6 +223,7 @@ int launch1_cfg(IGemmArgs& a, bool stats, hipStream_t st) {
   a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
   const int pfa_env = asm_tune().igemm_pfa;   // the addend-prefetching epilogue, chosen as igemm2 does (launch2_cfg)
   const bool pfa = a.addend != nullptr && !a.y_strided && (pfa_env >= 0 ? pfa_env != 0 : (BM == 256 || a.n_blocks <= 1024));
+  if (stats && a.red_y) return launch1_one<BM, BN, BK, WGM, WGN, true, NS, false, false, true>(a, st);
   if (stats) return launch1_one<BM, BN, BK, WGM, WGN, true, NS, false, false>(a, st);
   if (a.pool_dy) return launch1_one<BM, BN, BK, WGM, WGN, false, NS, false, true>(a, st);
   if (pfa) return launch1_one<BM, BN, BK, WGM, WGN, false, NS, true, false>(a, st);

@@ -33,7 +33,7 @@ namespace {
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
 
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE, bool BNRED = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
   using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE>;
   constexpr int NT = C::NT, CPR = C::CPR, RPP = C::RPP, XP = C::XP, WP = C::WP, ROWB = C::ROWB, STAGE = C::STAGE;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_kernel(IGemmArgs p) {
     __syncthreads();
   }
 
-  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS, false, false, false, BNRED>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -224,7 +224,7 @@ struct Cfg2 {
 // costs its wave 60-180 issue cycles (v_readfirstlane + M0 write + the buffer_load itself): with 8 pieces up front both waves
 // of a SIMD sit in their issue phase together and the matrix pipe idles for that long at the head of every step.
 template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS, bool PFA = false, bool POOL = false,
-          int SCHED = 0>
+          int SCHED = 0, bool BNRED = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
   using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, 2>;
   using C2 = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
     }
   }
 
-  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS, PFA, POOL>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, OUT_F32, STATS, PFA, POOL, false, BNRED>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -878,7 +878,7 @@ int try_halo(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
 }
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int R, int S, int NS = 2, bool PFA = false, bool POOL = false,
-          int SCHED = 0>
+          int SCHED = 0, bool BNRED = false>
 int launch2_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg2<BM, BN, BK, WGM, WGN, OUT_F32, STATS, NS>;
   constexpr int NTHR = 64 * WGM * WGN;
@@ -888,7 +888,7 @@ int launch2_one(const IGemmArgs& a, hipStream_t st) {
   if constexpr (SCHED == 0 && BK == 64 && BN >= 128 && !OUT_F32 && !POOL && ((R == 3 && S == 3) || (R == 1 && S == 1))) {
     if (R == 3) return launch2_one<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL, 1>(a, st);
   }
-  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL, SCHED>;
+  auto kern = igemm2_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, R, S, NS, PFA, POOL, SCHED, BNRED>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm2_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
@@ -913,6 +913,7 @@ int launch2_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
                    (pfa_env >= 0 ? pfa_env != 0 : (BM == 256 || a.n_blocks <= 1024));
   if (a.R == 1 && a.S == 1) {
     if (out_f32) return launch2_one<BM, BN, BK, WGM, WGN, true, false, 1, 1>(a, st);
+    if (stats && a.red_y) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 1, 1, 2, false, false, 0, true>(a, st);
     if (stats) return launch2_one<BM, BN, BK, WGM, WGN, false, true, 1, 1>(a, st);
     if (a.pool_dy) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 1, 2, false, true>(a, st);
     if (pfa) return launch2_one<BM, BN, BK, WGM, WGN, false, false, 1, 1, 2, true>(a, st);
@@ -942,10 +943,10 @@ int launch2_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   return 1;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE>
+template <int BM, int BN, int BK, int WGM, int WGN, bool OUT_F32, bool STATS, int MODE, bool BNRED = false>
 int launch_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE>;
-  auto kern = igemm_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE>;
+  auto kern = igemm_kernel<BM, BN, BK, WGM, WGN, OUT_F32, STATS, MODE, BNRED>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, C::LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
@@ -961,6 +962,7 @@ int launch_mode(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   a.n_blocks = cdiv(a.M, BM) * a.n_tiles_n;
   a.kchunks = cdiv(a.Ci, BK);
   if (out_f32) return launch_one<BM, BN, BK, WGM, WGN, true, false, MODE>(a, st);
+  if (stats && a.red_y) return launch_one<BM, BN, BK, WGM, WGN, false, true, MODE, true>(a, st);
   if (stats) return launch_one<BM, BN, BK, WGM, WGN, false, true, MODE>(a, st);
   return launch_one<BM, BN, BK, WGM, WGN, false, false, MODE>(a, st);
 }
@@ -1202,8 +1204,9 @@ extern "C" int asm_conv2d_dgrad_bnred(const asm_conv_desc* d, const void* dy, co
                                       float* partial, void* dx, void* stream) {
   ASM_REQUIRE(d && bn_y && partial, "conv dgrad_bnred: null pointer");
   ASM_REQUIRE(!addend_mask || addend, "conv dgrad_bnred: a mask needs its addend");
-  if (d->stride != 1 || d->C % 8)
-    ASM_FAIL(ASM_ENOTSUP, "conv dgrad_bnred: stride-1 convolutions with C %% 8 == 0 only (stride %d, C %d)", d->stride, d->C);
+  if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->C % 8)
+    ASM_FAIL(ASM_ENOTSUP, "conv dgrad_bnred: 1x1 stride-1 convolutions with C %% 8 == 0 only (%dx%d, stride %d, C %d)", d->R, d->S,
+             d->stride, d->C);
   const BnRed r = {bn_y, bn_relu_mask, partial};
   return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream, nullptr, &r);
 }

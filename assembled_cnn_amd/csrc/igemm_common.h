@@ -95,8 +95,11 @@ struct Cfg {
 // SPLIT8 (igemm8_kernel, conv_igemm8.hip): a wave's 128 x 64 outputs are two 64-row pieces (one per 128-row half of the pixel
 // tile) by two 32-channel pieces (one per 128-row half of the filter tile): acc[a][b] is filter half a, pixel half b >> 1,
 // 32-row sub-tile b & 1.
+// BNRED (with STATS; asm_conv2d_dgrad_bnred): the statistics partials are the batch-norm BACKWARD sums (sum dz, sum dz * y) of the
+// gradient this launch writes (IGemmArgs::red_y).  A separate instantiation: as a run-time branch in the statistics epilogue it
+// took the forward kernels from 60 to 152 VGPRs (4 -> 2 waves per SIMD) and the 1x1 class from 7.6 to 8.5 ms per step.
 template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS, bool PFA = false, bool POOL = false,
-          bool SPLIT8 = false>
+          bool SPLIT8 = false, bool BNRED = false>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[TN][TM], unsigned char* smem,
                                                int tile_m, int tile_n, int tid, int wm, int wn, int l31, int lhi,
                                                int patch_base = -1) {
@@ -248,7 +251,8 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
     for (int q = 0; q < SG; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[q][e] = ss[q][e] = 0.f;
-    // batch-norm backward sums (p.red_y): this thread's y vector and ReLU-mask byte of pass ps, fetched one pass ahead
+    static_assert(!BNRED || STATS, "the batch-norm backward sums use the statistics epilogue");
+    // batch-norm backward sums (BNRED, p.red_y): this thread's y vector and ReLU-mask byte of pass ps, fetched one pass ahead
     u32x4 ry_nxt = {0u, 0u, 0u, 0u};
     unsigned rmk_nxt = 0xffu;
     auto red_fetch = [&](int ps_, u32x4& yv, unsigned& mk) {
@@ -263,9 +267,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         if (p.red_mask) mk = (unsigned)p.red_mask[ro >> 3];
       }
     };
-    if constexpr (STATS) {
-      if (p.red_y) red_fetch(0, ry_nxt, rmk_nxt);
-    }
+    if constexpr (BNRED) red_fetch(0, ry_nxt, rmk_nxt);
 #pragma unroll
     for (int ps = 0; ps < OP; ++ps) {
       if constexpr (PF_ON) {
@@ -278,8 +280,8 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       const int m = tile_m * BM + row;
       u32x4 ry = ry_nxt;
       unsigned rmk = rmk_nxt;
-      if constexpr (STATS) {
-        if (p.red_y && ps + 1 < OP) red_fetch(ps + 1, ry_nxt, rmk_nxt);   // one pass ahead: lands under this pass's stores
+      if constexpr (BNRED) {
+        if (ps + 1 < OP) red_fetch(ps + 1, ry_nxt, rmk_nxt);   // one pass ahead: lands under this pass's stores
       }
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
       if (m < p.M && n0 < co8) {
@@ -329,7 +331,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         constexpr int PPG = OP / SG;   // passes per statistics group (rows are pass-major)
         float f[8];
         unpack8(v, f);
-        if (p.red_y) {      // batch-norm backward sums of the gradient just written (rows past M: v = 0, ry = 0)
+        if constexpr (BNRED) {      // batch-norm backward sums of the gradient just written (rows past M: v = 0, ry = 0)
           float fy[8];
           unpack8(ry, fy);
 #pragma unroll

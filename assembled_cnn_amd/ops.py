@@ -305,12 +305,11 @@ def dgrad_s2_ok(d: ConvDesc) -> bool:
 
 
 def dgrad_bnred_ok(d: ConvDesc) -> bool:
-  """should this layer's input gradient reduce the batch-norm backward sums of its input (asm_conv2d_dgrad_bnred)?  The call
-  takes any stride-1 convolution with C % 8 == 0; the default (ASM_BN_RED=1) uses it for the 1x1 layers -- the block-final
-  batch norms, 4 x the channels of the others -- ASM_BN_RED=2 also for the 3x3 layers, 0 never (measured, bench.py A/B on one
-  box: 3x3 layers included, the reduce passes saved 0.6 ms per step and the MFMA-bound 3x3 input gradients lost as much)."""
-  k = knob('ASM_BN_RED', '1')
-  return k != '0' and d.stride == 1 and d.C % 8 == 0 and not _is_dense(d) and (d.R == 1 or k == '2')
+  """should this layer's input gradient reduce the batch-norm backward sums of its input (asm_conv2d_dgrad_bnred)?  1x1 stride-1
+  layers with C % 8 == 0 (the block-final batch norms, 4 x the channels of the others; in the MFMA-bound 3x3 input gradients
+  the extra epilogue reads cost what the reduce pass they replace costs).  ASM_BN_RED=0: never"""
+  return (knob('ASM_BN_RED', '1') != '0' and d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0 and d.C % 8 == 0
+          and not _is_dense(d))
 
 
 def conv_dgrad_bnred(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend, addend_mask, bn_y: torch.Tensor, bn_mask):

@@ -193,7 +193,9 @@ int asm_conv2d_dgrad_pooled(const asm_conv_desc* d, const void* dy, const void* 
  * bn_y (that layer's pre-BN convolution output, bf16 [N*H*W][C]) and bn_relu_mask (its packed ReLU mask as written by
  * asm_bn_apply, or NULL: no ReLU) and emits partial [asm_conv2d_dgrad_bnred_blocks(d)][2][C] = per 128 rows (sum dz, sum dz * y)
  * of the bf16-ROUNDED dx; asm_bn_bwd_finalize_raw (below) takes these partials (asm_bn_partials_compact applies).
- * Stride-1 convolutions with C % 8 == 0 (ASM_ENOTSUP otherwise); no float atomics: fixed summation order. */
+ * 1x1 stride-1 convolutions with C % 8 == 0 (ASM_ENOTSUP otherwise: the block-final batch norms, whose gradient a conv1 input
+ * gradient completes, are 4 x the channels of the others; in the MFMA-bound 3x3 input gradients the extra epilogue reads cost
+ * what the reduce pass they replace costs); no float atomics: fixed summation order. */
 int asm_conv2d_dgrad_bnred_blocks(const asm_conv_desc* d);
 int asm_conv2d_dgrad_bnred(const asm_conv_desc* d, const void* dy, const void* wt, const void* addend,
                            const uint8_t* addend_mask, const void* bn_y, const uint8_t* bn_relu_mask, float* partial,

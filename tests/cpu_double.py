@@ -230,8 +230,8 @@ class CpuDouble(object):
 
   def asm_conv2d_dgrad_bnred(self, d, dy, wt, addend, addend_mask, bn_y, bn_mask, partial, dx, stream):
     dd = _desc(d)
-    if dd.stride != 1 or dd.C % 8:
-      self._err = b'conv dgrad_bnred: stride-1 convolutions with C % 8 == 0 only'
+    if dd.R != 1 or dd.S != 1 or dd.stride != 1 or dd.pad != 0 or dd.C % 8:
+      self._err = b'conv dgrad_bnred: 1x1 stride-1 convolutions with C % 8 == 0 only'
       return -2
     rc = self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream, addend_mask) if addend_mask else \
         self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream)

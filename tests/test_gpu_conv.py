@@ -682,19 +682,17 @@ def test_igemm8_ragged_last_round_split(hip_lib, monkeypatch):
 
 BNRED_CASES = [
     # N, H,  W,  C(dx), K(dy), k, knobs                       what runs
-    (4, 14, 14, 256, 64, 1, {}),                              # 1x1: igemm2 statistics epilogue (not a workload shape)
-    (256, 14, 14, 512, 128, 1, {}),                           # 1x1, a workload shape with an addend: igemm1 (code from the table)
-    (3, 14, 14, 128, 256, 3, {}),                             # 3x3: igemm3
-    (24, 14, 14, 256, 512, 3, {'ASM_IGEMM8': '2'}),           # 3x3: igemm8
-    (2, 16, 32, 32, 64, 3, {}),                               # 3x3 on a narrow layer: conv_halo
-    (2, 9, 11, 72, 40, 3, {'ASM_IGEMM_MODE': '1'}),           # the general kernel, channel tails
+    (4, 14, 14, 256, 64, 1, {}),                              # igemm2's statistics epilogue (not a workload shape), 8 row tiles
+    (256, 14, 14, 512, 128, 1, {}),                           # a workload shape: igemm1 (configuration from the table)
+    (3, 9, 11, 264, 72, 1, {}),                               # ragged rows, a channel tail in the third N tile
+    (2, 9, 11, 72, 40, 1, {'ASM_IGEMM_MODE': '1'}),           # the general kernel, channel tails
 ]
 
 
 @pytest.mark.parametrize('case', BNRED_CASES, ids=lambda c: 'x'.join(map(str, c[:6])))
 @pytest.mark.parametrize('relu', [True, False])
 def test_dgrad_with_bn_backward_sums_in_its_epilogue(hip_lib, case, relu, monkeypatch):
-  """asm_conv2d_dgrad_bnred: the input gradient that also reduces (sum dz, sum dz * y) of the batch norm behind its output.
+  """asm_conv2d_dgrad_bnred: the input gradient that also reduces (sum dz, sum dz * y) of the batch norm behind its output (1x1 layers).
   dx must be the bits asm_conv2d_dgrad[_masked] writes; the partial rows must sum to the sums of the bf16 dx it wrote; and
   the batch-norm backward finished from them (asm_bn_bwd_finalize_raw + apply) must agree with the three-pass form
   (reduce over (dx, y) + finalize + apply): dgamma / dbeta to 1e-3, dy rel-L2 <= 2e-3."""
@@ -717,7 +715,7 @@ def test_dgrad_with_bn_backward_sums_in_its_epilogue(hip_lib, case, relu, monkey
     ref = ops.conv_dgrad(d, dy, wt, addend, mask)
     kern = hip_lib.asm_debug_last_conv_kernel()
     dx, part = ops.conv_dgrad_bnred(d, dy, wt, addend, mask, y, rmask)
-    assert hip_lib.asm_debug_last_conv_kernel() == kern or kern == 1, 'the fused form left the kernel family'
+    assert hip_lib.asm_debug_last_conv_kernel() == kern, 'the fused form left the kernel family'
     assert torch.equal(dx, ref), 'dx differs from the plain input gradient'
     dz = dx.float().view(M, Cn)
     if relu:
@@ -739,3 +737,10 @@ def test_dgrad_with_bn_backward_sums_in_its_epilogue(hip_lib, case, relu, monkey
   assert torch.allclose(dg0, dg1, rtol=1e-3, atol=1e-3 * float(dg0.abs().max()))
   assert torch.allclose(db0, db1, rtol=1e-3, atol=1e-3 * float(db0.abs().max()))
   assert util.rel_l2(a1.float().cpu(), a0.float().cpu()) <= 2e-3
+
+
+def test_dgrad_bnred_refuses_what_it_does_not_cover(hip_lib):
+  from assembled_cnn_amd import ops
+  d = ops.make_conv_desc(2, 8, 8, 64, 64, 3, 3, 1)
+  assert hip_lib.asm_conv2d_dgrad_bnred(C.byref(d), 1, 1, None, None, 1, None, 1, 1, None) == -2      # ASM_ENOTSUP before any pointer is touched
+  assert not ops.dgrad_bnred_ok(d)
