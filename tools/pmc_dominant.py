@@ -36,8 +36,11 @@ def main():
   N, H, C, K = 256, 14, 512, 1024
   alg = {'fprop': 2 * (N * H * H * C + N * H * H * K + 9 * C * K), 'dgrad': 2 * (N * H * H * C + N * H * H * K + 9 * C * K),
          'wgrad': 2 * (N * H * H * C + N * H * H * K) + 4 * 9 * C * K}
-  groups = {'fprop': [k for k in f if (k.startswith('igemm2_kernel') and ', true, 3, 3' in k) or k.startswith('igemm3_kernel<128, true')],
-            'dgrad': [k for k in f if (k.startswith('igemm2_kernel') and ', false, 3, 3' in k) or k.startswith('igemm3_kernel<128, false')],
+  # (round 6: the forward launch is igemm8 for the rows of the full rounds + igemm3 for the last rows: both count)
+  groups = {'fprop': [k for k in f if (k.startswith('igemm2_kernel') and ', true, 3, 3' in k) or k.startswith('igemm3_kernel<128, true')
+                      or k.startswith('igemm8_kernel<true')],
+            'dgrad': [k for k in f if (k.startswith('igemm2_kernel') and ', false, 3, 3' in k) or k.startswith('igemm3_kernel<128, false')
+                      or k.startswith('igemm8_kernel<false')],
             'wgrad': [k for k in f if k.startswith('wgrad_')]}
   res = {'_about': 'HBM-side traffic per launch, N256 14x14x512 -> 1024 3x3/1, from separate rocprofv3 --pmc FETCH_SIZE / '
                    '--pmc WRITE_SIZE passes over tools/conv_bench.py (see tools/pmc_dominant.py); KiB counters, fetch x 2.'}
