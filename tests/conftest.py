@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+  # The CPU oracle is most of the GPU tier's wall time, and on the GPU box's 256 hardware threads PyTorch's default (one
+  # intra-op thread per hardware thread) is the slow choice for its layer-sized operators: one oracle-heavy test
+  # (test_sk_blocks_forward_and_backward_at_batch_256[stage_4]) takes 33.2 s with the default, 20.5 s with 64 threads, 15.5 s
+  # with 32, 16.7 s with 16 (round 6, same box).  OMP_NUM_THREADS in the environment wins.
+  if 'OMP_NUM_THREADS' not in os.environ:
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
 
 
 @pytest.fixture

@@ -29,6 +29,7 @@ def main():
       'config3_a-r50-d_train_b256_224': lambda: fwd('a-r50-d', 256, 224, True),
       'config4_a-r50-d_mixup1_ls_512in_224': lambda: train_fwd('a-r50-d', 512, 224, mixup_type=1, label_smoothing=0.1),
       'config5_a-r152_kd_b128_224': lambda: train_fwd('a-r152', 128, 224, kd_temp=1.0, noise_floor=True),
+      'noise_floor_a-r152_b8_128': lambda: mp.oracle_noise_floor_record(mp.make_pair('a-r152', 'cpu', 2, 64)[0], 'a-r152', 8, 128),
   }
   for key, job in jobs.items():
     if want and key not in want:

@@ -155,36 +155,54 @@ def check_forward(name, device, batch, size, training, logits_tol, early_tol=4e-
   return e
 
 
-def check_forward_noise_floor(name, device, batch, size, slack=1.25, floor=4e-3):
-  """Very deep nets (A-R152: 70 blocks) amplify bf16 rounding at random init beyond any fixed tolerance, so the
-  bound is calibrated on the spot: at every named tap the product must be at least as close to the bf16-emulating
-  oracle as that oracle is to its own fp32 evaluation (x slack).  A wiring or kernel bug shows up as an error well
-  above the rounding noise at the first tap it touches."""
+def oracle_noise_floor_record(om, name, batch, size):
+  """the oracle side of check_forward_noise_floor: the bf16-emulating forward (logits, tap subsets) and, per tap, how far
+  the oracle's own fp32 evaluation is from it (tests/golden/make_oracle_forward.py commits it)"""
   from oracle import assembled_oracle as O
-  om, pm = make_pair(name, device, batch, size)
   d = uses_d(name)
   _, x, _ = inputs(batch, size)
-  lo = om(x, True, use_resnet_d=d).detach()
+  with torch.no_grad():
+    lo = om(x, True, use_resnet_d=d).detach()
   taps_o = {k: v.detach().clone() for k, v in om.taps_nhwc().items()}
-  lp = pm(x.to(device), True, use_resnet_d=d).float().cpu()
   of = O.Model(num_classes=1001, emulate_bf16=False, zero_gamma=True, seed=0, **CONFIGS[name])
   of(torch.zeros(2, size, size, 3), True, use_resnet_d=d)
   of.vars.pending_updates = {}
   with torch.no_grad():
     for n, t in om.vars.trainable.items():
       of.vars.trainable[n].copy_(t)
-  lf = of(x, True, use_resnet_d=d).detach()
+    lf = of(x, True, use_resnet_d=d).detach()
   taps_f = of.taps_nhwc()
-  report = {}
+  rec = {'logits': lo.numpy().astype(np.float32), 'noise/logits': np.float64(util.rel_l2(lf, lo))}
   for k, v in taps_o.items():
+    rec['tap/' + k] = tap_subset(v.float(), k).numpy().astype(np.float32)
+    rec['noise/' + k] = np.float64(util.rel_l2(taps_f[k].detach(), v))
+  return rec
+
+
+def check_forward_noise_floor(name, device, batch, size, slack=1.25, floor=4e-3, golden=None):
+  """Very deep nets (A-R152: 70 blocks) amplify bf16 rounding at random init beyond any fixed tolerance, so the
+  bound is calibrated on the spot: at every named tap the product must be at least as close to the bf16-emulating
+  oracle as that oracle is to its own fp32 evaluation (x slack).  A wiring or kernel bug shows up as an error well
+  above the rounding noise at the first tap it touches."""
+  om, pm = make_pair(name, device, batch, size)
+  d = uses_d(name)
+  _, x, _ = inputs(batch, size)
+  rec, _ = oracle_cached(golden, lambda: oracle_noise_floor_record(om, name, batch, size))
+  lo = torch.from_numpy(rec['logits'])
+  lp = pm(x.to(device), True, use_resnet_d=d).float().cpu()
+  report = {}
+  for key in rec:
+    if not key.startswith('tap/'):
+      continue
+    k = key[4:]
     if k not in pm.taps:
       continue
-    pv = lp if k == 'final_dense' else pm.taps[k].float().cpu().reshape(v.shape)
-    e_p, e_f = util.rel_l2(pv, v), util.rel_l2(taps_f[k].detach(), v)
+    pv = tap_subset(lp if k == 'final_dense' else pm.taps[k].float(), k).cpu()
+    e_p, e_f = util.rel_l2(pv, torch.from_numpy(rec[key])), float(rec['noise/' + k])
     report[k] = (e_p, e_f)
     assert e_p <= max(slack * e_f, floor), '%s: tap %s product-vs-oracle %.3e > %.2f x rounding noise %.3e' % (
         name, k, e_p, slack, e_f)
-  assert util.rel_l2(lp, lo) <= max(slack * util.rel_l2(lf, lo), floor)
+  assert util.rel_l2(lp, lo) <= max(slack * float(rec['noise/logits']), floor)
   return report
 
 
