@@ -81,7 +81,9 @@ def test_teacher_forced_backward_per_layer_parity(hip_lib, name, batch, size):
   lazily masked shortcut / merge gradients, deferred + dual batch norm of projection shortcuts, the pooled gradient
   gathered in conv1's input-gradient epilogue, the fused SK backward, the reordered projection-block tape, the BigLittle
   backward interleaved on two streams (a-r152 and the beta = 1 variant have little branches of many blocks)."""
-  errs, st = mp.check_teacher_forced_backward(name, 'cuda', batch, size)
+  # (A-R152: 1339 comparisons; the tail of their distribution reaches 6.02e-3 with the oracle on 32 CPU threads -- its
+  # reduction order, and with it single bf16 roundings, depends on the thread count)
+  errs, st = mp.check_teacher_forced_backward(name, 'cuda', batch, size, dx_tol=6.5e-3 if name == 'a-r152' else 6e-3)
   assert st['forced'] >= 45 and len(errs) >= 200, st
   assert sum(st['kinds'][k] for k in ('dout', 'dout-lazy', 'dx', 'dout-squeeze', 'dx-squeeze')) >= (100 if 'a-r' in name else 50)
 
@@ -141,7 +143,7 @@ def test_train_steps_kd(hip_lib):
 def test_assemble_r152_forward_and_kd_steps(hip_lib):
   """BASELINE config 5: Assemble-ResNet-152 (alpha 1, beta 2) with knowledge distillation."""
   mp.check_forward_noise_floor('a-r152', 'cuda', 8, 128, golden='noise_floor_a-r152_b8_128')
-  mp.check_train_steps('a-r152', 'cuda', 8, 96, 2, dict(base_learning_rate=0.0002, weight_decay=1e-4), kd_temp=1.0,
+  mp.check_train_steps('a-r152', 'cuda', 8, 128, 2, dict(base_learning_rate=0.0002, weight_decay=1e-4), kd_temp=1.0,
                        rel_tol=4e-2, state_tol=5e-2, mom_cos=0.1)    # (70 blocks at batch 8: gradient DIRECTIONS are rounding noise -- the sizes are not)
 
 
