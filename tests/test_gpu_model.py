@@ -144,7 +144,9 @@ def test_assemble_r152_forward_and_kd_steps(hip_lib):
   """BASELINE config 5: Assemble-ResNet-152 (alpha 1, beta 2) with knowledge distillation."""
   mp.check_forward_noise_floor('a-r152', 'cuda', 8, 128, golden='noise_floor_a-r152_b8_128')
   mp.check_train_steps('a-r152', 'cuda', 8, 128, 2, dict(base_learning_rate=0.0002, weight_decay=1e-4), kd_temp=1.0,
-                       rel_tol=4e-2, state_tol=5e-2, mom_cos=0.1)    # (70 blocks at batch 8: gradient DIRECTIONS are rounding noise -- the sizes are not)
+                       rel_tol=4e-2, state_tol=5e-2, mom_cos=0.1, dec_band=(0.6, 1.6))
+  # (70 blocks at batch 8: gradient DIRECTIONS are rounding noise -- the sizes are not -- and so is the second digit of a
+  # two-step loss decrease: the oracle's own decrease moves between 0.35 and 0.64 with its CPU thread count)
 
 
 def test_step_is_deterministic(hip_lib):
