@@ -1,4 +1,6 @@
-# same-box A/B: the round-5 tree (git worktree _r5 at 7be2d3e, built in place) against this tree, default bench command, alternating
+# same-box A/B: the round-5 tree against this tree, default bench command, alternating.  Set-up (once, in the container):
+#   git worktree add _r5 7be2d3e && (cd _r5 && python -m assembled_cnn_amd.build)      # _r5/ is git-ignored and travels with gpurun
+# then on the GPU box: bash tools/debug/r6_ab_r5.sh
 for rep in 1 2 3; do
   for t in _r5 .; do
     (cd $t && timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-recipe --no-gradsync 2>/dev/null | python -c "
