@@ -43,6 +43,11 @@ struct WgradArgs {
 #endif
 constexpr int WPX = WG_WPX;   // pixels per step
 
+template <int N>
+struct IC8 {
+  static constexpr int value = N;
+};
+
 __device__ __forceinline__ bf16x4 ds_read_tr(const unsigned char* p) {
   typedef __attribute__((ext_vector_type(4))) short s4;
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -56,10 +61,9 @@ __device__ __forceinline__ int tr_swz(int row) {
   return RB >= 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0);
 }
 
-// BNW = output-channel (dy) tile width: 256 / 128 / 64 / 32, so narrow layers (K = 32 / 64 at 112x112 and 56x56,
+// BNW = output-channel (dy) tile width: 128 / 64 / 32, so narrow layers (K = 32 / 64 at 112x112 and 56x56,
 // where the pixel count is largest) neither waste MFMAs on zero rows nor LDS on empty tiles.  BCW = (tap, channel)
-// column tile: 128, or 256 together with BNW = 256 and 8 waves (each 64 x 128): half the staging loads, index
-// decodes and 3/4 of the LDS fragment reads per MFMA, for the layers whose dW is at least 256 x 256.
+// column tile: 128.  (The 256 x 256 tile of the layers whose dW is at least that large is wgrad8_kernel below.)
 // LIN: 1x1, stride 1, no padding over a densely packed x: output pixel m IS input pixel m and column j IS channel j, so
 // the staging loads need no (image, row, column) decode at all (two multiply-shift divisions, ~25 VALU per row and step in
 // the general form; most weight-gradient launches of a bottleneck network are such 1x1 layers).
@@ -69,8 +73,9 @@ __device__ __forceinline__ int tr_swz(int row) {
 // XOR swizzle of the transposing reads is applied on the SOURCE side (a lane's LDS destination is base + 16 * lane).  Same
 // steps in the same order as the register-staged loop: bit-identical sums.
 template <int BNW, int BCW, bool LIN = false, int NS = 0>
-__global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs p) {
-  constexpr int NTHR = BCW == 256 ? 512 : 256;
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+  static_assert(BCW == 128 && BNW <= 128, "the 256 x 256 tile is wgrad8_kernel");
+  constexpr int NTHR = 256;
   constexpr int WROWB = BCW * 2;            // x tile row bytes
   constexpr int WTILE = WPX * WROWB;
   constexpr int YROWB = BNW * 2;            // dy tile row bytes
@@ -82,19 +87,17 @@ __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs
   constexpr int CY = BNW / 8;               // 16-byte chunks per dy row
   constexpr int YRP = NTHR / CY;            // dy rows staged per pass
   constexpr int YP = WPX / YRP > 0 ? WPX / YRP : 1;             // dy passes (4 / 2 / 1)
-  constexpr bool BIG = BCW == 256;
   constexpr int NT = BNW >= 64 ? 2 : 1;     // 32-row dy tiles per wave
-  constexpr int CT = BIG ? 4 : (BNW == 128 ? 2 : 1);    // 32-col x tiles per wave
-  static_assert(!BIG || BNW == 256, "the 8-wave form is 256 x 256");
+  constexpr int CT = BNW == 128 ? 2 : 1;    // 32-col x tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wn = (BIG || BNW == 128) ? (wave >> 1) : 0;
-  const int wc = (BIG || BNW == 128) ? (wave & 1) : wave;
+  const int wn = BNW == 128 ? (wave >> 1) : 0;
+  const int wc = BNW == 128 ? (wave & 1) : wave;
   const int nbase = wn * 64;                                        // wave's first dy channel within the tile
-  const int cbase = wc * (BIG ? 128 : (BNW == 128 ? 64 : 32));      // wave's first column within the tile
+  const int cbase = wc * (BNW == 128 ? 64 : 32);                    // wave's first column within the tile
 
   // block -> (split, tile_n, tile_c): tiles of one split adjacent (they re-read the same pixels)
   // XCD-aware bijective remap (block b runs on XCD b % 8, each XCD has its own L2): give every XCD a
@@ -232,7 +235,13 @@ __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs
   };
 
   if constexpr (NS >= 2) {
-    static_assert(LIN && !BIG, "the ring form covers the linear-address 128-column tiles");
+    static_assert(LIN, "the ring form covers the linear-address layers");
+    // NOTE (round 6): behind a compiler-visible LDS read (the ds_read_tr builtin) hipcc waits for EVERY outstanding LDS-DMA --
+    // s_waitcnt vmcnt(0) before the first fragment read of a step, i.e. also for the tiles requested a moment earlier -- so
+    // inside one workgroup this ring overlaps nothing and depths 3 / 4 are the same loop with less occupancy; the overlap comes
+    // from the second workgroup on the CU.  Hiding the reads in inline asm with hand-counted lgkmcnt (what wgrad8_kernel does)
+    // was measured here too (tools/gemm1_sweep.py --wgrad, same box, every 1x1 layer at batch 256): 2751 against 2780 us per
+    // step summed over the layers, single layers +-10 % either way -- within the noise, so the simpler form stays.
     typedef __attribute__((address_space(3))) void* lptr_t;
     constexpr int YPW = YROWB == 256 ? 4 : (YROWB == 128 ? 2 : 1);   // dy pieces (1 KiB) per wave and step
     constexpr int P = 4 + YPW;
@@ -282,20 +291,6 @@ __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs
       compute(cur);
       cur = cur + 1 == NS ? 0 : cur + 1;
     }
-  } else if constexpr (BIG) {
-    // one register tile set (two would not fit beside 128 accumulator registers): tile k+1 is in flight in
-    // registers while tile k is multiplied; a 256 x 256 step is 32 MFMAs per wave, twice the cover of a 128 x 128 one
-    load_tile(0, ya, xa);
-    store_tile(0, ya, xa);
-    __syncthreads();
-#pragma unroll 1
-    for (int step = 0; step < steps; ++step) {
-      const int cur = step & 1;
-      load_tile(step + 1, ya, xa);
-      compute(cur);
-      store_tile(cur ^ 1, ya, xa);
-      __syncthreads();
-    }
   } else {
   // steps beyond the range load nothing (m >= m_end -> zeros), so the pair loop needs no tail branch
   load_tile(0, ya, xa);
@@ -327,6 +322,206 @@ __global__ __launch_bounds__(BCW == 256 ? 512 : 256) void wgrad_kernel(WgradArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = tile_n * BNW + nbase + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (n < p.Co) out[(size_t)n * p.cols + col] = acc[a][b][r];
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// wgrad8_kernel: the 256 x 256 weight-gradient tile on a wave-staggered, multi-phase main loop (conv_igemm8.hip is the forward /
+// input-gradient twin; same reasoning, different operand geometry).
+//
+// Same math and the same (pixel block of 16, MFMA) accumulation order as wgrad_kernel<256, 256> on the same plan -- bit-identical
+// sums.  What differs is how the operands travel:
+//   * a PHASE is one 16-pixel block of the reduction: 12 transposing fragment reads, 8 MFMAs 32x32x16 on the wave's 8 accumulators
+//     (no MFMA depends on one nearer than 8 issue slots);
+//   * LDS is a ring of eight such blocks per operand (dy: 16 rows x 512 B, x: 16 rows x 512 B; 2 x 64 KB), filled by LDS-DMA: in
+//     phase g every wave requests its two rows of block g + 6 (one dy piece, one x piece of 1 KB) -- no staging registers, no
+//     ds_write, no (image, row, column) decode for more than ONE pixel per lane and phase;
+//   * the DMA never drains: vmcnt(10) in phase g retires block g + 1 (requested five phases earlier), the barriers are raw;
+//   * waves w and w + 4 (one SIMD) run ONE BARRIER APART: in every barrier interval one of them multiplies (s_setprio 1) while the
+//     other reads fragments and issues DMA.
+//   Write-after-read: block g + 6 lands in the slot of block g - 2; its readers retired their reads in phase g - 2 (lgkmcnt(0)
+//     behind that phase's first barrier) and the staggered group is one barrier late: at least three barriers in between.
+//   Read-after-write: a wave's wait for block g + 1 sits before the first barrier of ITS phase g; the first read of that block
+//     (phase g + 1 of the group that is ahead) is behind the second one.
+// Blocks past the end of the pixel range are requested at the out-of-range offset (zero-fill; their products are zeros): the
+// counted waits need no tail case.
+template <bool LIN>
+__global__ __launch_bounds__(512) void wgrad8_kernel(WgradArgs p) {
+    constexpr int ROWB = 512, BLK = 16 * ROWB, RING = 8, XBASE = RING * BLK, DIST = 6, INFL = 2 * (DIST - 1);
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x 64 KB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                       // waves w and w + 4 share a SIMD: one of each group per SIMD
+  const int wn = wave >> 1, wc = wave & 1;
+  const int nbase = wn * 64, cbase = wc * 128;
+
+  int bid;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles = p.tiles_n * p.tiles_c;
+  const int split = bid / tiles;
+  bid -= split * tiles;
+  const int tile_n = bid / p.tiles_c;
+  const int tile_c = bid - tile_n * p.tiles_c;
+
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int groups = (m_end - m_begin + 127) >> 7;          // eight phases = 128 pixels per trip of the loop
+
+  // ---- what this lane requests in every phase: row rb of the block, 16-byte piece cp of the row (source-side swizzle) ----
+  const int rb = 2 * wave + (lane >> 5), cp = lane & 31;
+  const int lc = cp ^ tr_swz<ROWB>(rb);
+  const int j0 = tile_c * 256 + lc * 8;
+  const bool col_ok = j0 < p.cols;
+  int tap_c = 0, dr = 0, ds = 0;
+  if (!LIN && col_ok) {
+    const int t = j0 / p.Ci;
+    tap_c = j0 - t * p.Ci;
+    const int tr = t / p.S;
+    dr = tr - p.pad;
+    ds = (t - tr * p.S) - p.pad;
+  }
+  const int n0 = tile_n * 256 + lc * 8;
+  const bool n_ok = n0 < p.Co;
+  unsigned char* const ydst = smem + 2 * wave * ROWB;
+  unsigned char* const xdst = smem + XBASE + 2 * wave * ROWB;
+  int mrow = m_begin + rb;                                   // the pixel of the next block to request
+
+  // branch-free on purpose (bitwise tests, selects): a short-circuit here becomes exec-masked control flow around the requests
+  auto request = [&](const int slot) {
+    const int m = mrow;
+    mrow += 16;
+    const unsigned mok = (unsigned)(m < m_end);
+    const unsigned offy = ((unsigned)m * (unsigned)p.ldy + (unsigned)n0) * 2u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lptr_t)(ydst + slot * BLK), 16, (int)((mok & (unsigned)n_ok) ? offy : ASM_OOB), 0, 0, 0);
+    unsigned offx, ok = mok & (unsigned)col_ok;
+    if constexpr (LIN) {
+      offx = ((unsigned)m * (unsigned)p.Ci + (unsigned)j0) * 2u;
+    } else {
+      const unsigned um = (unsigned)min(m, p.M - 1);
+      const unsigned img = fd_div(um, p.fd_howo);
+      const unsigned rem = um - img * (unsigned)p.HoWo;
+      const unsigned ho = fd_div(rem, p.fd_wo);
+      const unsigned wo = rem - ho * (unsigned)p.Wo;
+      const int ih = (int)ho * p.so + dr;
+      const int iw = (int)wo * p.so + ds;
+      ok &= (unsigned)((unsigned)ih < (unsigned)p.Hi) & (unsigned)((unsigned)iw < (unsigned)p.Wi);
+      offx = (img * (unsigned)p.x_img_pitch + (unsigned)ih * (unsigned)p.x_row_pitch + (unsigned)iw * (unsigned)p.x_pix_pitch +
+              (unsigned)tap_c) * 2u;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xdst + slot * BLK), 16, (int)(ok ? offx : ASM_OOB), 0, 0, 0);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // transposing-read lane geometry (wgrad_kernel): the two reads of a fragment are rows `row` and `row + 4` of the block
+  const int t16 = lane & 15, g4 = lane >> 4;
+  const int colsel = (g4 & 1) * 16, tcol = (t16 & 3) * 4;
+  const int row = (g4 >> 1) * 8 + (t16 >> 2);              // (row + 4) & 3 == row & 3: one swizzle term for both
+  unsigned fyo[2], fxo[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int cy = nbase + a * 32 + colsel + tcol;
+    fyo[a] = (unsigned)(row * ROWB + ((((cy >> 3) ^ tr_swz<ROWB>(row)) << 4) | ((cy & 4) << 1)));
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int cx = cbase + b * 32 + colsel + tcol;
+    fxo[b] = (unsigned)(XBASE + row * ROWB + ((((cx >> 3) ^ tr_swz<ROWB>(row)) << 4) | ((cx & 4) << 1)));
+  }
+
+  // ---- pipeline fill: blocks 0 .. 5; block 0 has landed behind vmcnt(10) ----
+#pragma unroll
+  for (int s = 0; s < DIST; ++s) request(s);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
+
+  // The fragment reads are inline asm: behind a compiler-visible LDS read hipcc drains every outstanding LDS-DMA (s_waitcnt
+  // vmcnt(0) before the first ds_read of each phase -- the whole ring would be pointless).  Their completion is counted by the
+  // lgkmcnt(0) statement below, which names every destination (cdna_hip_programming.md 5.7, form (ii)).
+  typedef __attribute__((ext_vector_type(4))) short s4;
+#define WG8_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+  auto phase = [&](auto sc) {
+    constexpr int S = decltype(sc)::value;
+    s4 y0[2], y1[2], x0[4], x1[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      WG8_TR(y0[a], fyo[a], S * BLK);
+      WG8_TR(y1[a], fyo[a], S * BLK + 4 * ROWB);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      WG8_TR(x0[b], fxo[b], S * BLK);
+      WG8_TR(x1[b], fxo[b], S * BLK + 4 * ROWB);
+    }
+    request((S + DIST) % RING);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(y0[0]), "+v"(y1[0]), "+v"(y0[1]), "+v"(y1[1]), "+v"(x0[0]), "+v"(x1[0]), "+v"(x0[1]), "+v"(x1[1]),
+                   "+v"(x0[2]), "+v"(x1[2]), "+v"(x0[3]), "+v"(x1[3])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fy[2], fx[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+      fy[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(y0[a], y1[a], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      fx[b] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x0[b], x1[b], 0, 1, 2, 3, 4, 5, 6, 7));
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                      "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+#undef WG8_TR
+#pragma unroll 1
+  for (int gi = 0; gi < groups; ++gi) {
+    phase(IC8<0>{}); phase(IC8<1>{}); phase(IC8<2>{}); phase(IC8<3>{});
+    phase(IC8<4>{}); phase(IC8<5>{}); phase(IC8<6>{}); phase(IC8<7>{});
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();      // group 0 waits for group 1's last phase
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the zero-fill requests past the end
+
+  float* out = p.out + (size_t)split * p.Co * p.cols;
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = tile_c * 256 + cbase + b * 32 + l31;
+      if (col < p.cols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = tile_n * 256 + nbase + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           if (n < p.Co) out[(size_t)n * p.cols + col] = acc[a][b][r];
         }
       }
@@ -530,13 +725,17 @@ Plan make_plan(const asm_conv_desc* d) {
   const int cols = d->R * d->S * d->C;
   pl.bnw = (d->K <= 32 && WPX == 64) ? 32 : (d->K <= 64 ? 64 : 128);
   pl.bcw = 128;
-  // 256 x 256 / 8 waves when dW tiles exactly (no padded MFMAs) and there is enough of it; ASM_WGRAD_BIG=0/1 forces
+  // 256 x 256 / 8 waves (wgrad8_kernel) when dW tiles exactly (no padded MFMAs) and there is enough of it; ASM_WGRAD_BIG=0/1
+  // forces.  Round-6 same-box sweep of wgrad8 against the 128-wide kernels at batch 256 (tools/conv_bench.py --kinds wgrad,
+  // ASM_WGRAD_BIG=1 against the default): 3x3 layers win from 30 GFLOP up (7x7x256->512 69 -> 61 us, 14x14x128->256 60 -> 56 us;
+  // the >= 118 GFLOP ones 13 - 15 %); 1x1 layers from 53 GFLOP up, also with one column tile (28x28x256->512 92 -> 83 us), and lose
+  // 10 - 20 % at 26 GFLOP and below.  Column padding of up to 1/8 (3x3 with 128 input channels: 1152 -> 1280) still nets a win.
   const int big_env = asm_tune().wgrad_big;
-  // measured: -13..-20 % on the layers with >= 40 GFLOP, +5..+20 % on the small 7x7 / narrow ones; column padding
-  // of up to 1/8 (3x3 with 128 input channels: 1152 -> 1280 columns) still nets -14 %
   const int cpad = cdiv(cols, 256) * 256;
-  bool big = d->K % 256 == 0 && cols >= 512 && (cpad - cols) * 8 <= cpad &&
-             2.0 * (double)M * d->K * cols >= 40e9;
+  const double gflop = 2.0 * (double)M * d->K * cols * 1e-9;
+  const bool taps = d->R * d->S > 1;
+  bool big = d->K % 256 == 0 && (cpad - cols) * 8 <= cpad &&
+             (taps ? (cols >= 512 && gflop >= 25.0) : (cols >= 256 && gflop >= 40.0));
   if (big_env == 0) big = false;
   if (big_env == 1 && d->K >= 256 && cols >= 256) big = true;
   if (big) pl.bnw = pl.bcw = 256;
@@ -701,17 +900,17 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
     else if (pl.bnw == 64) ASM_LAUNCH((wgrad_kernel<64, 128, true>), grid, dim3(256), 2 * (WPX * 128 + WPX * 256), st, a);
     else ASM_LAUNCH((wgrad_kernel<32, 128, true>), grid, dim3(256), 2 * (WPX * 64 + WPX * 256), st, a);
   } else if (pl.bcw == 256) {
-    constexpr int LDS = 2 * (WPX * 512 + WPX * 512);   // 128 KiB
-    static bool attr_done[ASM_MAX_DEVICES] = {};
-    if (hipError_t e = asm_ensure_dyn_lds(wgrad_kernel<256, 256>, LDS, attr_done); e != hipSuccess)
-      ASM_FAIL(ASM_EHIP, "wgrad_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
+    constexpr int LDS = 2 * 8 * 16 * 512;              // 128 KiB: two rings of eight 16-pixel blocks
     if (lin) {
       static bool attr_done_l[ASM_MAX_DEVICES] = {};
-      if (hipError_t e = asm_ensure_dyn_lds(wgrad_kernel<256, 256, true>, LDS, attr_done_l); e != hipSuccess)
-        ASM_FAIL(ASM_EHIP, "wgrad_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
-      ASM_LAUNCH((wgrad_kernel<256, 256, true>), grid, dim3(512), LDS, st, a);
+      if (hipError_t e = asm_ensure_dyn_lds(wgrad8_kernel<true>, LDS, attr_done_l); e != hipSuccess)
+        ASM_FAIL(ASM_EHIP, "wgrad8_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
+      ASM_LAUNCH((wgrad8_kernel<true>), grid, dim3(512), LDS, st, a);
     } else {
-      ASM_LAUNCH((wgrad_kernel<256, 256>), grid, dim3(512), LDS, st, a);
+      static bool attr_done[ASM_MAX_DEVICES] = {};
+      if (hipError_t e = asm_ensure_dyn_lds(wgrad8_kernel<false>, LDS, attr_done); e != hipSuccess)
+        ASM_FAIL(ASM_EHIP, "wgrad8_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
+      ASM_LAUNCH((wgrad8_kernel<false>), grid, dim3(512), LDS, st, a);
     }
   } else if (pl.bnw == 128) {
     ASM_LAUNCH((wgrad_kernel<128, 128>), grid, dim3(256), 2 * (WPX * 256 + WPX * 256), st, a);

@@ -176,7 +176,7 @@ def test_every_conv_shape_on_an_8_image_slice_vs_oracle(hip_lib, workload):
 
 
 BIG_WGRAD_SHAPES = [
-    # N, H,  W,  C,   K,   k, stride        what it exercises in wgrad_kernel<256, 256>
+    # N, H,  W,  C,   K,   k, stride        what it exercises in wgrad8_kernel (the 256 x 256 tile)
     (2, 14, 14, 128, 256, 3, 1),     # 1152 columns -> 5 column tiles, the last one half empty; 392 pixels (ragged steps)
     (3, 7, 7, 256, 512, 1, 1),       # 256 columns exactly, two dy row-tiles, 147 pixels
     (2, 14, 14, 256, 256, 3, 2),     # strided gather, 98 pixels (< 2 steps)
@@ -208,7 +208,7 @@ def test_wgrad_256x256_kernel_forced_vs_oracle(hip_lib, shape, splits, monkeypat
   yr = O._conv_raw(x.float().permute(0, 3, 1, 2), wr.permute(1, 2, 3, 0), k, stride)
   (gw,) = torch.autograd.grad(yr, [wr], dy.float().permute(0, 3, 1, 2))
   r = util.rel_l2(dw.cpu(), gw)
-  assert r <= 2e-3, 'wgrad<256,256> rel_l2 %.3e (plan %s)' % (r, plan)
+  assert r <= 2e-3, 'wgrad8 rel_l2 %.3e (plan %s)' % (r, plan)
   # the same call with the 128-wide kernels gives the same numbers up to summation order
   util.set_knob(monkeypatch, 'ASM_WGRAD_BIG', '0')
   dw0 = torch.empty_like(dw)

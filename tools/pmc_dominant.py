@@ -41,7 +41,7 @@ def main():
                       or k.startswith('igemm8_kernel<true')],
             'dgrad': [k for k in f if (k.startswith('igemm2_kernel') and ', false, 3, 3' in k) or k.startswith('igemm3_kernel<128, false')
                       or k.startswith('igemm8_kernel<false')],
-            'wgrad': [k for k in f if k.startswith('wgrad_')]}
+            'wgrad': [k for k in f if k.startswith('wgrad')]}
   res = {'_about': 'HBM-side traffic per launch, N256 14x14x512 -> 1024 3x3/1, from separate rocprofv3 --pmc FETCH_SIZE / '
                    '--pmc WRITE_SIZE passes over tools/conv_bench.py (see tools/pmc_dominant.py); KiB counters, fetch x 2.'}
   for kind, ks in groups.items():

@@ -27,7 +27,7 @@ def load(d, counter):
 def conv3x3(k):
   """3x3 convolution class by kernel name: igemm2 with a multi-tap filter that is not a stem row filter (3x3 and the
   1x2 / 2x1 / 2x2 parity sub-filters of a stride-2 3x3 input gradient), the resident-halo kernels, and the general
-  (non linear-address) weight-gradient kernel, which on this network runs the 3x3 layers and the two stems."""
+  (non linear-address) weight-gradient kernels (wgrad_kernel, wgrad8_kernel), which on this network run the 3x3 layers and the two stems."""
   m = re.match(r'igemm2?_kernel<([^>]*)', k)
   if m:
     a = [t.strip() for t in m.group(1).split(',')]
@@ -36,7 +36,7 @@ def conv3x3(k):
       return r * q > 1 and q != 1 or (r, q) == (2, 1)
     return False
   return (k.startswith('conv_halo_kernel') or k.startswith('wgrad_halo_kernel') or k.startswith('igemm3_kernel') or
-          bool(re.match(r'wgrad_kernel<\d+, \d+, false', k)))
+          bool(re.match(r'wgrad_kernel<\d+, \d+, false', k)) or k.startswith('wgrad8_kernel<false'))
 
 
 def bn_family(k):
