@@ -744,23 +744,35 @@ Plan make_plan(const asm_conv_desc* d) {
   const int tiles = pl.tiles_n * pl.tiles_c;
   const int msteps = cdiv(M, WPX);
   // Split count from a small cost model (microseconds): the MFMA/stream time scales with how evenly
-  // tiles*splits blocks fill the resident slots (256 CUs x 2..4 workgroups), the slab path costs
+  // tiles*splits blocks fill the resident slots (256 CUs x 1..4 workgroups), the slab path costs
   // (splits + 1) x |dW| of fp32 traffic.  With the XCD-contiguous block order every split's pixel range stays
-  // on one XCD's L2, so extra splits do not add HBM reads of x / dy.
+  // on one XCD's L2, so extra splits do not add HBM reads of x / dy -- as long as the splits do not straddle XCDs:
+  // Round-6 sweep (tools/wgrad_split_sweep.py, every layer at batch 256, same box): with several tiles per split a split
+  // count that is a multiple of 8 gives every XCD whole splits, and one that is not costs 8 - 15 % (56x56x64 -> 128 3x3:
+  // 96 splits 179 us, 102 splits 206; 28x28x256 -> 512 1x1: 96 splits 78 us, 126 splits 94).  The 256 x 256 tile (one 128 KB
+  // workgroup per CU) pays ~12 us per round of the chip in pipeline fill and slab epilogue, and an under-full single round
+  // costs it less than its share of idle CUs (the busy ones clock higher: 14x14x512 -> 1024 3x3 on 216 of 256 CUs in one round
+  // 404 us, on 504 workgroups in two rounds 430).
   const size_t wbytes = (size_t)d->K * cols * sizeof(float);
   const double flops = 2.0 * (double)M * d->K * cols;
   const double io_bytes = 2.0 * ((double)M * d->C + (double)M * d->K);
-  const double work_us = fmax(flops / 6.0e8, io_bytes / 4.0e6);      // ~600 TFLOP/s or ~4 TB/s
+  const bool big8 = pl.bnw == 256;
+  const double work_us = fmax(flops / (big8 ? 9.0e8 : 6.0e8), io_bytes / 4.0e6);      // ~900 / ~600 TFLOP/s or ~4 TB/s
   const int slots = 256 * (pl.bnw == 256 ? 1 : (pl.bnw == 128 ? 2 : (pl.bnw == 64 ? 3 : 4))) * (64 / WPX);
   const int max_splits = msteps / 4 > 0 ? msteps / 4 : 1;            // at least 4 steps per block
   int splits = 1;
   double best = 1e30;
-  for (int sp = 1; sp <= 256 && sp <= max_splits; ++sp) {
+  for (int req = 1; req <= 256 && req <= max_splits; ++req) {
+    const int sp = cdiv(msteps, cdiv(msteps, req));                   // the split count a request for `req` ends up with
+    if (sp != req) continue;
     const double blocks = (double)tiles * sp;
-    const double fill = ceil(blocks / slots) / (blocks / slots);      // >= 1: quantisation of the last round
-    const double under = blocks < slots ? (double)slots / blocks * 0.5 + 0.5 : 1.0;  // too few blocks: less overlap
+    const double rounds = ceil(blocks / slots);
+    const double fill = rounds / (blocks / slots);                    // >= 1: quantisation of the last round
+    const double under = blocks >= slots ? 1.0                        // too few blocks: less overlap
+                         : (big8 ? 1.0 + 0.35 * ((double)slots / blocks - 1.0) : (double)slots / blocks * 0.5 + 0.5);
+    const double straddle = (tiles > 1 && sp > 8 && sp % 8 != 0) ? 1.08 : 1.0;
     const double slab = sp > 1 ? ((double)(sp + 1) * wbytes / 4.0e6 + 4.0) : 0.0;
-    const double est = work_us * (blocks < slots ? under : fill) + slab;
+    const double est = work_us * (blocks < slots ? under : fill) * straddle + slab + (big8 ? 12.0 * rounds : 0.0);
     if (est < best) {
       best = est;
       splits = sp;
