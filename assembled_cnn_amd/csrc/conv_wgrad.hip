@@ -559,45 +559,61 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 
 // ------------------------------------------------------------------------------------------------------------
-// wgrad_halo_kernel: weight gradient of the NARROW 3x3 stride-1 layers at high resolution (C, K in {32, 64}; 112 x 112
-// maps), persistent.  The general kernel gathers one x tile PER TAP COLUMN GROUP, i.e. reads (nearly) the same pixels 9
-// times through L2; here a workgroup walks a contiguous run of 8 x 16 pixel patches, stages the patch's dy rows and the
-// 10 x 18 halo of x in LDS once, and accumulates ALL nine taps of dW[k][t][c] in registers from them (transposing
-// ds_read_b64_tr_b16 fragments, tap shifts are plain row offsets into the halo).  The next patch is prefetched into
-// registers under the MFMAs.  One fp32 slab per workgroup, summed by wgrad_reduce_kernel in fixed order (deterministic).
-template <int KF, int CI>
+// wgrad_halo_kernel: weight gradient of the NARROW 3x3 stride-1 layers (C in {32, 64}, K in {32, 64, 128}), persistent.
+// The general kernel gathers one x tile PER TAP COLUMN GROUP, i.e. reads (nearly) the same pixels 9 times through L2 and spends
+// more VALU on the (image, row, column) decode of its gather than MFMA cycles on these layers (28 % MFMA-busy; 56x56x64 -> 128 at
+// batch 256 takes 300 us in the step, six times its bound).  Here a workgroup walks a contiguous run of pixel PATCHES of one
+// image -- PH x PW pixels: 8 x 16 on the 112 x 112 maps, whole-row bands of 2 x 56 / 4 x 28 on the 56 x 56 / 28 x 28 ones -- stages
+// the patch's dy rows and the (PH + 2) x (PW + 2) halo of x in LDS once, and accumulates ALL nine taps of dW[k][t][c] in
+// registers from them (transposing ds_read_b64_tr_b16 fragments; a tap is a constant offset into the halo).  The reduction runs
+// over the patch's pixels in groups of 16 (a group may straddle image rows: every lane addresses its own pixel).  The next patch
+// is prefetched into registers under the MFMAs.  With K = 128 a workgroup owns one 64-channel half of dy (two workgroups per
+// patch run, adjacent in the XCD-contiguous order: the second one's x halo comes from L2).  One fp32 slab [K][9 C] per patch
+// run, summed by wgrad_reduce_kernel in fixed order (deterministic).
+// NW waves per workgroup: 4 (two workgroups per CU), or 8 for the 64 x 64 channel form -- its 36 accumulator units are 9 per wave
+// on four waves (144 accumulator + 144 other registers: one wave per SIMD, i.e. ONE four-wave workgroup per CU and nothing to
+// overlap a patch's staging with); on eight waves 5 per wave, 2 waves per SIMD.
+template <int KF, int CI, int PH, int PW, int NW = (KF == 64 && CI == 64 ? 8 : 4)>
 struct WHalo {
+  static constexpr int NTHR = 64 * NW;
+  static constexpr int PPX = PH * PW, NKK = PPX / 16;            // pixels per patch (128 / 112), reduction groups
+  static constexpr int HWD = PW + 2, NHP = (PH + 2) * HWD;       // halo width, halo pixels
   static constexpr int XRB = CI == 32 ? 64 : 192;    // row strides = 16 dwords mod 64: the 4 pixel rows of a transposing
   static constexpr int YRB = KF == 32 ? 64 : 192;    // read land on disjoint banks (C = 64: 128 data + 64 pad bytes)
-  static constexpr int XS = 180 * XRB, YS = 128 * YRB;
+  static constexpr int XS = NHP * XRB, YS = PPX * YRB;
   static constexpr int LDS = XS + YS;
   static constexpr int KT = KF / 32, CT = CI / 32;
   static constexpr int NU = KT * CT * 9;             // 32 x 32 accumulator units (tap, k-tile, c-tile)
-  static constexpr int UPW = (NU + 3) / 4;           // per wave
-  static constexpr int NVX = 180 * (CI / 8), NVY = 128 * (KF / 8);
-  static constexpr int HPX = (NVX + 255) / 256, HPY = NVY / 256;
+  static constexpr int UPW = (NU + NW - 1) / NW;     // per wave
+  static constexpr int NVX = NHP * (CI / 8), NVY = PPX * (KF / 8);
+  static constexpr int HPX = (NVX + NTHR - 1) / NTHR, HPY = (NVY + NTHR - 1) / NTHR;
+  static_assert(PPX % 16 == 0 && LDS <= 80 * 1024, "patch");
 };
 
-template <int KF, int CI>
-__global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
-  using W = WHalo<KF, CI>;
-  constexpr int XRB = W::XRB, YRB = W::YRB, CPX = CI / 8, CPY = KF / 8;
+template <int KF, int CI, int PH, int PW>
+__global__ __launch_bounds__((WHalo<KF, CI, PH, PW>::NTHR)) void wgrad_halo_kernel(WgradArgs p) {
+  using W = WHalo<KF, CI, PH, PW>;
+  constexpr int XRB = W::XRB, YRB = W::YRB, CPX = CI / 8, CPY = KF / 8, HWD = W::HWD, NTHR = W::NTHR, NW = NTHR / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xs = smem;
   unsigned char* ys = smem + W::XS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  const int n_m = p.M >> 7;
-  int t_begin, t_end, logical;
+  const int khalves = p.tiles_n;                     // K / KF workgroups per patch run
+  const int tiles_x = p.Wi / PW, tpi = tiles_x * (p.Hi / PH);
+  const int n_m = (p.M / (p.Hi * p.Wi)) * tpi;       // patches
+  int t_begin, t_end, logical, khalf;
   {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
     const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous runs of patches
-    const int per = n_m / nb, extra = n_m - per * nb;
+    const int lg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous runs of patches
+    logical = lg / khalves;
+    khalf = lg - logical * khalves;
+    const int runs = nb / khalves;
+    const int per = n_m / runs, extra = n_m - per * runs;
     t_begin = logical * per + (logical < extra ? logical : extra);
     t_end = t_begin + per + (logical < extra ? 1 : 0);
   }
-  const int tiles_x = p.Wi >> 4, tpi = tiles_x * (p.Hi >> 3);
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
 
@@ -605,12 +621,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
   auto load_patch = [&](int tile) {
     const int img = tile / tpi, trem = tile - img * tpi;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    const int y0 = ty * 8, x0 = tx * 16;
+    const int y0 = ty * PH, x0 = tx * PW;
 #pragma unroll
     for (int k = 0; k < W::HPX; ++k) {
-      const int i = k * 256 + tid;
+      const int i = k * NTHR + tid;
       const int hp = i / CPX, ck = i - hp * CPX;
-      const int hyy = hp / 18, hxx = hp - hyy * 18;
+      const int hyy = hp / HWD, hxx = hp - hyy * HWD;
       const int gy = y0 - 1 + hyy, gx = x0 - 1 + hxx;
       const bool ok = (i < W::NVX) && ((unsigned)gy < (unsigned)p.Hi) && ((unsigned)gx < (unsigned)p.Wi);
       const unsigned off = (((unsigned)img * (unsigned)p.Hi + (unsigned)gy) * (unsigned)p.Wi + (unsigned)gx) * (unsigned)p.Ci * 2u +
@@ -619,24 +635,48 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
     }
 #pragma unroll
     for (int k = 0; k < W::HPY; ++k) {
-      const int i = k * 256 + tid;
+      const int i = k * NTHR + tid;
       const int row = i / CPY, ck = i - row * CPY;
-      const unsigned m = ((unsigned)img * (unsigned)p.Hi + (unsigned)(y0 + (row >> 4))) * (unsigned)p.Wi + (unsigned)(x0 + (row & 15));
-      hy[k] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (m * (unsigned)p.ldy + (unsigned)ck * 8u) * 2u, 0, 0);
+      const int ry = row / PW, rxx = row - ry * PW;
+      const unsigned m = ((unsigned)img * (unsigned)p.Hi + (unsigned)(y0 + ry)) * (unsigned)p.Wi + (unsigned)(x0 + rxx);
+      hy[k] = __builtin_amdgcn_raw_buffer_load_b128(
+          rdy, i < W::NVY ? (m * (unsigned)p.ldy + (unsigned)(khalf * KF) + (unsigned)ck * 8u) * 2u : ASM_OOB, 0, 0);
     }
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int k = 0; k < W::HPX; ++k) {
-      const int i = k * 256 + tid;
+      const int i = k * NTHR + tid;
       const int hp = i / CPX, ck = i - hp * CPX;
       if (i < W::NVX) *reinterpret_cast<u32x4*>(xs + hp * XRB + ck * 16) = hx[k];
     }
 #pragma unroll
     for (int k = 0; k < W::HPY; ++k) {
-      const int i = k * 256 + tid;
+      const int i = k * NTHR + tid;
       const int row = i / CPY, ck = i - row * CPY;
-      *reinterpret_cast<u32x4*>(ys + row * YRB + ck * 16) = hy[k];
+      if (i < W::NVY) *reinterpret_cast<u32x4*>(ys + row * YRB + ck * 16) = hy[k];
+    }
+  };
+
+  // Which accumulator units (tap t, k-tile kt, c-tile ct) a wave owns.  General: unit wave + NW * i of the (t, kt, ct) order.
+  // The eight-wave 64 x 64 form (36 units, two k-tiles): the two k-tiles of a (t, ct) PAIR multiply the same x fragment, so a wave
+  // takes pairs -- units 0 - 3 = pairs 2 w and 2 w + 1, and waves 0 - 3 one more unit, half of pairs 16 / 17: 6 instead of 10 x
+  // fragment reads per 16 pixels for the five-unit waves (the LDS pipe, not the MFMA pipe, bounds this kernel).
+  constexpr bool PAIRED = NW == 8 && W::KT == 2 && W::NU == 36;
+  auto unit_of = [&](const int i, int& t, int& kt, int& ct) -> bool {
+    if constexpr (PAIRED) {
+      const int pair = i < 4 ? 2 * wave + (i >> 1) : 16 + (wave >> 1);
+      kt = i < 4 ? (i & 1) : (wave & 1);
+      t = pair / W::CT;
+      ct = pair - t * W::CT;
+      return i < 4 || wave < 4;
+    } else {
+      const int u = wave + NW * i;
+      t = u / (W::KT * W::CT);
+      const int rem = u - t * (W::KT * W::CT);
+      kt = rem / W::CT;
+      ct = rem - kt * W::CT;
+      return u < W::NU;
     }
   };
 
@@ -649,7 +689,15 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
   // transposing-read lane geometry (see wgrad_kernel): lane l of a 32x32x16 operand = channel l & 31, pixels (l >> 5) * 8 ..
   const int t16 = lane & 15, g = lane >> 4;
   const int chan = (g & 1) * 16 + (t16 & 3) * 4;    // first of this lane's 4 source channels within a 32-channel tile
-  const int prow = (g >> 1) * 8 + (t16 >> 2);       // source pixel within the 16-pixel patch row (second read: + 4)
+  const int prow = (g >> 1) * 8 + (t16 >> 2);       // source pixel within the 16-pixel reduction group (second read: + 4)
+  // halo row (tap (0, 0)) of this lane's two source pixels of every reduction group, in bytes
+  unsigned hb0[W::NKK], hb1[W::NKK];
+#pragma unroll
+  for (int kk = 0; kk < W::NKK; ++kk) {
+    const int p0 = kk * 16 + prow, p1 = p0 + 4;
+    hb0[kk] = (unsigned)(((p0 / PW) * HWD + p0 % PW) * XRB);
+    hb1[kk] = (unsigned)(((p1 / PW) * HWD + p1 % PW) * XRB);
+  }
 
   if (t_begin < t_end) load_patch(t_begin);
 #pragma unroll 1
@@ -659,7 +707,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
     __syncthreads();
     if (tile + 1 < t_end) load_patch(tile + 1);
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {    // patch row kk = 16 reduction pixels
+    for (int kk = 0; kk < W::NKK; ++kk) {    // 16 reduction pixels
       bf16x8 fy[W::KT];
 #pragma unroll
       for (int kt = 0; kt < W::KT; ++kt) {
@@ -667,32 +715,31 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
         const bf16x4 y0 = ds_read_tr(a), y1 = ds_read_tr(a + 4 * YRB);
         fy[kt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
+      bf16x8 fx;
 #pragma unroll
       for (int i = 0; i < W::UPW; ++i) {
-        const int u = wave + 4 * i;                 // wave-uniform
-        if (u < W::NU) {
-          const int t = u / (W::KT * W::CT), rem = u - t * (W::KT * W::CT);
-          const int kt = rem / W::CT, ct = rem - kt * W::CT;
-          const int r = t / 3, q = t - r * 3;
-          const unsigned char* b = xs + ((kk + r) * 18 + q + prow) * XRB + (ct * 32 + chan) * 2;
-          const bf16x4 x0 = ds_read_tr(b), x1 = ds_read_tr(b + 4 * XRB);
-          const bf16x8 fx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        int t, kt, ct;
+        if (unit_of(i, t, kt, ct)) {                // wave-uniform
+          if (!(PAIRED && i < 4 && (i & 1))) {      // (the second unit of a pair multiplies the same x fragment)
+            const int r = t / 3, q = t - r * 3;
+            const unsigned tapo = (unsigned)((r * HWD + q) * XRB + (ct * 32 + chan) * 2);
+            const bf16x4 x0 = ds_read_tr(xs + hb0[kk] + tapo), x1 = ds_read_tr(xs + hb1[kk] + tapo);
+            fx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
           const bf16x8 fa = (W::KT == 1 || kt == 0) ? fy[0] : fy[W::KT - 1];   // static register indices only
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fx, acc[i], 0, 0, 0);
         }
       }
     }
   }
-  // this workgroup's partial dW: slab [logical][KF][9 * CI]
+  // this workgroup's partial dW: rows [khalf * KF, + KF) of slab [logical][K][9 * CI]
   const int cols = 9 * CI;
-  float* out = p.out + (size_t)logical * KF * cols;
+  float* out = p.out + ((size_t)logical * p.Co + (size_t)khalf * KF) * cols;
   const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
   for (int i = 0; i < W::UPW; ++i) {
-    const int u = wave + 4 * i;
-    if (u < W::NU) {
-      const int t = u / (W::KT * W::CT), rem = u - t * (W::KT * W::CT);
-      const int kt = rem / W::CT, ct = rem - kt * W::CT;
+    int t, kt, ct;
+    if (unit_of(i, t, kt, ct)) {
       const int col = t * CI + ct * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -703,16 +750,31 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs p) {
   }
 }
 
-// workgroups of the persistent halo form for this layer, or 0 if it does not apply
+// patch geometry of the halo form for a map: 8 x 16 patches where the map tiles into them, whole-row bands of 112 pixels on the
+// 56- and 28-wide maps; 0 = none
+inline int halo_patch_w(const asm_conv_desc* d) {
+  if (d->H % 8 == 0 && d->W % 16 == 0) return 16;
+  if (d->W == 56 && d->H % 2 == 0) return 56;
+  if (d->W == 28 && d->H % 4 == 0) return 28;
+  return 0;
+}
+
+// patch runs (= slabs) of the persistent halo form for this layer, or 0 if it does not apply; the launch has K / KF workgroups
+// per run (KF = 64 for K = 128)
 int wgrad_halo_blocks(const asm_conv_desc* d) {
   const int mode = asm_tune().wgrad_halo;     // 0 off, 1 on for the large maps, 2 whenever the shape allows (tests)
   if (!mode) return 0;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
-  if (d->H % 8 || d->W % 16 || d->x_img_pitch || d->x_row_pitch || d->x_pix_pitch) return 0;
-  if (!((d->C == 32 || d->C == 64) && (d->K == 32 || d->K == 64))) return 0;
-  const int n_m = d->N * (d->H / 8) * (d->W / 16);
+  if (d->x_img_pitch || d->x_row_pitch || d->x_pix_pitch) return 0;
+  const int pw = halo_patch_w(d);
+  if (!pw) return 0;
+  if (!((d->C == 32 || d->C == 64) && (d->K == 32 || d->K == 64 || d->K == 128))) return 0;
+  const int ppx = pw == 16 ? 128 : 112;
+  const int n_m = d->N * d->H * d->W / ppx;
   if (mode != 2 && n_m < 512) return 0;   // a slab per workgroup only pays on the large maps
-  return n_m < 512 ? n_m : 512;           // 2 workgroups per CU
+  const int kh = d->K == 128 ? 2 : 1;
+  const int wgs = (d->C == 64 && d->K >= 64) ? 256 : 512;    // the eight-wave form runs one workgroup per CU, the others two
+  return n_m < wgs / kh ? n_m : wgs / kh;
 }
 
 struct Plan {
@@ -842,21 +904,35 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
               workspace_bytes, need);
   if (const int hb = wgrad_halo_blocks(d)) {
     WgradArgs h;
+    const int kf = d->K == 128 ? 64 : d->K, kh = d->K / kf, pw = halo_patch_w(d);
     h.dy = dy; h.x = x; h.out = reinterpret_cast<float*>(workspace);
     h.dy_bytes = (unsigned)(dyelems * 2); h.x_bytes = (unsigned)(xelems * 2);
     h.M = d->N * d->H * d->W; h.Hi = d->H; h.Wi = d->W; h.Ci = d->C; h.Co = d->K; h.ldy = ldy;
     h.R = 3; h.S = 3; h.so = 1; h.pad = 1;
     h.x_img_pitch = d->H * d->W * d->C; h.x_row_pitch = d->W * d->C; h.x_pix_pitch = d->C;
-    h.cols = 9 * d->C; h.tiles_n = h.tiles_c = 1; h.splits = hb; h.m_per_split = 0;
+    h.cols = 9 * d->C; h.tiles_n = kh; h.tiles_c = 1; h.splits = hb; h.m_per_split = 0;
     h.HoWo = d->H * d->W; h.Wo = d->W;
     h.fd_howo = make_fastdiv((unsigned)h.HoWo); h.fd_wo = make_fastdiv((unsigned)h.Wo);
     hipStream_t hs = (hipStream_t)stream;
-#define LAUNCH_WH(KF, CI)                                                                                        \
-    ASM_LAUNCH((wgrad_halo_kernel<KF, CI>), dim3(hb), dim3(256), (WHalo<KF, CI>::LDS), hs, h)
-    if (d->K == 32 && d->C == 64) LAUNCH_WH(32, 64);
-    else if (d->K == 64 && d->C == 32) LAUNCH_WH(64, 32);
-    else if (d->K == 32 && d->C == 32) LAUNCH_WH(32, 32);
-    else LAUNCH_WH(64, 64);
+#define LAUNCH_WH(KF, CI, PH, PW)                                                                                      \
+    do {                                                                                                               \
+      constexpr int LDS_ = WHalo<KF, CI, PH, PW>::LDS;                                                                 \
+      static bool done_[ASM_MAX_DEVICES] = {};                                                                         \
+      if (hipError_t e = asm_ensure_dyn_lds(wgrad_halo_kernel<KF, CI, PH, PW>, LDS_, done_); e != hipSuccess)          \
+        ASM_FAIL(ASM_EHIP, "wgrad_halo_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));                         \
+      ASM_LAUNCH((wgrad_halo_kernel<KF, CI, PH, PW>), dim3(hb * kh), dim3(WHalo<KF, CI, PH, PW>::NTHR), LDS_, hs, h);                          \
+    } while (0)
+#define LAUNCH_WH_GEO(KF, CI)                                  \
+    do {                                                       \
+      if (pw == 16) LAUNCH_WH(KF, CI, 8, 16);                  \
+      else if (pw == 56) LAUNCH_WH(KF, CI, 2, 56);             \
+      else LAUNCH_WH(KF, CI, 4, 28);                           \
+    } while (0)
+    if (kf == 32 && d->C == 64) LAUNCH_WH_GEO(32, 64);
+    else if (kf == 64 && d->C == 32) LAUNCH_WH_GEO(64, 32);
+    else if (kf == 32 && d->C == 32) LAUNCH_WH_GEO(32, 32);
+    else LAUNCH_WH_GEO(64, 64);
+#undef LAUNCH_WH_GEO
 #undef LAUNCH_WH
     ASM_CHECK_LAUNCH("wgrad_halo_kernel");
     const size_t n = (size_t)d->K * 9 * d->C;

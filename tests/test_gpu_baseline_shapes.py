@@ -279,7 +279,11 @@ def test_igemm_variants_are_per_call_knobs(hip_lib, v2, parity, monkeypatch):
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 32, 64, 32), (3, 8, 16, 32, 64), (1, 24, 48, 32, 32), (2, 16, 16, 64, 64),
-                                   (8, 112, 112, 64, 32)], ids=lambda s: 'x'.join(map(str, s)))
+                                   (8, 112, 112, 64, 32),
+                                   # whole-row bands of 112 pixels (2 x 56, 4 x 28); K = 128 as two 64-channel halves
+                                   (3, 56, 56, 64, 128), (5, 28, 28, 64, 128), (2, 56, 56, 32, 64), (3, 28, 28, 64, 64),
+                                   (2, 28, 28, 32, 32), (1, 4, 28, 64, 128), (1, 2, 56, 32, 128)],
+                         ids=lambda s: 'x'.join(map(str, s)))
 def test_wgrad_halo_kernel_forced_vs_oracle(hip_lib, shape, monkeypatch):
   """wgrad_halo_kernel (persistent, halo-resident, all nine taps per patch) on small shapes and on an 8-image slice of
   its own layer: against the oracle's autograd and bit-reproducible."""
