@@ -1015,15 +1015,13 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
     // (its 8-wave loop reads 0.75 instead of 1 LDS fragment per MFMA and has half the barriers), so those stay.
     // asm_tuning.igemm3 = 2 forces it wherever the shape allows (tests).
     const int h3 = asm_tune().igemm3;
-    // h3 == 4 (round 5, in-situ sweep tools/insitu_sweep.py --settings): also the deep layers of the 14 x 14 / 7 x 7 maps that the
-    // 256 x 256 tile carries -- stand-alone that tile wins them by 3 - 15 %, beside the weight-gradient streams two 80 KB
-    // workgroups per CU finish sooner than one 128 KB one (heaviest input gradient 618 -> 472 us in situ)
-    const bool deep_small = h3 == 4 && bigv && a.Wi <= 14 && a.Ci >= 256;
+    // (asm_tuning.igemm3 = 4 -- also the deep 14- / 7-wide layers of the 256 x 256 tile on igemm3 -- measured 0.2 ms slower in the
+    // step in rounds 5 and 6 and was removed.)
     // igemm8_kernel: the layers of the 256 x 256 tile on the wave-staggered multi-phase loop (bit-identical results)
     const int h8 = asm_tune().igemm8;
     // (the short-reduction layers on >= 768 tiles stay on igemm3, below: 28x28x128 -> 256 forward 127 us there, 131 us here)
     const bool to_igemm3 = h3 && b256v >= 768 && a.Ci <= 128;
-    if (ftile == 0 && !deep_small && ((h8 == 1 && bigv && !to_igemm3) || h8 == 2)) {
+    if (ftile == 0 && ((h8 == 1 && bigv && !to_igemm3) || h8 == 2)) {
       // The ragged last round.  One 128 KB workgroup per CU: n tiles take ceil(n / CUs) rounds, and 784 tiles on 256 CUs
       // (14x14x512 -> 1024 and 28x28x128 -> 256 at batch 256) spend a whole round on their last 16.  When the tail is short,
       // the row tiles of the full rounds go to igemm8 and the remaining rows to the 128 x 128 kernels (igemm3 / igemm2: four
@@ -1056,7 +1054,7 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
         if (rc != 1) return rc;
       }
     }
-    if (ftile == 0 && h3 && (h3 == 2 || !bigv || (b256v >= 768 && a.Ci <= 128) || deep_small)) {
+    if (ftile == 0 && h3 && (h3 == 2 || !bigv || (b256v >= 768 && a.Ci <= 128))) {
       rc = try_igemm3(a, out_f32, stats, st);
       if (rc != 1) return rc;
     }

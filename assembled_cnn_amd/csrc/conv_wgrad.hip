@@ -67,9 +67,8 @@ __device__ __forceinline__ int tr_swz(int row) {
 // LIN: 1x1, stride 1, no padding over a densely packed x: output pixel m IS input pixel m and column j IS channel j, so
 // the staging loads need no (image, row, column) decode at all (two multiply-shift divisions, ~25 VALU per row and step in
 // the general form; most weight-gradient launches of a bottleneck network are such 1x1 layers).
-// NS >= 2 (LIN, 128-column tiles): the two tiles of a step arrive by LDS-DMA into a ring of NS stages, requested NS - 1 steps
-// ahead with counted vmcnt (the loads of the following steps stay in flight across the barrier; csrc/conv_gemm1.hip has the
-// forward / input-gradient twin): no staging registers, no ds_write, and a prefetch distance that does not cost VGPRs.  The
+// NS = 2 (LIN, 128-column tiles): the two tiles of a step arrive by LDS-DMA into the other of two stages, requested one step
+// ahead (csrc/conv_gemm1.hip has the forward / input-gradient twin): no staging registers, no ds_write.  The
 // XOR swizzle of the transposing reads is applied on the SOURCE side (a lane's LDS destination is base + 16 * lane).  Same
 // steps in the same order as the register-staged loop: bit-identical sums.
 template <int BNW, int BCW, bool LIN = false, int NS = 0>
@@ -235,17 +234,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   };
 
   if constexpr (NS >= 2) {
-    static_assert(LIN, "the ring form covers the linear-address layers");
+    static_assert(LIN && NS == 2, "the ring form covers the linear-address layers, two stages");
     // NOTE (round 6): behind a compiler-visible LDS read (the ds_read_tr builtin) hipcc waits for EVERY outstanding LDS-DMA --
     // s_waitcnt vmcnt(0) before the first fragment read of a step, i.e. also for the tiles requested a moment earlier -- so
-    // inside one workgroup this ring overlaps nothing and depths 3 / 4 are the same loop with less occupancy; the overlap comes
-    // from the second workgroup on the CU.  Hiding the reads in inline asm with hand-counted lgkmcnt (what wgrad8_kernel does)
+    // inside one workgroup this ring overlaps nothing (and the depths 3 / 4 that existed until round 6 were the same loop with
+    // less occupancy: removed); the overlap comes from the second workgroup on the CU.  Hiding the reads in inline asm with hand-counted lgkmcnt (what wgrad8_kernel does)
     // was measured here too (tools/gemm1_sweep.py --wgrad, same box, every 1x1 layer at batch 256): 2751 against 2780 us per
     // step summed over the layers, single layers +-10 % either way -- within the noise, so the simpler form stays.
     typedef __attribute__((address_space(3))) void* lptr_t;
     constexpr int YPW = YROWB == 256 ? 4 : (YROWB == 128 ? 2 : 1);   // dy pieces (1 KiB) per wave and step
-    constexpr int P = 4 + YPW;
-    static_assert(P * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
     constexpr int YRPP = 1024 / YROWB;                                // dy rows per piece: 4 / 8 / 16
     auto issue = [&](int stage, int step) {
       unsigned char* ys = smem + stage * STAGE;
@@ -272,24 +269,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
                                                  (int)((m < m_end && n < p.Co) ? off : ASM_OOB), 0, 0, 0);
       }
     };
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-      if (s < steps) issue(s, s);
+    if (steps > 0) issue(0, 0);
     int cur = 0;
 #pragma unroll 1
     for (int step = 0; step < steps; ++step) {
-      const int rem = steps - 1 - step;     // steps requested after this one may stay in flight (at most NS - 2 of them)
-      if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS >= 4 ? 2 * P : 0) : "memory");
-      else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS >= 3 ? P : 0) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this step's tiles visible; step - 1's stage released
-      if (step + NS - 1 < steps) {
-        int nst = cur + NS - 1;
-        if (nst >= NS) nst -= NS;
-        issue(nst, step + NS - 1);
-      }
+      if (step + 1 < steps) issue(cur ^ 1, step + 1);
       compute(cur);
-      cur = cur + 1 == NS ? 0 : cur + 1;
+      cur ^= 1;
     }
   } else {
   // steps beyond the range load nothing (m >= m_end -> zeros), so the pair loop needs no tail branch
@@ -850,15 +838,16 @@ Plan make_plan(const asm_conv_desc* d) {
 }
 
 // ring depth of the LDS-DMA form for a linear-address 1x1 layer with 128-column tiles (asm_tuning.wgrad_ring: 0 never,
-// n >= 2 forced, -1 per layer from the same-box sweep, tools/gemm1_sweep.py --wgrad), or 0 for the register-staged loop
+// n >= 1 the two-stage ring forced, -1 per layer from the same-box sweep, tools/gemm1_sweep.py --wgrad), or 0 for the register-staged loop
 int wgrad_ring_depth(const asm_conv_desc* d, const Plan& pl) {
   const int mode = asm_tune().wgrad_ring;
   if (mode == 0 || WPX != 64) return 0;
-  if (mode > 0) return mode < 2 ? 2 : (mode > 4 ? 4 : mode);
+  if (mode > 0) return 2;
   // Round-5 sweep (tools/gemm1_sweep.py --wgrad, every 1x1 shape of Assemble-ResNet-50 at batch 256, bit-identical sums): two
   // stages (64 KB, two workgroups per CU like the register-staged loop) win 3 - 10 % on the 28 x 28 and smaller maps and on
   // the 56 x 56 layers with >= 128 input channels, and lose 20 - 30 % on the narrow 56 x 56 ones (x rows of 64 / 128 bytes:
-  // a quarter / half of every 256-byte DMA row is padding); three and four stages (one workgroup per CU) lose everywhere.
+  // a quarter / half of every 256-byte DMA row is padding).  Deeper rings (three / four stages, one workgroup per CU) lost
+  // everywhere and were removed in round 6 (see the note in wgrad_kernel: hipcc drains the ring before every fragment read).
   (void)pl;
   if ((long long)d->N * d->H * d->W >= 500000 && d->C <= 64) return 0;
   return 2;
@@ -978,9 +967,7 @@ extern "C" int asm_conv2d_wgrad(const asm_conv_desc* d, const void* x, const voi
       else if (pl.bnw == 64) LAUNCH_RING(64, NS_);               \
       else LAUNCH_RING(32, NS_);                                 \
     } while (0)
-    if (ring == 2) LAUNCH_RING_NS(2);
-    else if (ring == 3) LAUNCH_RING_NS(3);
-    else LAUNCH_RING_NS(4);
+    LAUNCH_RING_NS(2);
 #undef LAUNCH_RING_NS
 #undef LAUNCH_RING
   } else if (lin && pl.bcw != 256) {

@@ -325,7 +325,7 @@ extern "C" void asm_tuning_defaults(asm_tuning* t) {
 extern "C" int asm_set_tuning(const asm_tuning* t) {
   if (t && (t->bn_rows <= 0 || t->igemm_mode < 0 || t->igemm_mode > 1 || (t->igemm_tile != 0 && t->igemm_tile != 1 && t->igemm_tile != 3) ||
             t->igemm_pfa < -1 || t->igemm_pfa > 1 || t->dgrad_parity < 0 || t->dgrad_parity > 2 || t->wgrad_halo < 0 || t->wgrad_halo > 2 ||
-            t->wgrad_big < -1 || t->wgrad_big > 1 || t->wgrad_splits < 0 || t->igemm3 < 0 || t->igemm3 > 4 || t->gemm1 < -2 ||
+            t->wgrad_big < -1 || t->wgrad_big > 1 || t->wgrad_splits < 0 || t->igemm3 < 0 || t->igemm3 > 3 || t->gemm1 < -2 ||
             t->wgrad_ring < -1 || t->igemm8 < 0 || t->igemm8 > 2))
     ASM_FAIL(ASM_EINVAL, "asm_set_tuning: field out of range");
   g_tuning = t ? *t : make_default_tuning();

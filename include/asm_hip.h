@@ -101,14 +101,12 @@ typedef struct asm_tuning {
   int32_t igemm3;          /* 3x3 stride-1 layers with >= 128 input channels on maps up to 30 wide with the activation rows
                               resident across the nine taps (igemm3_kernel): 1: where it measured faster than igemm2's
                               tile for the layer; 2: wherever the shape allows; 0: never; 3: as 1, plus the layers with ONE
-                              64-channel chunk (Ci = 64, maps up to 62 wide) with a single row buffer (default); 4: as 3,
-                              plus the deep layers of the 14- / 7-wide maps that the 256 x 256 tile carries (faster in
-                              situ per layer, no faster as a step: opt-in)                                          */
+                              64-channel chunk (Ci = 64, maps up to 62 wide) with a single row buffer (default)        */
   int32_t gemm1;           /* 1x1 convolutions (forward / input gradient) as a GEMM with a ring of LDS stages, the loads of a
                               K step requested several steps ahead (igemm1_kernel): -1 per layer (default), 0 never
                               (igemm2_kernel), n > 0 force tile / depth n of the table in csrc/conv_gemm1.hip            */
-  int32_t wgrad_ring;      /* 1x1 stride-1 weight gradients with a ring of LDS-DMA stages (wgrad1_kernel): -1 per layer
-                              (default), 0 never, n > 0 force ring depth n                                               */
+  int32_t wgrad_ring;      /* 1x1 stride-1 weight gradients with their tiles by LDS-DMA into two LDS stages (wgrad_kernel<.., 2>):
+                              -1 per layer (default), 0 never, n > 0 always                                              */
   int32_t igemm8;          /* 3x3 stride-1 layers (forward / input gradient) with >= 256 output channels on the wave-staggered
                               multi-phase 256 x 256 kernel (igemm8_kernel, csrc/conv_igemm8.hip; bit-identical to igemm2's
                               256 x 256 tile): 1 where the layer took the 256 x 256 tile, the ragged last round on the

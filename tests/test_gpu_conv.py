@@ -561,9 +561,9 @@ def test_ring_gemm_of_the_1x1_layers_is_igemm2_bit_for_bit(hip_lib, shape, monke
 @pytest.mark.parametrize('shape', [(2, 14, 14, 256, 512), (3, 7, 7, 520, 264), (1, 28, 28, 64, 48), (2, 9, 11, 40, 24)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_ring_weight_gradient_is_the_register_staged_one_bit_for_bit(hip_lib, shape, monkeypatch):
-  """wgrad_kernel<.., LIN, NS>: the two tiles of a 64-pixel step by LDS-DMA into a ring of NS stages (source-side swizzle
+  """wgrad_kernel<.., LIN, 2>: the two tiles of a 64-pixel step by LDS-DMA into the other of two stages (source-side swizzle
   of the transposing reads) instead of through registers -- the same steps in the same order under the same pixel split,
-  so dW must be IDENTICAL for every depth, pixel tails and channel tails included; and within fp32 noise of a float64
+  so dW must be IDENTICAL, pixel tails and channel tails included; and within fp32 noise of a float64
   product."""
   from assembled_cnn_amd import ops
   N, H, W, Cn, K = shape
@@ -573,13 +573,12 @@ def test_ring_weight_gradient_is_the_register_staged_one_bit_for_bit(hip_lib, sh
   outs = {}
   for splits in ('0', '3'):
     util.set_knob(monkeypatch, 'ASM_WGRAD_SPLITS', splits)
-    for ring in ('0', '2', '3', '4'):
+    for ring in ('0', '2'):
       util.set_knob(monkeypatch, 'ASM_WGRAD_RING', ring)
       dw = torch.full((K, 1, 1, Cn), float('nan'), dtype=torch.float32, device='cuda')
       ops.conv_wgrad(d, x, dy, dw)
       outs[(splits, ring)] = dw
-    for ring in ('2', '3', '4'):
-      assert torch.equal(outs[(splits, ring)], outs[(splits, '0')]), (splits, ring)
+    assert torch.equal(outs[(splits, '2')], outs[(splits, '0')]), splits
   want = dy.double().reshape(-1, K).t() @ x.double().reshape(-1, Cn)
   got = outs[('0', '2')].double().reshape(K, Cn)
   assert float((got - want).norm() / want.norm()) <= 1e-5
