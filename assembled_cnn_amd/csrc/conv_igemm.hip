@@ -26,6 +26,7 @@ using namespace asm_igemm;
 int asm_gemm1_try(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st);
 // conv_igemm8.hip: the wide 3x3 stride-1 layers on the wave-staggered multi-phase main loop (returns 1 when it does not take the layer)
 int asm_igemm8_try(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st);
+bool asm_igemm8_covers(const IGemmArgs& a, bool out_f32);
 
 namespace {
 
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm2_kernel(IGemmArgs p) {
 // convolutions of the 56 x 56 and 28 x 28 stages) has no next chunk to stage under the current one, so one buffer does, and
 // with it 256 rows (W <= 62) fit 64 KB together with the two filter stages: two workgroups per CU like igemm2's tile, 178 +
 // 9 x 128 instead of 9 x 256 staged rows per workgroup.
-template <int BN, bool STATS, bool PFA, int H3_ROWS = 192, int NHB = 2>
+template <int BN, bool STATS, bool PFA, int H3_ROWS = 192, int NHB = 2, bool BNRED = false>
 __global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
   constexpr int BM = 128, BK = 64, WGM = 2, WGN = 2;
   using C = Cfg<BM, BN, BK, WGM, WGN, false, STATS, 2>;
@@ -623,15 +624,15 @@ __global__ __launch_bounds__(256) void igemm3_kernel(IGemmArgs p) {
     mma((KK - 1) & 1);
   }
   __syncthreads();   // every wave's fragment reads are done: the epilogue reuses the region
-  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, false, STATS, PFA, false>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+  igemm_epilogue<C, BM, BN, WTM, WTN, TM, TN, false, STATS, PFA, false, false, BNRED, 8>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
-template <int BN, bool STATS, bool PFA, int HR = 192, int NHB = 2>
+template <int BN, bool STATS, bool PFA, int HR = 192, int NHB = 2, bool BNRED = false>
 int launch3_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg<128, BN, 64, 2, 2, false, STATS, 2>;
   constexpr int LDS = cmax(cmax(NHB * HR * 128 + 2 * BN * 128, C::EPI), C::RED);
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
-  auto kern = igemm3_kernel<BN, STATS, PFA, HR, NHB>;
+  auto kern = igemm3_kernel<BN, STATS, PFA, HR, NHB, BNRED>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm3_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
@@ -641,32 +642,43 @@ int launch3_one(const IGemmArgs& a, hipStream_t st) {
   return ASM_OK;
 }
 
+// is the layer one igemm3_kernel covers?
+bool igemm3_covers(const IGemmArgs& a, bool out_f32) {
+  if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.pool_dy) return false;
+  if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return false;
+  if (a.wt0 != 0 || a.wtr != 3 || a.wts != 1) return false;
+  const bool one_chunk = a.Ci == 64;      // asm_tuning.igemm3 >= 2: also the single-chunk layers (one halo buffer)
+  if (one_chunk && asm_tune().igemm3 == 1) return false;
+  if (a.Ci % 64 || a.Co <= 64 || a.Wi > ((one_chunk ? 256 : 192) - 1 - 128 - 2) / 2) return false;
+  if (a.HoWo != a.Hi * a.Wi || a.Wo != a.Wi || a.M % a.HoWo) return false;
+  if (a.x_pix_pitch != a.Ci || a.x_row_pitch != a.Wi * a.Ci || a.x_img_pitch != a.Hi * a.Wi * a.Ci) return false;
+  return true;
+}
+
 // returns 1 when the layer is not one igemm3_kernel covers
 int try_igemm3(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
-  if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.pool_dy) return 1;
-  if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return 1;
-  if (a.wt0 != 0 || a.wtr != 3 || a.wts != 1) return 1;
-  const bool one_chunk = a.Ci == 64;      // asm_tuning.igemm3 >= 2: also the single-chunk layers (one halo buffer)
-  if (one_chunk && asm_tune().igemm3 == 1) return 1;
-  if (a.Ci % 64 || a.Co <= 64 || a.Wi > ((one_chunk ? 256 : 192) - 1 - 128 - 2) / 2) return 1;
-  if (a.HoWo != a.Hi * a.Wi || a.Wo != a.Wi || a.M % a.HoWo) return 1;
-  if (a.x_pix_pitch != a.Ci || a.x_row_pitch != a.Wi * a.Ci || a.x_img_pitch != a.Hi * a.Wi * a.Ci) return 1;
+  if (!igemm3_covers(a, out_f32)) return 1;
+  const bool one_chunk = a.Ci == 64;
   a.n_tiles_n = cdiv(a.Co, 128);
   a.n_blocks = (cdiv(a.M, 128) - a.m_tile0) * a.n_tiles_n;
   a.kchunks = a.Ci / 64;
   a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
   const int pfa_env = asm_tune().igemm_pfa;
   const bool pfa = a.addend != nullptr && (pfa_env >= 0 ? pfa_env != 0 : a.n_blocks <= 1024);
+  const bool bnred = stats && a.red_y;      // an input gradient that also reduces the batch-norm backward sums of its output
   if (one_chunk) {
     if (a.Wi <= 30) {
+      if (bnred) return launch3_one<128, true, false, 192, 1, true>(a, st);
       if (stats) return launch3_one<128, true, false, 192, 1>(a, st);
       if (pfa) return launch3_one<128, false, true, 192, 1>(a, st);
       return launch3_one<128, false, false, 192, 1>(a, st);
     }
+    if (bnred) return launch3_one<128, true, false, 256, 1, true>(a, st);
     if (stats) return launch3_one<128, true, false, 256, 1>(a, st);
     if (pfa) return launch3_one<128, false, true, 256, 1>(a, st);
     return launch3_one<128, false, false, 256, 1>(a, st);
   }
+  if (bnred) return launch3_one<128, true, false, 192, 2, true>(a, st);
   if (stats) return launch3_one<128, true, false>(a, st);
   if (pfa) return launch3_one<128, false, true>(a, st);
   return launch3_one<128, false, false>(a, st);
@@ -863,13 +875,19 @@ int launch_halo(IGemmArgs& a, bool stats, hipStream_t st) {
   return ASM_OK;
 }
 
+// is the layer one the halo kernel covers?
+bool halo_covers(const IGemmArgs& a, bool out_f32) {
+  if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.bn_scale) return false;
+  if (a.Hi % 8 || a.Wi % 16 || a.M != (a.HoWo / a.Wo) * a.Wo * (a.M / a.HoWo) || a.HoWo != a.Hi * a.Wi) return false;
+  if (a.x_pix_pitch != a.Ci || a.x_row_pitch != a.Wi * a.Ci || a.x_img_pitch != a.Hi * a.Wi * a.Ci) return false;
+  if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return false;
+  if (a.wt0 != 0 || a.wtr != 3 || a.wts != 1) return false;
+  return (a.Ci == 32 || a.Ci == 64) && (a.Co == 32 || a.Co == 64);
+}
+
 // returns 1 when the layer is not one the halo kernel covers
 int try_halo(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
-  if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.bn_scale) return 1;
-  if (a.Hi % 8 || a.Wi % 16 || a.M != (a.HoWo / a.Wo) * a.Wo * (a.M / a.HoWo) || a.HoWo != a.Hi * a.Wi) return 1;
-  if (a.x_pix_pitch != a.Ci || a.x_row_pitch != a.Wi * a.Ci || a.x_img_pitch != a.Hi * a.Wi * a.Ci) return 1;
-  if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return 1;
-  if (a.wt0 != 0 || a.wtr != 3 || a.wts != 1) return 1;
+  if (!halo_covers(a, out_f32)) return 1;
   if (a.Ci == 64 && a.Co == 32) return launch_halo<32, 64, 4, 1>(a, stats, st);
   if (a.Ci == 32 && a.Co == 32) return launch_halo<32, 32, 4, 1>(a, stats, st);
   if (a.Ci == 32 && a.Co == 64) return launch_halo<64, 32, 2, 2>(a, stats, st);
@@ -973,6 +991,34 @@ int launch_cfg(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
   return launch_mode<BM, BN, BK, WGM, WGN, 2>(a, out_f32, stats, st);
 }
 
+// which of the specialised 3x3 kernels launch() would try for a layer (the knobs included)
+struct Sel3 {
+  bool bigv, to_igemm3, try8, try3;
+};
+Sel3 select_3x3(const IGemmArgs& a) {
+  const int ftile = asm_tune().igemm_tile, h3 = asm_tune().igemm3, h8 = asm_tune().igemm8;
+  const bool heavy = a.Ci % 64 == 0 && (long long)a.R * a.S * a.Ci >= 512;
+  const long long b256v = (long long)cdiv(a.M, 256) * cdiv(a.Co, 256);
+  Sel3 r;
+  r.bigv = heavy && a.Co >= 256 && b256v >= 192;
+  if (ftile == 1) r.bigv = false;
+  if (ftile == 3 && a.Ci % 64 == 0) r.bigv = true;
+  // (the short-reduction layers on >= 768 tiles stay on igemm3: 28x28x128 -> 256 forward 127 us there, 131 us on igemm8)
+  r.to_igemm3 = h3 && b256v >= 768 && a.Ci <= 128;
+  r.try8 = ftile == 0 && ((h8 == 1 && r.bigv && !r.to_igemm3) || h8 == 2);
+  r.try3 = ftile == 0 && h3 && (h3 == 2 || !r.bigv || r.to_igemm3);
+  return r;
+}
+
+// An input gradient that also reduces the batch-norm backward sums of its output (IGemmArgs::red_y) needs the BNRED instantiation
+// of whatever kernel runs it: for the 3x3 layers those exist for igemm8 and igemm3.  Would launch() end up on one of them?
+bool bnred_3x3_supported(const IGemmArgs& a) {
+  if (asm_tune().igemm_mode != 0 || asm_tune().igemm_tile != 0) return false;
+  if (halo_covers(a, false)) return false;       // launch() would send it to conv_halo_kernel: no such instantiation there
+  const Sel3 s3 = select_3x3(a);
+  return (s3.try8 && asm_igemm8_covers(a, false)) || (s3.try3 && igemm3_covers(a, false));
+}
+
 int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_only = false) {
   // Measured on MI355X (tools/conv_bench.py, Assemble-ResNet-50 shapes, batch 256):
   //  * HBM-bound layers (1x1, and everything at 112x112): LDS-DMA staging + the smallest footprint wins
@@ -993,7 +1039,10 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
   const bool v2 = true;     // (asm_tuning.igemm_mode != 0 is what sends a layer to the general kernel)
   if (a.pool_dy && !(v2 && fmode == 0 && !out_f32 && !stats && a.R == 1 && a.S == 1 && !a.y_strided))
     ASM_FAIL(ASM_ENOTSUP, "conv dgrad_pooled: only the 1x1 stride-1 igemm2 path folds an average-pool backward in");
-  if (v2 && fmode == 0 && ftile == 0) {
+  // only igemm8 and igemm3 have that instantiation for a 3x3 (in the bandwidth-bound halo kernel of the 112-wide maps the y reads
+  // cost 0.22 ms per step and saved 0.09 of reduce passes: measured, removed)
+  const bool bnred3 = stats && a.red_y && a.R * a.S > 1;
+  if (v2 && fmode == 0 && ftile == 0 && !bnred3) {
     const int rc = try_halo(a, out_f32, stats, st);
     if (rc != 1) return rc;
   }
@@ -1003,10 +1052,8 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
   }
   if (v2 && fmode == 0) {
     int rc;
-    const long long b256v = (long long)cdiv(a.M, 256) * cdiv(a.Co, 256);
-    bool bigv = heavy && a.Co >= 256 && b256v >= 192;
-    if (ftile == 1) bigv = false;
-    if (ftile == 3 && a.Ci % 64 == 0) bigv = true;
+    const Sel3 s3 = select_3x3(a);
+    const bool bigv = s3.bigv;
     // igemm3_kernel (128 x 128 tiles, activation rows resident across the taps, two workgroups per CU) against igemm2
     // (tools/conv_bench.py --iters 50, same box, steady state): it wins wherever igemm2 would run 128-row tiles
     // (28x28x128 -> 256 input gradient 124 -> 112 us, 7x7x256 -> 512 37 -> 35 / 48.6 -> 40, 7x7x512 -> 1024 input gradient
@@ -1014,14 +1061,11 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
     // (28x28x128 -> 256: 131 -> 117.5); against the 256 x 256 tile it loses 3 - 15 % where that tile fills the chip
     // (its 8-wave loop reads 0.75 instead of 1 LDS fragment per MFMA and has half the barriers), so those stay.
     // asm_tuning.igemm3 = 2 forces it wherever the shape allows (tests).
-    const int h3 = asm_tune().igemm3;
     // (asm_tuning.igemm3 = 4 -- also the deep 14- / 7-wide layers of the 256 x 256 tile on igemm3 -- measured 0.2 ms slower in the
     // step in rounds 5 and 6 and was removed.)
     // igemm8_kernel: the layers of the 256 x 256 tile on the wave-staggered multi-phase loop (bit-identical results)
     const int h8 = asm_tune().igemm8;
-    // (the short-reduction layers on >= 768 tiles stay on igemm3, below: 28x28x128 -> 256 forward 127 us there, 131 us here)
-    const bool to_igemm3 = h3 && b256v >= 768 && a.Ci <= 128;
-    if (ftile == 0 && ((h8 == 1 && bigv && !to_igemm3) || h8 == 2)) {
+    if (s3.try8) {
       // The ragged last round.  One 128 KB workgroup per CU: n tiles take ceil(n / CUs) rounds, and 784 tiles on 256 CUs
       // (14x14x512 -> 1024 and 28x28x128 -> 256 at batch 256) spend a whole round on their last 16.  When the tail is short,
       // the row tiles of the full rounds go to igemm8 and the remaining rows to the 128 x 128 kernels (igemm3 / igemm2: four
@@ -1036,7 +1080,7 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
       const long long rem = n8 - (long long)m_full * nt8;              // 256 x 256 tiles left over
       const double small = 4 * rem <= cus ? 0.3 : 0.5 * (double)((4 * rem + 2 * cus - 1) / (2 * cus));
       const double split_cost = (double)((long long)m_full * nt8 / cus) + small, whole_cost = (double)((n8 + cus - 1) / cus);
-      if (h8 == 1 && m_full > 0 && rem > 0 && split_cost < whole_cost - 0.15) {
+      if (h8 == 1 && m_full > 0 && rem > 0 && split_cost < whole_cost - 0.15 && (!bnred3 || igemm3_covers(a, out_f32))) {
         IGemmArgs head = a;
         head.M = m_full * 256;            // rows of the full rounds (the gather itself is bounded by the tensor, not by M)
         rc = asm_igemm8_try(head, out_f32, stats, st);
@@ -1054,10 +1098,11 @@ int launch(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st, bool igemm2_o
         if (rc != 1) return rc;
       }
     }
-    if (ftile == 0 && h3 && (h3 == 2 || !bigv || (b256v >= 768 && a.Ci <= 128))) {
+    if (s3.try3) {
       rc = try_igemm3(a, out_f32, stats, st);
       if (rc != 1) return rc;
     }
+    if (bnred3) ASM_FAIL(ASM_ENOTSUP, "conv dgrad_bnred: no kernel with the batch-norm sums for this 3x3 layer");
     if (a.Co <= 32) rc = bk64 ? launch2_cfg<128, 32, 64, 4, 1>(a, out_f32, stats, st) : launch2_cfg<128, 32, 32, 4, 1>(a, out_f32, stats, st);
     else if (a.Co <= 64) rc = bk64 ? launch2_cfg<128, 64, 64, 2, 2>(a, out_f32, stats, st) : launch2_cfg<128, 64, 32, 2, 2>(a, out_f32, stats, st);
     else if (bigv) rc = launch2_cfg<256, 256, 64, 4, 2>(a, out_f32, stats, st);
@@ -1192,8 +1237,30 @@ extern "C" int asm_conv2d_dgrad_pooled(const asm_conv_desc* d, const void* dy, c
   return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream, &pa);
 }
 
+// does asm_conv2d_dgrad_bnred cover this layer?  1x1 / stride 1 / no padding (every kernel of that class has the instantiation),
+// and the 3x3 / stride 1 / pad 1 layers that launch() sends to igemm8_kernel or igemm3_kernel
+static bool dgrad_bnred_covers(const asm_conv_desc* d) {
+  if (!d || d->C % 8 || d->K % 8 || d->stride != 1 || d->x_img_pitch || d->x_row_pitch || d->x_pix_pitch || d->out_f32) return false;
+  if (d->R == 1 && d->S == 1 && d->pad == 0) return true;
+  if (d->R != 3 || d->S != 3 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return false;
+  IGemmArgs a;            // the geometry of dgrad_impl's generic form, as far as the selection reads it
+  a.M = d->N * d->H * d->W;
+  a.Hi = d->Ho; a.Wi = d->Wo; a.Ci = d->K;
+  a.Wo = d->W; a.HoWo = d->H * d->W;
+  a.Co = d->C; a.ldy = d->C;
+  a.R = 3; a.S = 3;
+  a.x_bytes = (unsigned)((int64_t)d->N * d->Ho * d->Wo * d->K * 2);
+  a.x_img_pitch = d->Ho * d->Wo * d->K; a.x_row_pitch = d->Wo * d->K; a.x_pix_pitch = d->K;
+  a.wt0 = 0; a.wtr = 3; a.wts = 1; a.y_strided = 0; a.m_tile0 = 0;
+  a.pool_dy = nullptr; a.bn_scale = nullptr;
+  a.so = 1; a.sd = 1; a.tsign = -1; a.pad = -1; a.pad_w = -1;
+  return bnred_3x3_supported(a);
+}
+
+// partial rows of asm_conv2d_dgrad_bnred for this layer; 0: the layer is not one it covers
 extern "C" int asm_conv2d_dgrad_bnred_blocks(const asm_conv_desc* d) {
   if (!d) return ASM_EINVAL;
+  if (!dgrad_bnred_covers(d)) return 0;
   return cdiv(d->N * d->H * d->W, STATS_BM);
 }
 
@@ -1202,9 +1269,9 @@ extern "C" int asm_conv2d_dgrad_bnred(const asm_conv_desc* d, const void* dy, co
                                       float* partial, void* dx, void* stream) {
   ASM_REQUIRE(d && bn_y && partial, "conv dgrad_bnred: null pointer");
   ASM_REQUIRE(!addend_mask || addend, "conv dgrad_bnred: a mask needs its addend");
-  if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->C % 8)
-    ASM_FAIL(ASM_ENOTSUP, "conv dgrad_bnred: 1x1 stride-1 convolutions with C %% 8 == 0 only (%dx%d, stride %d, C %d)", d->R, d->S,
-             d->stride, d->C);
+  if (!dgrad_bnred_covers(d))
+    ASM_FAIL(ASM_ENOTSUP, "conv dgrad_bnred: 1x1 stride-1 layers, and the 3x3 stride-1 layers of the igemm8 / igemm3 kernels, with "
+             "C %% 8 == 0 only (%dx%d, stride %d, C %d)", d->R, d->S, d->stride, d->C);
   const BnRed r = {bn_y, bn_relu_mask, partial};
   return dgrad_impl(d, dy, wt, addend, addend_mask, dx, stream, nullptr, &r);
 }

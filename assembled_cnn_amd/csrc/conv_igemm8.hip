@@ -54,7 +54,7 @@ struct IC {
   static constexpr int value = N;
 };
 
-template <bool STATS, bool PFA>
+template <bool STATS, bool PFA, bool BNRED = false>
 __global__ __launch_bounds__(512) void igemm8_kernel(IGemmArgs p) {
   using C = Cfg<256, 256, 64, 2, 4, false, STATS, 2>;
   constexpr int ROWB = 128, HALF = 128 * ROWB, TILE = 4 * HALF;
@@ -251,15 +251,15 @@ __global__ __launch_bounds__(512) void igemm8_kernel(IGemmArgs p) {
   if (wm == 0) __builtin_amdgcn_s_barrier();      // group 0 waits for group 1's last phase
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the zero-fill DMA of the steps past the end
   __syncthreads();                                 // the epilogue reuses the region
-  igemm_epilogue<C, 256, 256, 128, 64, 4, 2, false, STATS, PFA, false, true>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
+  igemm_epilogue<C, 256, 256, 128, 64, 4, 2, false, STATS, PFA, false, true, BNRED, 8>(p, acc, smem, tile_m, tile_n, tid, wm, wn, l31, lhi);
 }
 
-template <bool STATS, bool PFA>
+template <bool STATS, bool PFA, bool BNRED = false>
 int launch8_one(const IGemmArgs& a, hipStream_t st) {
   using C = Cfg<256, 256, 64, 2, 4, false, STATS, 2>;
   constexpr int LDS = cmax(cmax(2 * 4 * 128 * 128, C::EPI), C::RED);
   static_assert(LDS <= 160 * 1024, "lds");
-  auto kern = igemm8_kernel<STATS, PFA>;
+  auto kern = igemm8_kernel<STATS, PFA, BNRED>;
   static bool attr_done[ASM_MAX_DEVICES] = {};
   if (hipError_t e = asm_ensure_dyn_lds(kern, LDS, attr_done); e != hipSuccess)
     ASM_FAIL(ASM_EHIP, "igemm8_kernel: dynamic LDS opt-in: %s", hipGetErrorString(e));
@@ -271,19 +271,25 @@ int launch8_one(const IGemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// is the layer one igemm8_kernel covers?
+bool asm_igemm8_covers(const IGemmArgs& a, bool out_f32) {
+  if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.pool_dy) return false;
+  if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return false;
+  if (a.Ci % 64 || a.Co % 8) return false;
+  const long long span = (long long)a.x_bytes + 2ll * (a.x_row_pitch + a.x_pix_pitch);
+  return span < (long long)ASM_OOB;
+}
+
 // returns 1 when the layer is not one igemm8_kernel covers (the caller goes on to igemm3 / igemm2)
 int asm_igemm8_try(IGemmArgs& a, bool out_f32, bool stats, hipStream_t st) {
-  if (out_f32 || a.R != 3 || a.S != 3 || a.so != 1 || a.sd != 1 || a.y_strided || a.pool_dy) return 1;
-  if (!((a.tsign > 0 && a.pad == 1 && a.pad_w == 1) || (a.tsign < 0 && a.pad == -1 && a.pad_w == -1))) return 1;
-  if (a.Ci % 64 || a.Co % 8) return 1;
-  const long long span = (long long)a.x_bytes + 2ll * (a.x_row_pitch + a.x_pix_pitch);
-  if (span >= (long long)ASM_OOB) return 1;
+  if (!asm_igemm8_covers(a, out_f32)) return 1;
   a.n_tiles_n = cdiv(a.Co, 256);
   a.n_blocks = cdiv(a.M, 256) * a.n_tiles_n;
   a.kchunks = a.Ci / 64;
   a.fd_ntn = make_fastdiv((unsigned)a.n_tiles_n);
   const int pfa_env = asm_tune().igemm_pfa;
   const bool pfa = a.addend != nullptr && (pfa_env >= 0 ? pfa_env != 0 : true);
+  if (stats && a.red_y) return launch8_one<true, false, true>(a, st);   // the batch-norm backward sums of an input gradient
   if (stats) return launch8_one<true, false>(a, st);
   if (pfa) return launch8_one<false, true>(a, st);
   return launch8_one<false, false>(a, st);

@@ -98,8 +98,12 @@ struct Cfg {
 // BNRED (with STATS; asm_conv2d_dgrad_bnred): the statistics partials are the batch-norm BACKWARD sums (sum dz, sum dz * y) of the
 // gradient this launch writes (IGemmArgs::red_y).  A separate instantiation: as a run-time branch in the statistics epilogue it
 // took the forward kernels from 60 to 152 VGPRs (4 -> 2 waves per SIMD) and the 1x1 class from 7.6 to 8.5 ms per step.
+// RPF (BNRED): how many output passes ahead the y vectors and mask bytes of the batch-norm sums are fetched.  1 for the
+// bandwidth-bound 1x1 kernels (registers are occupancy there); 8 for the MFMA kernels, whose accumulators are dead once they are
+// in LDS: with one load in flight per lane every pass of the epilogue is a dependent HBM round trip (8 - 16 per workgroup), which
+// is what made the 3x3 form cost what it saved when it was first measured.
 template <class C, int BM, int BN, int WTM, int WTN, int TM, int TN, bool OUT_F32, bool STATS, bool PFA = false, bool POOL = false,
-          bool SPLIT8 = false, bool BNRED = false>
+          bool SPLIT8 = false, bool BNRED = false, int RPF = 1>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[TN][TM], unsigned char* smem,
                                                int tile_m, int tile_n, int tid, int wm, int wn, int l31, int lhi,
                                                int patch_base = -1) {
@@ -252,9 +256,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[q][e] = ss[q][e] = 0.f;
     static_assert(!BNRED || STATS, "the batch-norm backward sums use the statistics epilogue");
-    // batch-norm backward sums (BNRED, p.red_y): this thread's y vector and ReLU-mask byte of pass ps, fetched one pass ahead
-    u32x4 ry_nxt = {0u, 0u, 0u, 0u};
-    unsigned rmk_nxt = 0xffu;
+    // batch-norm backward sums (BNRED, p.red_y): this thread's y vector and ReLU-mask byte of pass ps, fetched RD passes ahead
+    constexpr int RD = !BNRED ? 1 : (RPF < OP ? RPF : OP);
+    u32x4 ryv[RD];
+    unsigned rmkv[RD];
     auto red_fetch = [&](int ps_, u32x4& yv, unsigned& mk) {
       const int row = ps_ * RPO + orow;
       const int m = tile_m * BM + row;
@@ -267,7 +272,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         if (p.red_mask) mk = (unsigned)p.red_mask[ro >> 3];
       }
     };
-    if constexpr (BNRED) red_fetch(0, ry_nxt, rmk_nxt);
+    if constexpr (BNRED) {
+#pragma unroll
+      for (int i = 0; i < RD; ++i) red_fetch(i, ryv[i], rmkv[i]);
+    }
 #pragma unroll
     for (int ps = 0; ps < OP; ++ps) {
       if constexpr (PF_ON) {
@@ -278,10 +286,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
       }
       const int row = ps * RPO + orow;
       const int m = tile_m * BM + row;
-      u32x4 ry = ry_nxt;
-      unsigned rmk = rmk_nxt;
+      u32x4 ry = ryv[ps % RD];
+      unsigned rmk = rmkv[ps % RD];
       if constexpr (BNRED) {
-        if (ps + 1 < OP) red_fetch(ps + 1, ry_nxt, rmk_nxt);   // one pass ahead: lands under this pass's stores
+        if (ps + RD < OP) red_fetch(ps + RD, ryv[ps % RD], rmkv[ps % RD]);   // RD passes ahead: lands under the passes between
       }
       u32x4 v = *reinterpret_cast<const u32x4*>(os + row * LDO + oc * 16);
       if (m < p.M && n0 < co8) {

@@ -305,11 +305,15 @@ def dgrad_s2_ok(d: ConvDesc) -> bool:
 
 
 def dgrad_bnred_ok(d: ConvDesc) -> bool:
-  """should this layer's input gradient reduce the batch-norm backward sums of its input (asm_conv2d_dgrad_bnred)?  1x1 stride-1
-  layers with C % 8 == 0 (the block-final batch norms, 4 x the channels of the others; in the MFMA-bound 3x3 input gradients
-  the extra epilogue reads cost what the reduce pass they replace costs).  ASM_BN_RED=0: never"""
-  return (knob('ASM_BN_RED', '1') != '0' and d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0 and d.C % 8 == 0
-          and not _is_dense(d))
+  """should this layer's input gradient reduce the batch-norm backward sums of its input (asm_conv2d_dgrad_bnred)?  Whatever the
+  library covers (asm_conv2d_dgrad_bnred_blocks > 0): the 1x1 stride-1 layers and the 3x3 stride-1 layers of its igemm8 / igemm3
+  kernels.  ASM_BN_RED=0: never; ASM_BN_RED=1x1: the 1x1 layers only (round 6 A/B)"""
+  mode = knob('ASM_BN_RED', '1')
+  if mode == '0' or _is_dense(d) or d.stride != 1 or d.C % 8:
+    return False
+  if mode == '1x1' and d.R != 1:
+    return False
+  return L().asm_conv2d_dgrad_bnred_blocks(C.byref(d)) > 0
 
 
 def conv_dgrad_bnred(d: ConvDesc, dy: torch.Tensor, wt: torch.Tensor, addend, addend_mask, bn_y: torch.Tensor, bn_mask):

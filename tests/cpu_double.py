@@ -224,14 +224,28 @@ class CpuDouble(object):
   def asm_conv2d_dgrad_masked(self, d, dy, wt, addend, addend_mask, dx, stream):
     return self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream, addend_mask)
 
+  @staticmethod
+  def _bnred_covers(d):
+    """the layers asm_conv2d_dgrad_bnred covers on the GPU side, as far as a host test can tell: every 1x1 stride-1 layer, and the
+    3x3 stride-1 pad-1 layers with K % 64 == 0 and more than 64 input channels (igemm3 / igemm8 territory)"""
+    if d.stride != 1 or d.C % 8:
+      return False
+    if d.R == 1 and d.S == 1 and d.pad == 0:
+      return True
+    if not (d.R == 3 and d.S == 3 and d.pad == 1):
+      return False
+    if d.C in (32, 64) and d.K in (32, 64) and d.H % 8 == 0 and d.W % 16 == 0:      # conv_halo_kernel: not there
+      return False
+    return d.K % 64 == 0 and d.C > 64
+
   def asm_conv2d_dgrad_bnred_blocks(self, d):
     d = _desc(d)
-    return (d.N * d.H * d.W + 127) // 128
+    return (d.N * d.H * d.W + 127) // 128 if self._bnred_covers(d) else 0
 
   def asm_conv2d_dgrad_bnred(self, d, dy, wt, addend, addend_mask, bn_y, bn_mask, partial, dx, stream):
     dd = _desc(d)
-    if dd.R != 1 or dd.S != 1 or dd.stride != 1 or dd.pad != 0 or dd.C % 8:
-      self._err = b'conv dgrad_bnred: 1x1 stride-1 convolutions with C % 8 == 0 only'
+    if not self._bnred_covers(dd):
+      self._err = b'conv dgrad_bnred: layer not covered'
       return -2
     rc = self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream, addend_mask) if addend_mask else \
         self.asm_conv2d_dgrad(d, dy, wt, addend, dx, stream)

@@ -685,13 +685,18 @@ BNRED_CASES = [
     (256, 14, 14, 512, 128, 1, {}),                           # a workload shape: igemm1 (configuration from the table)
     (3, 9, 11, 264, 72, 1, {}),                               # ragged rows, a channel tail in the third N tile
     (2, 9, 11, 72, 40, 1, {'ASM_IGEMM_MODE': '1'}),           # the general kernel, channel tails
+    (2, 14, 14, 128, 256, 3, {}),                             # 3x3 on igemm3_kernel: 4 chunks, ragged last row tile
+    (3, 7, 7, 192, 128, 3, {}),                               # igemm3, two chunks, M = 147 (two row tiles, the second ragged)
+    (2, 28, 28, 128, 64, 3, {}),                              # igemm3's single-chunk form (one halo buffer)
+    (24, 14, 14, 512, 256, 3, {'ASM_IGEMM8': '2'}),           # igemm8_kernel (forced): 19 row tiles, two column tiles
+    (3, 7, 7, 448, 192, 3, {'ASM_IGEMM8': '2'}),              # igemm8, M = 147 < one tile, N tail 192 of 256 ... 3 chunks
 ]
 
 
 @pytest.mark.parametrize('case', BNRED_CASES, ids=lambda c: 'x'.join(map(str, c[:6])))
 @pytest.mark.parametrize('relu', [True, False])
 def test_dgrad_with_bn_backward_sums_in_its_epilogue(hip_lib, case, relu, monkeypatch):
-  """asm_conv2d_dgrad_bnred: the input gradient that also reduces (sum dz, sum dz * y) of the batch norm behind its output (1x1 layers).
+  """asm_conv2d_dgrad_bnred: the input gradient that also reduces (sum dz, sum dz * y) of the batch norm behind its output (1x1 layers, and 3x3 layers on igemm3 / igemm8).
   dx must be the bits asm_conv2d_dgrad[_masked] writes; the partial rows must sum to the sums of the bf16 dx it wrote; and
   the batch-norm backward finished from them (asm_bn_bwd_finalize_raw + apply) must agree with the three-pass form
   (reduce over (dx, y) + finalize + apply): dgamma / dbeta to 1e-3, dy rel-L2 <= 2e-3."""
@@ -739,7 +744,12 @@ def test_dgrad_with_bn_backward_sums_in_its_epilogue(hip_lib, case, relu, monkey
 
 
 def test_dgrad_bnred_refuses_what_it_does_not_cover(hip_lib):
+  """3x3 layers outside igemm8 / igemm3 (64 or fewer output channels of the gradient; stride 2) have no kernel with the sums"""
   from assembled_cnn_amd import ops
-  d = ops.make_conv_desc(2, 8, 8, 64, 64, 3, 3, 1)
-  assert hip_lib.asm_conv2d_dgrad_bnred(C.byref(d), 1, 1, None, None, 1, None, 1, 1, None) == -2      # ASM_ENOTSUP before any pointer is touched
-  assert not ops.dgrad_bnred_ok(d)
+  for d in (ops.make_conv_desc(2, 16, 32, 64, 32, 3, 3, 1), ops.make_conv_desc(2, 9, 9, 64, 64, 3, 3, 1),
+            ops.make_conv_desc(2, 16, 16, 128, 128, 3, 3, 2),
+            ops.make_conv_desc(2, 8, 8, 128, 72, 3, 3, 1)):
+    assert hip_lib.asm_conv2d_dgrad_bnred_blocks(C.byref(d)) == 0
+    assert hip_lib.asm_conv2d_dgrad_bnred(C.byref(d), 1, 1, None, None, 1, None, 1, 1, None) == -2    # ASM_ENOTSUP before any pointer is touched
+    assert not ops.dgrad_bnred_ok(d)
+  assert ops.dgrad_bnred_ok(ops.make_conv_desc(2, 14, 14, 128, 256, 3, 3, 1))
