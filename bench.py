@@ -54,8 +54,8 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
-PMC_FILE = 'round6_e_pmc_traffic.json'        # dominant layer, tools/conv_bench.py in isolation (round 6, tools/profile_round.sh dominant)
-CLASS_TRAFFIC_FILE = 'round6_e_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
+PMC_FILE = 'round6_f_pmc_traffic.json'        # dominant layer, tools/conv_bench.py in isolation (round 6, tools/profile_round.sh dominant)
+CLASS_TRAFFIC_FILE = 'round6_f_step_class_traffic.json'   # per-class HBM bytes per step from --pmc passes of bench.py itself
 HBM_PEAK_GBS = 8000.0            # spec; MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {
